@@ -1,0 +1,662 @@
+/*
+ * bsw_api.hip — host side of libbwasw_mi355.so: context, batch manager, C ABI.
+ *
+ * Plays the role of the reference's batch_manager.v + tbb.v + rbb.v (CSR/DSM handshake,
+ * 256 KiB task batches in, 16 KiB result batches out, round-robin over 4 PE arrays:
+ * batch_manager.v:358-739) on top of the HIP runtime: tasks are binned by the number of
+ * eh[] columns a lane must hold, packed 16 bases per uint64 into pinned staging, streamed
+ * with hipMemcpyAsync on several streams, and the kernels write results in task order.
+ * There is no CPU compute path here: every DP cell is evaluated by the HIP kernels.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bsw_device.h"
+
+namespace bsw {
+int wave_class_count();
+int wave_class_cols(int cls);
+hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
+                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
+}  // namespace bsw
+
+#define MAX_CLASSES 8
+
+struct bsw_ctx {
+    int device = 0;
+    bsw_config cfg{};
+    std::vector<hipStream_t> streams;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    std::string err;
+    /* async submit */
+    std::thread worker;
+    bool worker_active = false;
+    int worker_rc = 0;
+};
+
+struct bsw_dev_batch {
+    uint64_t n = 0;
+    bsw_dparams P{};
+    int variant = 0;
+    uint64_t *d_seq = nullptr;
+    bsw_dtask *d_tasks = nullptr;
+    uint32_t *d_order = nullptr;
+    bsw_result *d_out = nullptr;
+    uint64_t seq_words = 0;
+    uint32_t cls_start[MAX_CLASSES + 1] = {0};
+    uint64_t launches = 0;
+};
+
+static int fail(bsw_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, BSW_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+/* ------------------------------------------------------------------------- */
+extern "C" void bsw_default_params(bsw_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 5; ++j) p->mat[i * 5 + j] = (i == 4 || j == 4) ? -1 : (i == j ? 1 : -4);
+    p->o_del = p->o_ins = 6;
+    p->e_del = p->e_ins = 1;
+    p->w = 100;
+    p->pen_clip5 = p->pen_clip3 = 5;
+    p->zdrop = 100;
+    p->max_band_try = 2;
+    p->variant = BSW_VARIANT_H;
+}
+
+extern "C" void bsw_default_config(bsw_config *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->device = 0;
+    c->kernel = BSW_KERNEL_AUTO;
+    c->streams = 2;
+    c->pack_threads = 4;
+    c->chunk_tasks = 65536;
+}
+
+extern "C" int bsw_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, d) == hipSuccess && strncmp(pr.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+extern "C" const char *bsw_last_error(const bsw_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
+{
+    if (!out) return BSW_E_INVAL;
+    *out = nullptr;
+    bsw_config c;
+    if (cfg) c = *cfg; else bsw_default_config(&c);
+    if (c.streams < 1) c.streams = 2;
+    if (c.streams > 8) c.streams = 8;
+    if (c.pack_threads < 1) c.pack_threads = 1;
+    if (c.chunk_tasks == 0) c.chunk_tasks = 65536;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fprintf(stderr, "libbwasw_mi355: no HIP device visible — this library has no CPU path\n");
+        return BSW_E_NODEVICE;
+    }
+    if (c.device < 0 || c.device >= n) return BSW_E_INVAL;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, c.device) != hipSuccess) return BSW_E_HIP;
+    if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "libbwasw_mi355: device %d is %s, kernels are built for gfx950 only\n", c.device, pr.gcnArchName);
+        return BSW_E_NODEVICE;
+    }
+    bsw_ctx *ctx = new bsw_ctx();
+    ctx->device = c.device;
+    ctx->cfg = c;
+    if (hipSetDevice(c.device) != hipSuccess) { delete ctx; return BSW_E_HIP; }
+    ctx->streams.resize((size_t)c.streams);
+    for (auto &s : ctx->streams)
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BSW_E_HIP; }
+    if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) { delete ctx; return BSW_E_HIP; }
+    *out = ctx;
+    return BSW_OK;
+}
+
+extern "C" void bsw_destroy(bsw_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->worker_active && ctx->worker.joinable()) ctx->worker.join();
+    (void)hipSetDevice(ctx->device);
+    for (auto s : ctx->streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    delete ctx;
+}
+
+/* ---- validation + packing -------------------------------------------------- */
+static int check_params(bsw_ctx *ctx, const bsw_params *p, bsw_dparams *dp)
+{
+    if (!p) return fail(ctx, BSW_E_INVAL, "params is NULL");
+    if (p->e_del < 1 || p->e_ins < 1 || p->o_del < 0 || p->o_ins < 0)
+        return fail(ctx, BSW_E_INVAL, "need e_del,e_ins >= 1 and o_del,o_ins >= 0");
+    if (p->w < 0 || p->w > (1 << 20) || p->max_band_try > 8) return fail(ctx, BSW_E_INVAL, "band out of range");
+    if (p->variant != BSW_VARIANT_H && p->variant != BSW_VARIANT_M) return fail(ctx, BSW_E_INVAL, "bad variant");
+    if (p->o_del + p->e_del > 4096 || p->o_ins + p->e_ins > 4096) return fail(ctx, BSW_E_LIMIT, "gap penalties too large");
+    memset(dp, 0, sizeof(*dp));
+    memcpy(dp->mat, p->mat, 25);
+    dp->o_del = p->o_del; dp->e_del = p->e_del; dp->o_ins = p->o_ins; dp->e_ins = p->e_ins;
+    dp->w = p->w; dp->pen_clip5 = p->pen_clip5; dp->pen_clip3 = p->pen_clip3; dp->zdrop = p->zdrop;
+    dp->max_band_try = p->max_band_try > 0 ? p->max_band_try : 1;
+    return BSW_OK;
+}
+
+static inline int mat_max(const int8_t *mat)
+{
+    int mx = 0;                                  /* bwa starts the scan at 0 */
+    for (int i = 0; i < 25; ++i) mx = mx > mat[i] ? mx : mat[i];
+    return mx;
+}
+
+/* min(max_ins, max_del): the longest useful gap (sw_pe_array_proc_element.v:925,933 H5/H6);
+ * integer form of (int)((double)(qlen*max+end_bonus-o)/e + 1.) */
+static inline int gap_limit(const bsw_params *p, int mx, int qlen, int end_bonus)
+{
+    int mi = (qlen * mx + end_bonus - p->o_ins + p->e_ins) / p->e_ins;
+    int md = (qlen * mx + end_bonus - p->o_del + p->e_del) / p->e_del;
+    if (mi < 1) mi = 1;
+    if (md < 1) md = 1;
+    int l = mi < md ? mi : md;
+    return l > 65535 ? 65535 : l;
+}
+
+static inline size_t nwords(int len) { return (size_t)((len + 15) >> 4); }
+
+static void pack_seq(const uint8_t *s, int len, uint64_t *dst)
+{
+    const int nw = (len + 15) >> 4;
+    for (int w = 0; w < nw; ++w) {
+        uint64_t v = 0;
+        const int lo = w << 4, hi = lo + 16 < len ? lo + 16 : len;
+        for (int k = lo; k < hi; ++k) {
+            const uint64_t b = s[k] > 4 ? 4 : s[k];
+            v |= b << ((k - lo) * 4);
+        }
+        dst[w] = v;
+    }
+}
+
+struct packed_host {
+    std::vector<uint64_t> seq;
+    std::vector<bsw_dtask> tasks;
+    std::vector<uint32_t> order;
+    uint32_t cls_start[MAX_CLASSES + 1];
+};
+
+static int task_class(int qmax)
+{
+    const int nc = bsw::wave_class_count();
+    for (int c = 0; c < nc; ++c)
+        if (qmax + 1 <= bsw::wave_class_cols(c)) return c;
+    return -1;
+}
+
+/* validate, lay out and pack tasks[0..n) — `threads` host threads do the nibble packing */
+static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, int threads,
+                      uint64_t *seq_dst /* may be NULL: use ph.seq */, size_t seq_cap, packed_host &ph,
+                      bsw_dtask *task_dst, uint32_t *order_dst, size_t *seq_words_out)
+{
+    const int mx = mat_max(p->mat);
+    std::vector<uint64_t> off(n + 1);
+    std::vector<uint8_t> cls(n);
+    uint32_t count[MAX_CLASSES] = {0};
+    uint64_t acc = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_task &t = tasks[i];
+        if (t.lqlen < 0 || t.rqlen < 0 || t.ltlen < 0 || t.rtlen < 0)
+            return fail(ctx, BSW_E_INVAL, "task %zu: negative length", i);
+        if (t.lqlen > BSW_MAX_QLEN || t.rqlen > BSW_MAX_QLEN || t.ltlen > BSW_MAX_TLEN || t.rtlen > BSW_MAX_TLEN)
+            return fail(ctx, BSW_E_LIMIT, "task %zu: length beyond BSW_MAX_QLEN/BSW_MAX_TLEN", i);
+        if (t.h0 <= 0) return fail(ctx, BSW_E_INVAL, "task %zu: h0 must be > 0", i);
+        if ((int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * mx >= BSW_MAX_SCORE)
+            return fail(ctx, BSW_E_LIMIT, "task %zu: score range beyond BSW_MAX_SCORE", i);
+        if ((t.lqlen && (!t.lquery || (t.ltlen && !t.ltarget))) || (t.rqlen && (!t.rquery || (t.rtlen && !t.rtarget))))
+            return fail(ctx, BSW_E_INVAL, "task %zu: NULL sequence pointer", i);
+        const int c = task_class(t.lqlen > t.rqlen ? t.lqlen : t.rqlen);
+        if (c < 0) return fail(ctx, BSW_E_LIMIT, "task %zu: no kernel class", i);
+        cls[i] = (uint8_t)c;
+        ++count[c];
+        off[i] = acc;
+        acc += (t.lqlen ? nwords(t.lqlen) + nwords(t.ltlen) : 0) + (t.rqlen ? nwords(t.rqlen) + nwords(t.rtlen) : 0);
+    }
+    off[n] = acc;
+    if (acc >= (1ull << 32)) return fail(ctx, BSW_E_LIMIT, "batch sequence arena beyond 2^32 words; split the batch");
+    uint64_t *seq = seq_dst;
+    if (!seq) { ph.seq.assign((size_t)acc + 1, 0); seq = ph.seq.data(); }
+    else if (acc > seq_cap) return fail(ctx, BSW_E_NOMEM, "staging too small");
+    bsw_dtask *dt = task_dst;
+    if (!dt) { ph.tasks.resize(n); dt = ph.tasks.data(); }
+    uint32_t *ord = order_dst;
+    if (!ord) { ph.order.resize(n ? n : 1); ord = ph.order.data(); }
+
+    /* counting sort by class -> launch order */
+    uint32_t pos[MAX_CLASSES];
+    ph.cls_start[0] = 0;
+    for (int c = 0; c < MAX_CLASSES; ++c) ph.cls_start[c + 1] = ph.cls_start[c] + count[c];
+    for (int c = 0; c < MAX_CLASSES; ++c) pos[c] = ph.cls_start[c];
+    for (size_t i = 0; i < n; ++i) ord[pos[cls[i]]++] = (uint32_t)i;
+
+    auto work = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const bsw_task &t = tasks[i];
+            bsw_dtask &d = dt[i];
+            uint64_t o = off[i];
+            memset(&d, 0, sizeof(d));
+            if (t.lqlen) {
+                d.lq_off = (uint32_t)o; pack_seq(t.lquery, t.lqlen, seq + o); o += nwords(t.lqlen);
+                d.lt_off = (uint32_t)o; pack_seq(t.ltarget, t.ltlen, seq + o); o += nwords(t.ltlen);
+            }
+            if (t.rqlen) {
+                d.rq_off = (uint32_t)o; pack_seq(t.rquery, t.rqlen, seq + o); o += nwords(t.rqlen);
+                d.rt_off = (uint32_t)o; pack_seq(t.rtarget, t.rtlen, seq + o); o += nwords(t.rtlen);
+            }
+            d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
+            d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
+            d.wlim_l = (uint16_t)gap_limit(p, mx, t.lqlen, p->pen_clip5);
+            d.wlim_r = (uint16_t)gap_limit(p, mx, t.rqlen, p->pen_clip3);
+            d.h0 = t.h0; d.init_score = t.init_score; d.qbeg = t.qbeg; d.tag = t.tag;
+        }
+    };
+    if (threads <= 1 || n < 4096) work(0, n);
+    else {
+        std::vector<std::thread> th;
+        const size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+        for (int k = 0; k < threads; ++k) {
+            const size_t lo = per * (size_t)k, hi = std::min(n, lo + per);
+            if (lo < hi) th.emplace_back(work, lo, hi);
+        }
+        for (auto &t : th) t.join();
+    }
+    if (seq_words_out) *seq_words_out = (size_t)acc;
+    return BSW_OK;
+}
+
+/* ---- device-resident batches ------------------------------------------------ */
+extern "C" void bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b)
+{
+    if (!b) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (b->d_seq) (void)hipFree(b->d_seq);
+    if (b->d_tasks) (void)hipFree(b->d_tasks);
+    if (b->d_order) (void)hipFree(b->d_order);
+    if (b->d_out) (void)hipFree(b->d_out);
+    delete b;
+}
+
+extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out)
+{
+    if (!ctx || !out || (!tasks && n)) return fail(ctx, BSW_E_INVAL, "bsw_upload: NULL argument");
+    *out = nullptr;
+    if (n >= (1ull << 32)) return fail(ctx, BSW_E_LIMIT, "more than 2^32-1 tasks in one batch");
+    bsw_dparams dp;
+    int rc = check_params(ctx, p, &dp);
+    if (rc) return rc;
+    packed_host ph;
+    size_t words = 0;
+    rc = pack_tasks(ctx, p, tasks, n, ctx->cfg.pack_threads, nullptr, 0, ph, nullptr, nullptr, &words);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    bsw_dev_batch *b = new bsw_dev_batch();
+    b->n = n; b->P = dp; b->variant = p->variant; b->seq_words = words;
+    memcpy(b->cls_start, ph.cls_start, sizeof(b->cls_start));
+    hipError_t e = hipSuccess;
+    if ((e = hipMalloc((void **)&b->d_seq, (words + 1) * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&b->d_tasks, (n + 1) * sizeof(bsw_dtask))) != hipSuccess ||
+        (e = hipMalloc((void **)&b->d_order, (n + 1) * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&b->d_out, (n + 1) * sizeof(bsw_result))) != hipSuccess) {
+        bsw_free_batch(ctx, b);
+        return fail(ctx, BSW_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    hipStream_t s = ctx->streams[0];
+    if ((e = hipMemcpyAsync(b->d_seq, ph.seq.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, s)) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_tasks, ph.tasks.data(), n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s)) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_order, ph.order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s)) != hipSuccess ||
+        (e = hipMemsetAsync(b->d_out, 0xff, n * sizeof(bsw_result), s)) != hipSuccess ||
+        (e = hipStreamSynchronize(s)) != hipSuccess) {
+        bsw_free_batch(ctx, b);
+        return fail(ctx, BSW_E_HIP, "upload: %s", hipGetErrorString(e));
+    }
+    *out = b;
+    return BSW_OK;
+}
+
+static int enqueue_batch(bsw_ctx *ctx, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
+                         const uint32_t *d_order, const uint32_t *cls_start, bsw_result *d_out, hipStream_t s, uint64_t *launches)
+{
+    const int nc = bsw::wave_class_count();
+    for (int c = 0; c < nc; ++c) {
+        const uint32_t cnt = cls_start[c + 1] - cls_start[c];
+        if (!cnt) continue;
+        HIPCHK(ctx, bsw::launch_wave(c, variant, P, d_seq, d_tasks, d_order + cls_start[c], cnt, d_out, s));
+        if (launches) ++*launches;
+    }
+    return BSW_OK;
+}
+
+extern "C" int bsw_run(bsw_ctx *ctx, bsw_dev_batch *b)
+{
+    if (!ctx || !b) return fail(ctx, BSW_E_INVAL, "bsw_run: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->streams[0];
+    HIPCHK(ctx, hipEventRecord(ctx->ev_start, s));
+    b->launches = 0;
+    int rc = enqueue_batch(ctx, b->P, b->variant, b->d_seq, b->d_tasks, b->d_order, b->cls_start, b->d_out, s, &b->launches);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_stop, s));
+    ctx->timed = true;
+    return BSW_OK;
+}
+
+extern "C" int bsw_sync(bsw_ctx *ctx)
+{
+    if (!ctx) return BSW_E_INVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (auto s : ctx->streams) HIPCHK(ctx, hipStreamSynchronize(s));
+    return BSW_OK;
+}
+
+extern "C" int bsw_last_run_ms(bsw_ctx *ctx, float *ms)
+{
+    if (!ctx || !ms || !ctx->timed) return BSW_E_INVAL;
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_stop));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return BSW_OK;
+}
+
+extern "C" int bsw_download(bsw_ctx *ctx, bsw_dev_batch *b, bsw_result *out)
+{
+    if (!ctx || !b || (!out && b->n)) return fail(ctx, BSW_E_INVAL, "bsw_download: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->streams[0]));
+    HIPCHK(ctx, hipMemcpy(out, b->d_out, b->n * sizeof(bsw_result), hipMemcpyDeviceToHost));
+    return BSW_OK;
+}
+
+extern "C" int bsw_batch_info(const bsw_dev_batch *b, uint64_t *n_tasks, uint64_t *in_bytes, uint64_t *out_bytes, uint64_t *n_launches)
+{
+    if (!b) return BSW_E_INVAL;
+    if (n_tasks) *n_tasks = b->n;
+    if (in_bytes) *in_bytes = b->seq_words * 8 + b->n * (sizeof(bsw_dtask) + sizeof(uint32_t));
+    if (out_bytes) *out_bytes = b->n * sizeof(bsw_result);
+    if (n_launches) *n_launches = b->launches;
+    return BSW_OK;
+}
+
+/* ---- streaming submit: pinned double buffering over several streams ----------- */
+struct slot_t {
+    uint64_t *h_seq = nullptr, *d_seq = nullptr; size_t seq_cap = 0;
+    bsw_dtask *h_tasks = nullptr, *d_tasks = nullptr;
+    uint32_t *h_order = nullptr, *d_order = nullptr;
+    bsw_result *h_out = nullptr, *d_out = nullptr;
+    size_t task_cap = 0;
+    size_t base = 0, cnt = 0;       /* chunk in flight */
+    bool busy = false;
+};
+
+static void slot_free(slot_t &s)
+{
+    if (s.h_seq) (void)hipHostFree(s.h_seq);
+    if (s.d_seq) (void)hipFree(s.d_seq);
+    if (s.h_tasks) (void)hipHostFree(s.h_tasks);
+    if (s.d_tasks) (void)hipFree(s.d_tasks);
+    if (s.h_order) (void)hipHostFree(s.h_order);
+    if (s.d_order) (void)hipFree(s.d_order);
+    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.d_out) (void)hipFree(s.d_out);
+    s = slot_t();
+}
+
+static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, size_t n, bsw_result *out)
+{
+    bsw_dparams dp;
+    int rc = check_params(ctx, &p, &dp);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t chunk = ctx->cfg.chunk_tasks;
+    const size_t nslots = ctx->streams.size();
+    std::vector<slot_t> slots(nslots);
+    auto cleanup = [&]() { for (auto &s : slots) slot_free(s); };
+    auto drain = [&](size_t k) -> int {
+        slot_t &s = slots[k];
+        if (!s.busy) return BSW_OK;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->streams[k]));
+        memcpy(out + s.base, s.h_out, s.cnt * sizeof(bsw_result));
+        s.busy = false;
+        return BSW_OK;
+    };
+    size_t ci = 0;
+    for (size_t base = 0; base < n; base += chunk, ++ci) {
+        const size_t k = ci % nslots, cnt = std::min(chunk, n - base);
+        slot_t &s = slots[k];
+        hipStream_t st = ctx->streams[k];
+        if ((rc = drain(k)) != BSW_OK) { cleanup(); return rc; }
+        /* size the slot */
+        size_t words = 0;
+        for (size_t i = base; i < base + cnt; ++i) {
+            const bsw_task &t = tasks[i];
+            if (t.lqlen < 0 || t.rqlen < 0 || t.ltlen < 0 || t.rtlen < 0) { cleanup(); return fail(ctx, BSW_E_INVAL, "task %zu: negative length", i); }
+            words += (t.lqlen ? nwords(t.lqlen) + nwords(t.ltlen) : 0) + (t.rqlen ? nwords(t.rqlen) + nwords(t.rtlen) : 0);
+        }
+        hipError_t e = hipSuccess;
+        if (s.seq_cap < words + 1) {
+            if (s.h_seq) (void)hipHostFree(s.h_seq);
+            if (s.d_seq) (void)hipFree(s.d_seq);
+            s.seq_cap = (words + 1) * 5 / 4;
+            if ((e = hipHostMalloc((void **)&s.h_seq, s.seq_cap * 8, hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&s.d_seq, s.seq_cap * 8)) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_NOMEM, "staging: %s", hipGetErrorString(e)); }
+        }
+        if (s.task_cap < cnt) {
+            if (s.h_tasks) { (void)hipHostFree(s.h_tasks); (void)hipFree(s.d_tasks); (void)hipHostFree(s.h_order); (void)hipFree(s.d_order); (void)hipHostFree(s.h_out); (void)hipFree(s.d_out); }
+            s.task_cap = std::max(cnt, chunk);
+            if ((e = hipHostMalloc((void **)&s.h_tasks, s.task_cap * sizeof(bsw_dtask), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&s.d_tasks, s.task_cap * sizeof(bsw_dtask))) != hipSuccess ||
+                (e = hipHostMalloc((void **)&s.h_order, s.task_cap * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&s.d_order, s.task_cap * sizeof(uint32_t))) != hipSuccess ||
+                (e = hipHostMalloc((void **)&s.h_out, s.task_cap * sizeof(bsw_result), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&s.d_out, s.task_cap * sizeof(bsw_result))) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_NOMEM, "staging: %s", hipGetErrorString(e)); }
+        }
+        packed_host ph;
+        size_t w2 = 0;
+        rc = pack_tasks(ctx, &p, tasks + base, cnt, ctx->cfg.pack_threads, s.h_seq, s.seq_cap, ph, s.h_tasks, s.h_order, &w2);
+        if (rc) { cleanup(); return rc; }
+        if ((e = hipMemcpyAsync(s.d_seq, s.h_seq, w2 * 8, hipMemcpyHostToDevice, st)) != hipSuccess ||
+            (e = hipMemcpyAsync(s.d_tasks, s.h_tasks, cnt * sizeof(bsw_dtask), hipMemcpyHostToDevice, st)) != hipSuccess ||
+            (e = hipMemcpyAsync(s.d_order, s.h_order, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_HIP, "H2D: %s", hipGetErrorString(e)); }
+        rc = enqueue_batch(ctx, dp, p.variant, s.d_seq, s.d_tasks, s.d_order, ph.cls_start, s.d_out, st, nullptr);
+        if (rc) { cleanup(); return rc; }
+        if ((e = hipMemcpyAsync(s.h_out, s.d_out, cnt * sizeof(bsw_result), hipMemcpyDeviceToHost, st)) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_HIP, "D2H: %s", hipGetErrorString(e)); }
+        s.base = base; s.cnt = cnt; s.busy = true;
+    }
+    for (size_t k = 0; k < nslots; ++k)
+        if ((rc = drain(k)) != BSW_OK) { cleanup(); return rc; }
+    cleanup();
+    return BSW_OK;
+}
+
+extern "C" int bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out)
+{
+    if (!ctx || !p || (!tasks && n) || (!out && n)) return fail(ctx, BSW_E_INVAL, "bsw_submit: NULL argument");
+    if (ctx->worker_active) return fail(ctx, BSW_E_BUSY, "previous bsw_submit not waited for");
+    bsw_dparams dp;
+    int rc = check_params(ctx, p, &dp);
+    if (rc) return rc;
+    ctx->worker_active = true;
+    ctx->worker_rc = 0;
+    bsw_params pc = *p;
+    ctx->worker = std::thread([ctx, pc, tasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, tasks, n, out); });
+    return BSW_OK;
+}
+
+extern "C" int bsw_wait(bsw_ctx *ctx)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!ctx->worker_active) return BSW_OK;
+    if (ctx->worker.joinable()) ctx->worker.join();
+    ctx->worker_active = false;
+    return ctx->worker_rc;
+}
+
+/* ---- batched plain ksw_extend2 ------------------------------------------------ */
+extern "C" int bsw_extend_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_ext_task *tasks, size_t n, bsw_ext *out)
+{
+    if (!ctx || !p || (!tasks && n) || (!out && n)) return fail(ctx, BSW_E_INVAL, "bsw_extend_batch: NULL argument");
+    /* group by (w, end_bonus): each group is one pair-batch with only the right side populated,
+     * one band try, clip penalties = end_bonus (they only feed max_ins/max_del here). */
+    std::vector<uint32_t> idx(n);
+    for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+        if (tasks[a].w != tasks[b].w) return tasks[a].w < tasks[b].w;
+        return tasks[a].end_bonus < tasks[b].end_bonus;
+    });
+    size_t g0 = 0;
+    while (g0 < n) {
+        size_t g1 = g0;
+        while (g1 < n && tasks[idx[g1]].w == tasks[idx[g0]].w && tasks[idx[g1]].end_bonus == tasks[idx[g0]].end_bonus) ++g1;
+        bsw_params pp = *p;
+        pp.w = tasks[idx[g0]].w;
+        pp.pen_clip3 = pp.pen_clip5 = tasks[idx[g0]].end_bonus;
+        pp.max_band_try = 1;
+        std::vector<bsw_task> pt(g1 - g0);
+        for (size_t k = g0; k < g1; ++k) {
+            const bsw_ext_task &e = tasks[idx[k]];
+            bsw_task &t = pt[k - g0];
+            memset(&t, 0, sizeof(t));
+            if (e.qlen < 1) return fail(ctx, BSW_E_INVAL, "ext task %u: qlen must be >= 1", idx[k]);
+            t.rquery = e.query; t.rtarget = e.target; t.rqlen = e.qlen; t.rtlen = e.tlen;
+            t.h0 = e.h0; t.init_score = -1; t.tag = idx[k];
+        }
+        std::vector<bsw_result> res(g1 - g0);
+        bsw_dev_batch *b = nullptr;
+        int rc = bsw_upload(ctx, &pp, pt.data(), pt.size(), &b);
+        if (rc) return rc;
+        rc = bsw_run(ctx, b);
+        if (!rc) rc = bsw_download(ctx, b, res.data());
+        bsw_free_batch(ctx, b);
+        if (rc) return rc;
+        for (size_t k = g0; k < g1; ++k) {
+            out[idx[k]] = res[k - g0].right;
+            out[idx[k]].aw = tasks[idx[k]].w;
+        }
+        g0 = g1;
+    }
+    return BSW_OK;
+}
+
+/* ---- drop-in scalar ABI -------------------------------------------------------- */
+static std::mutex g_mu;
+static bsw_ctx *g_ctx = nullptr;
+static std::atomic<int> g_variant{BSW_VARIANT_H};
+
+extern "C" void bsw_set_default_variant(int variant) { g_variant = variant == BSW_VARIANT_M ? BSW_VARIANT_M : BSW_VARIANT_H; }
+
+extern "C" int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                           int o_del, int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0,
+                           int *qle, int *tle, int *gtle, int *gscore, int *max_off)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ctx) {
+        bsw_config c;
+        bsw_default_config(&c);
+        const char *dv = getenv("BSW_DEVICE");
+        if (dv) c.device = atoi(dv);
+        int rc = bsw_create(&c, &g_ctx);
+        if (rc) {
+            fprintf(stderr, "ksw_extend2(libbwasw_mi355): cannot create GPU context (%d); no CPU fallback exists\n", rc);
+            return -1;
+        }
+    }
+    if (m != 5 || !mat || !query || (tlen > 0 && !target)) {
+        fprintf(stderr, "ksw_extend2(libbwasw_mi355): unsupported arguments (m must be 5)\n");
+        return -1;
+    }
+    bsw_params p;
+    bsw_default_params(&p);
+    memcpy(p.mat, mat, 25);
+    p.o_del = o_del; p.e_del = e_del; p.o_ins = o_ins; p.e_ins = e_ins;
+    p.zdrop = zdrop; p.variant = g_variant;
+    bsw_ext_task t;
+    memset(&t, 0, sizeof(t));
+    t.query = query; t.target = target; t.qlen = qlen; t.tlen = tlen; t.w = w; t.end_bonus = end_bonus; t.h0 = h0;
+    bsw_ext x;
+    int rc = bsw_extend_batch(g_ctx, &p, &t, 1, &x);
+    if (rc) {
+        fprintf(stderr, "ksw_extend2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
+        return -1;
+    }
+    if (qle) *qle = x.qle;
+    if (tle) *tle = x.tle;
+    if (gtle) *gtle = x.gtle;
+    if (gscore) *gscore = x.gscore;
+    if (max_off) *max_off = x.max_off;
+    return x.score;
+}
+
+extern "C" int ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                          int gapo, int gape, int w, int end_bonus, int zdrop, int h0,
+                          int *qle, int *tle, int *gtle, int *gscore, int *max_off)
+{
+    return ksw_extend2(qlen, query, tlen, target, m, mat, gapo, gape, gapo, gape, w, end_bonus, zdrop, h0,
+                       qle, tle, gtle, gscore, max_off);
+}
+
+/* ---- reference wire format end to end ----------------------------------------- */
+extern "C" int bsw_refbatch_run(bsw_ctx *ctx, const uint32_t *in_words, uint32_t *out_words, int variant, int zdrop)
+{
+    if (!ctx || !in_words || !out_words) return fail(ctx, BSW_E_INVAL, "bsw_refbatch_run: NULL argument");
+    const uint32_t n = in_words[2];
+    if (n > BSW_REFBATCH_MAX_TASKS) return fail(ctx, BSW_E_LIMIT, "task batch announces %u tasks (> %d)", n, BSW_REFBATCH_MAX_TASKS);
+    bsw_params p;
+    std::vector<bsw_task> tasks(n ? n : 1);
+    std::vector<uint8_t> seqbuf((size_t)BSW_REFBATCH_IN_WORDS * 8 + 64);
+    int got = bsw_refbatch_decode(in_words, &p, tasks.data(), n, seqbuf.data(), seqbuf.size());
+    if (got < 0) return fail(ctx, got, "malformed task batch");
+    p.variant = variant; p.zdrop = zdrop;
+    std::vector<bsw_result> res((size_t)got ? (size_t)got : 1);
+    if (got) {
+        bsw_dev_batch *b = nullptr;
+        int rc = bsw_upload(ctx, &p, tasks.data(), (size_t)got, &b);
+        if (rc) return rc;
+        rc = bsw_run(ctx, b);
+        if (!rc) rc = bsw_download(ctx, b, res.data());
+        bsw_free_batch(ctx, b);
+        if (rc) return rc;
+    }
+    memset(out_words, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
+    return bsw_refbatch_encode_results(res.data(), (size_t)got, out_words);
+}

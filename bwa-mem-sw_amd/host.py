@@ -1,0 +1,309 @@
+"""Host-side mirror of the reference's operator interface, over the C ABI (ctypes).
+
+Names follow the reference's domain: a *task batch* of seeds goes in, a *result batch*
+comes out (batch_manager.v / tbb.v / rbb.v); PARAMS = global words G0/G1, TASK = header
+H0..H7, RESULT = record R0..R4 (sw_pe_array_proc_element.v:807-933, :1662-1665).
+numpy structured dtypes below are byte-for-byte the C structs of include/bwa_sw_mi355.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libbwasw_mi355.so")
+
+PARAMS = np.dtype([("mat", "i1", (25,)), ("_pad", "i1", (3,)), ("o_del", "<i4"), ("e_del", "<i4"),
+                   ("o_ins", "<i4"), ("e_ins", "<i4"), ("w", "<i4"), ("pen_clip5", "<i4"),
+                   ("pen_clip3", "<i4"), ("zdrop", "<i4"), ("max_band_try", "<i4"), ("variant", "<i4")])
+TASK = np.dtype([("lquery", "<u8"), ("ltarget", "<u8"), ("rquery", "<u8"), ("rtarget", "<u8"),
+                 ("lqlen", "<i4"), ("ltlen", "<i4"), ("rqlen", "<i4"), ("rtlen", "<i4"),
+                 ("h0", "<i4"), ("init_score", "<i4"), ("qbeg", "<i4"), ("tag", "<u4")])
+EXT = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "<i4"), ("gscore", "<i4"),
+                ("max_off", "<i4"), ("aw", "<i4"), ("cells", "<u4")])
+RESULT = np.dtype([("tag", "<u4"), ("qb", "<i4"), ("qe", "<i4"), ("rb", "<i4"), ("re", "<i4"),
+                   ("score", "<i4"), ("truesc", "<i4"), ("w", "<i4"), ("left", EXT), ("right", EXT)])
+EXT_TASK = np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"),
+                     ("w", "<i4"), ("end_bonus", "<i4"), ("h0", "<i4"), ("_pad", "<i4")])
+SYNTH = np.dtype([("seed", "<u8"), ("read_len", "<i4"), ("seed_len_min", "<i4"), ("seed_len_max", "<i4"),
+                  ("seed_at_start", "<i4"), ("sub_rate", "<f8"), ("indel_rate", "<f8"), ("n_rate", "<f8"),
+                  ("junk_frac", "<f8"), ("a", "<i4"), ("w", "<i4"), ("o", "<i4"), ("e", "<i4")])
+CONFIG = np.dtype([("device", "<i4"), ("kernel", "<i4"), ("streams", "<i4"), ("pack_threads", "<i4"),
+                   ("chunk_tasks", "<u8")])
+assert PARAMS.itemsize == 68 and TASK.itemsize == 64 and EXT.itemsize == 32 and RESULT.itemsize == 96
+assert EXT_TASK.itemsize == 40 and SYNTH.itemsize == 72 and CONFIG.itemsize == 24
+
+REFBATCH_IN_WORDS, REFBATCH_OUT_WORDS, REFBATCH_MAX_TASKS = 65536, 4096, 819
+KERNEL_AUTO, KERNEL_WAVE, KERNEL_LANE = 0, 1, 2
+VARIANT_H, VARIANT_M = 0, 1
+
+ERRORS = {0: "BSW_OK", -1: "BSW_E_NODEVICE", -2: "BSW_E_INVAL", -3: "BSW_E_LIMIT", -4: "BSW_E_HIP",
+          -5: "BSW_E_NOMEM", -6: "BSW_E_BUSY"}
+
+
+class BswError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("%s (%d) %s" % (ERRORS.get(code, "?"), code, msg))
+        self.code = code
+
+
+def lib_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compile csrc/ for gfx950 into libbwasw_mi355.so (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(_LIB):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    """The C-ABI library.  Raises if it is missing: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise RuntimeError("libbwasw_mi355.so is not built (run __graft_entry__.build()); "
+                               "this package has no CPU/PyTorch fallback")
+        L = C.CDLL(_LIB)
+        vp, sz = C.c_void_p, C.c_size_t
+        sig = {
+            "bsw_default_params": (None, [vp]), "bsw_default_config": (None, [vp]),
+            "bsw_device_count": (C.c_int, []),
+            "bsw_create": (C.c_int, [vp, C.POINTER(vp)]), "bsw_destroy": (None, [vp]),
+            "bsw_last_error": (C.c_char_p, [vp]),
+            "bsw_submit": (C.c_int, [vp, vp, vp, sz, vp]), "bsw_wait": (C.c_int, [vp]),
+            "bsw_extend_batch": (C.c_int, [vp, vp, vp, sz, vp]),
+            "bsw_upload": (C.c_int, [vp, vp, vp, sz, C.POINTER(vp)]),
+            "bsw_run": (C.c_int, [vp, vp]), "bsw_sync": (C.c_int, [vp]),
+            "bsw_download": (C.c_int, [vp, vp, vp]),
+            "bsw_batch_info": (C.c_int, [vp] + [C.POINTER(C.c_uint64)] * 4),
+            "bsw_last_run_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+            "bsw_free_batch": (None, [vp, vp]),
+            "bsw_refbatch_encode": (C.c_int, [vp, vp, sz, vp]),
+            "bsw_refbatch_decode": (C.c_int, [vp, vp, vp, sz, vp, sz]),
+            "bsw_refbatch_encode_results": (C.c_int, [vp, sz, vp]),
+            "bsw_refbatch_decode_results": (C.c_int, [vp, sz, vp]),
+            "bsw_refbatch_run": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+            "bsw_synth_generate": (C.c_int64, [vp, sz, vp, vp, sz]),
+            "bsw_synth_arena_bound": (sz, [vp, sz]),
+            "bsw_set_default_variant": (None, [C.c_int]),
+            "ksw_extend2": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp] + [C.c_int] * 8 + [vp] * 5),
+            "ksw_extend": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp] + [C.c_int] * 6 + [vp] * 5),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+EXPORTS = ["ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_default_params", "bsw_default_config",
+           "bsw_device_count", "bsw_create", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
+           "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
+           "bsw_last_run_ms", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
+           "bsw_refbatch_encode_results", "bsw_refbatch_decode_results", "bsw_refbatch_run",
+           "bsw_synth_generate", "bsw_synth_arena_bound"]
+
+
+def default_params(**over):
+    p = np.zeros(1, dtype=PARAMS)
+    lib().bsw_default_params(p.ctypes.data)
+    for k, v in over.items():
+        p[k] = v
+    return p
+
+
+def bwa_matrix(a=1, b=4, n=-1):
+    m = np.full((5, 5), -b, dtype=np.int8)
+    for i in range(4):
+        m[i, i] = a
+    m[4, :] = n
+    m[:, 4] = n
+    return m.reshape(25)
+
+
+def synth_tasks(n, **spec):
+    """Generate n synthetic seeds.  Returns (tasks, arena); keep arena alive."""
+    s = np.zeros(1, dtype=SYNTH)
+    d = dict(seed=1, read_len=150, seed_len_min=19, seed_len_max=19, seed_at_start=1, sub_rate=0.01,
+             indel_rate=0.001, n_rate=0.0, junk_frac=0.0, a=1, w=100, o=6, e=1)
+    d.update(spec)
+    for k, v in d.items():
+        s[k] = v
+    L = lib()
+    bound = L.bsw_synth_arena_bound(s.ctypes.data, n)
+    arena = np.zeros(bound, dtype=np.uint8)
+    tasks = np.zeros(n, dtype=TASK)
+    used = L.bsw_synth_generate(s.ctypes.data, n, tasks.ctypes.data, arena.ctypes.data, arena.size)
+    if used < 0:
+        raise BswError(int(used), "bsw_synth_generate")
+    return tasks, arena
+
+
+def make_tasks(seeds):
+    """Build a TASK array from python dicts {lq, lt, rq, rt, h0, [init_score, qbeg, tag]} (sequences =
+    iterables of base codes).  Returns (tasks, arena)."""
+    total = sum(len(s.get(k, ())) for s in seeds for k in ("lq", "lt", "rq", "rt"))
+    arena = np.zeros(total + 8, dtype=np.uint8)
+    tasks = np.zeros(len(seeds), dtype=TASK)
+    off = 0
+    base = arena.ctypes.data
+    for i, s in enumerate(seeds):
+        for key, pf, lf in (("lq", "lquery", "lqlen"), ("lt", "ltarget", "ltlen"),
+                            ("rq", "rquery", "rqlen"), ("rt", "rtarget", "rtlen")):
+            a = np.asarray(s.get(key, ()), dtype=np.uint8)
+            arena[off:off + len(a)] = a
+            tasks[i][pf] = base + off
+            tasks[i][lf] = len(a)
+            off += len(a)
+        tasks[i]["h0"] = s["h0"]
+        tasks[i]["init_score"] = s.get("init_score", -1)
+        tasks[i]["qbeg"] = s.get("qbeg", len(s.get("lq", ())))
+        tasks[i]["tag"] = s.get("tag", i)
+    return tasks, arena
+
+
+class DeviceBatch:
+    def __init__(self, ctx, handle, n):
+        self.ctx, self.handle, self.n = ctx, handle, n
+
+    def info(self):
+        v = [C.c_uint64(0) for _ in range(4)]
+        lib().bsw_batch_info(self.handle, *[C.byref(x) for x in v])
+        return dict(n_tasks=v[0].value, in_bytes=v[1].value, out_bytes=v[2].value, launches=v[3].value)
+
+    def free(self):
+        if self.handle:
+            lib().bsw_free_batch(self.ctx.handle, self.handle)
+            self.handle = None
+
+
+class BswContext:
+    """One GPU context = one of the reference's PE arrays behind its batch manager."""
+
+    def __init__(self, device=0, kernel=KERNEL_AUTO, streams=2, pack_threads=4, chunk_tasks=65536):
+        cfg = np.zeros(1, dtype=CONFIG)
+        cfg["device"], cfg["kernel"], cfg["streams"] = device, kernel, streams
+        cfg["pack_threads"], cfg["chunk_tasks"] = pack_threads, chunk_tasks
+        h = C.c_void_p()
+        rc = lib().bsw_create(cfg.ctypes.data, C.byref(h))
+        if rc:
+            raise BswError(rc, "bsw_create")
+        self.handle = h
+        self._keep = None
+
+    def _chk(self, rc, what):
+        if rc:
+            raise BswError(rc, "%s: %s" % (what, lib().bsw_last_error(self.handle).decode()))
+
+    def close(self):
+        if self.handle:
+            lib().bsw_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # streaming path: host buffers in, host buffers out
+    def submit(self, params, tasks):
+        out = np.zeros(len(tasks), dtype=RESULT)
+        self._keep = (params, tasks, out)
+        self._chk(lib().bsw_submit(self.handle, params.ctypes.data, tasks.ctypes.data, len(tasks), out.ctypes.data), "bsw_submit")
+        return out
+
+    def wait(self):
+        self._chk(lib().bsw_wait(self.handle), "bsw_wait")
+        self._keep = None
+
+    def extend_pairs(self, params, tasks):
+        out = self.submit(params, tasks)
+        self.wait()
+        return out
+
+    def extend_batch(self, params, etasks):
+        out = np.zeros(len(etasks), dtype=EXT)
+        self._chk(lib().bsw_extend_batch(self.handle, params.ctypes.data, etasks.ctypes.data, len(etasks), out.ctypes.data), "bsw_extend_batch")
+        return out
+
+    # device-resident path
+    def upload(self, params, tasks):
+        h = C.c_void_p()
+        self._chk(lib().bsw_upload(self.handle, params.ctypes.data, tasks.ctypes.data, len(tasks), C.byref(h)), "bsw_upload")
+        return DeviceBatch(self, h, len(tasks))
+
+    def run(self, batch):
+        self._chk(lib().bsw_run(self.handle, batch.handle), "bsw_run")
+
+    def sync(self):
+        self._chk(lib().bsw_sync(self.handle), "bsw_sync")
+
+    def last_run_ms(self):
+        ms = C.c_float(0)
+        self._chk(lib().bsw_last_run_ms(self.handle, C.byref(ms)), "bsw_last_run_ms")
+        return ms.value
+
+    def download(self, batch):
+        out = np.zeros(batch.n, dtype=RESULT)
+        self._chk(lib().bsw_download(self.handle, batch.handle, out.ctypes.data), "bsw_download")
+        return out
+
+    def refbatch_run(self, in_words, variant=VARIANT_H, zdrop=0):
+        in_words = np.ascontiguousarray(in_words, dtype=np.uint32)
+        assert in_words.size == REFBATCH_IN_WORDS
+        out = np.zeros(REFBATCH_OUT_WORDS, dtype=np.uint32)
+        rc = lib().bsw_refbatch_run(self.handle, in_words.ctypes.data, out.ctypes.data, variant, zdrop)
+        if rc < 0:
+            self._chk(rc, "bsw_refbatch_run")
+        return out, rc
+
+
+def refbatch_encode(params, tasks):
+    words = np.zeros(REFBATCH_IN_WORDS, dtype=np.uint32)
+    n = lib().bsw_refbatch_encode(params.ctypes.data, tasks.ctypes.data, len(tasks), words.ctypes.data)
+    if n < 0:
+        raise BswError(n, "bsw_refbatch_encode")
+    return words, n
+
+
+def refbatch_decode(words):
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    p = np.zeros(1, dtype=PARAMS)
+    tasks = np.zeros(REFBATCH_MAX_TASKS, dtype=TASK)
+    seqbuf = np.zeros(REFBATCH_IN_WORDS * 8 + 64, dtype=np.uint8)
+    n = lib().bsw_refbatch_decode(words.ctypes.data, p.ctypes.data, tasks.ctypes.data, len(tasks), seqbuf.ctypes.data, seqbuf.size)
+    if n < 0:
+        raise BswError(n, "bsw_refbatch_decode")
+    return p, tasks[:n], seqbuf
+
+
+def refbatch_encode_results(res):
+    words = np.zeros(REFBATCH_OUT_WORDS, dtype=np.uint32)
+    n = lib().bsw_refbatch_encode_results(res.ctypes.data, len(res), words.ctypes.data)
+    if n < 0:
+        raise BswError(n, "bsw_refbatch_encode_results")
+    return words
+
+
+def refbatch_decode_results(words, n):
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    res = np.zeros(n, dtype=RESULT)
+    rc = lib().bsw_refbatch_decode_results(words.ctypes.data, n, res.ctypes.data)
+    if rc < 0:
+        raise BswError(rc, "bsw_refbatch_decode_results")
+    return res
+
+
+def task_seq(tasks, i, field, lenfield):
+    """Read one sequence of task i back as a numpy array (for tests / fixtures)."""
+    n = int(tasks[i][lenfield])
+    if n == 0:
+        return np.zeros(0, dtype=np.uint8)
+    return np.ctypeslib.as_array(C.cast(int(tasks[i][field]), C.POINTER(C.c_uint8)), shape=(n,)).copy()

@@ -1,0 +1,204 @@
+/*
+ * bwa_sw_mi355.h — C ABI of libbwasw_mi355.so
+ *
+ * MI355X (gfx950) implementation of BWA-MEM's banded affine-gap Smith-Waterman
+ * seed-extension path: ksw_extend / ksw_extend2 as driven by mem_chain2aln
+ * (left extension, right extension, MAX_BAND_TRY band doubling, clip-vs-extend
+ * decision).  Every entry point below computes on the GPU through hand-written
+ * HIP kernels; there is NO CPU fallback in this library.  If no gfx950 device
+ * (or no usable HIP runtime) is present the calls fail with BSW_E_NODEVICE.
+ *
+ * What each entry point replaces in the reference (peterpengwei/bwa-mem-sw,
+ * FPGA RTL; citations are into that tree):
+ *
+ *   ksw_extend2 / ksw_extend   the software ABI the accelerator stands in for
+ *                              (bwa ksw.h; hardware statement of it:
+ *                              sw_pe_array_sw_extend.v:96-123 ports,
+ *                              :1639-1705 FSM)
+ *   bsw_params                 batch-global words G0/G1
+ *                              (sw_pe_array_proc_element.v:816-819, :916-917)
+ *   bsw_task                   8-word task header H0..H7 + packed bases
+ *                              (sw_pe_array_task_parse.v:1884-1951,
+ *                               sw_pe_array_proc_element.v:807-933, :1638-1683)
+ *   bsw_result                 5-word result record R0..R4
+ *                              (sw_pe_array_proc_element.v:1662-1665, :1190-1199)
+ *   bsw_create/.../bsw_wait    CSR + DSM handshake and the TBB/RBB round trip
+ *                              (batch_manager.v:208-221, :358-739; tbb.v; rbb.v)
+ *   bsw_refbatch_*             the exact 256 KiB task batch / 16 KiB result
+ *                              batch wire format (bwa_mem_sw.v:163-170)
+ *
+ * Base codes: 0..3 = A,C,G,T; 4 = N; one base per byte, exactly as bwa passes
+ * them to ksw_extend.  Left-extension query/target must already be reversed by
+ * the caller (as mem_chain2aln does before calling ksw_extend2).
+ */
+#ifndef BWA_SW_MI355_H
+#define BWA_SW_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (never abort; the reference signals no errors at all) ---- */
+#define BSW_OK            0
+#define BSW_E_NODEVICE   (-1)  /* no gfx950 GPU / HIP runtime unusable            */
+#define BSW_E_INVAL      (-2)  /* NULL pointer, bad params (e_ins<=0, h0<=0, ...) */
+#define BSW_E_LIMIT      (-3)  /* task outside device limits (see BSW_MAX_*)      */
+#define BSW_E_HIP        (-4)  /* a HIP runtime call failed                       */
+#define BSW_E_NOMEM      (-5)
+#define BSW_E_BUSY       (-6)  /* submit while a previous submit is in flight     */
+
+/* ---- device limits ------------------------------------------------------- */
+#define BSW_MAX_QLEN   1023    /* query side length per extension                 */
+#define BSW_MAX_TLEN   65535   /* target side length per extension                */
+#define BSW_MAX_SCORE  (1 << 20) /* h0 + qlen*max(mat) must stay below this       */
+
+/* recurrence variant: H = bwa<=0.7.8 and the RTL
+ * (sw_pe_array_sw_extend.v:1797-1798,1863,1866); M = bwa>=0.7.9 ("M? M+q : 0") */
+#define BSW_VARIANT_H  0
+#define BSW_VARIANT_M  1
+
+typedef struct bsw_params {
+    int8_t  mat[25];        /* 5x5 scoring matrix, row = target base (K6)        */
+    int8_t  _pad[3];
+    int32_t o_del, e_del;   /* G0 [7:0], [15:8]                                  */
+    int32_t o_ins, e_ins;   /* G0 [23:16], [31:24]                               */
+    int32_t w;              /* G1 [23:16]  opt->w                                */
+    int32_t pen_clip5;      /* G1 [7:0]    also end_bonus of the left extension  */
+    int32_t pen_clip3;      /* G1 [15:8]   also end_bonus of the right extension */
+    int32_t zdrop;          /* not in the RTL (quirk Q3); bwa default 100        */
+    int32_t max_band_try;   /* MAX_BAND_TRY, 2 in bwa and in the RTL (:1963)     */
+    int32_t variant;        /* BSW_VARIANT_H (default) or BSW_VARIANT_M          */
+} bsw_params;
+
+/* One seed = left + right extension (what one RTL processing element handles). */
+typedef struct bsw_task {
+    const uint8_t *lquery;  /* reversed query[0..qbeg)          (H0 qlen0)       */
+    const uint8_t *ltarget; /* reversed reference left of seed  (H0 tlen0)       */
+    const uint8_t *rquery;  /* query[qbeg+len..l_query)         (H1 qlen1)       */
+    const uint8_t *rtarget; /* reference right of the seed      (H1 tlen1)       */
+    int32_t  lqlen, ltlen, rqlen, rtlen;
+    int32_t  h0;            /* s->len * a                       (H4)             */
+    int32_t  init_score;    /* a->score before the left ext; bwa: -1 (H3 low)    */
+    int32_t  qbeg;          /* s->qbeg                          (H3 high)        */
+    uint32_t tag;           /* opaque, echoed back              (H7 -> R0)       */
+} bsw_task;
+
+/* Raw outputs of the last ksw_extend2 pass of one side (K9) + bookkeeping. */
+typedef struct bsw_ext {
+    int32_t  score, qle, tle, gtle, gscore, max_off;
+    int32_t  aw;            /* band width of the last pass, unclamped w<<k (P3)  */
+    uint32_t cells;         /* DP cells evaluated over all passes of this side   */
+} bsw_ext;
+
+typedef struct bsw_result {
+    uint32_t tag;           /* R0                                                */
+    int32_t  qb, qe;        /* R1: qb absolute in the query; qe relative to the
+                                   seed's query end                              */
+    int32_t  rb, re;        /* R2: relative to the seed's reference begin / end
+                                   (rb = -tle or -gtle)                          */
+    int32_t  score, truesc; /* R3                                                */
+    int32_t  w;             /* R4: max(aw_left, aw_right)                        */
+    bsw_ext  left, right;   /* not in the RTL record; for parity checking        */
+} bsw_result;
+
+/* One plain ksw_extend2 call (no band retry), for batched single extensions. */
+typedef struct bsw_ext_task {
+    const uint8_t *query, *target;
+    int32_t qlen, tlen;
+    int32_t w, end_bonus, h0;
+} bsw_ext_task;
+
+typedef struct bsw_config {
+    int32_t device;         /* HIP device ordinal                                */
+    int32_t kernel;         /* BSW_KERNEL_*                                      */
+    int32_t streams;        /* copy/compute streams for bsw_submit (>=1, def 2)  */
+    int32_t pack_threads;   /* host packer threads (def 4)                       */
+    size_t  chunk_tasks;    /* tasks per H2D/launch chunk in bsw_submit (def 64Ki) */
+} bsw_config;
+
+#define BSW_KERNEL_AUTO  0  /* per-bin choice (batch manager)                    */
+#define BSW_KERNEL_WAVE  1  /* one wavefront per task, row-synchronous           */
+#define BSW_KERNEL_LANE  2  /* one lane per task, inter-task SIMD                */
+
+typedef struct bsw_ctx bsw_ctx;
+typedef struct bsw_dev_batch bsw_dev_batch;
+
+/* ---- drop-in scalar ABI (bwa ksw.h).  Each call is a 1-task GPU launch. ---- */
+int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
+                int m, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins,
+                int w, int end_bonus, int zdrop, int h0,
+                int *qle, int *tle, int *gtle, int *gscore, int *max_off);
+int ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
+               int m, const int8_t *mat, int gapo, int gape,
+               int w, int end_bonus, int zdrop, int h0,
+               int *qle, int *tle, int *gtle, int *gscore, int *max_off);
+/* recurrence variant used by ksw_extend/ksw_extend2 (process-wide, default H) */
+void bsw_set_default_variant(int variant);
+
+/* ---- batch API ------------------------------------------------------------ */
+void     bsw_default_params(bsw_params *p);          /* bwa defaults a=1,b=4,o=6,e=1,w=100,clip=5,zdrop=100 */
+void     bsw_default_config(bsw_config *c);
+int      bsw_device_count(void);                     /* gfx950 devices visible; <=0 if none */
+int      bsw_create(const bsw_config *cfg, bsw_ctx **out);
+void     bsw_destroy(bsw_ctx *ctx);
+const char *bsw_last_error(const bsw_ctx *ctx);      /* text of the last failure  */
+
+/* Asynchronous: bins + packs tasks into pinned staging, streams them to the
+ * device in chunks, launches, copies results back into out[] in TASK ORDER.
+ * out[] and the task sequences must stay valid until bsw_wait returns.        */
+int      bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out);
+int      bsw_wait(bsw_ctx *ctx);
+/* Batched plain ksw_extend2 (one pass each, w/end_bonus/h0 per task); synchronous. */
+int      bsw_extend_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_ext_task *tasks, size_t n, bsw_ext *out);
+
+/* ---- device-resident batches (inputs in HBM before the timed region) ------- */
+int      bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out);
+int      bsw_run(bsw_ctx *ctx, bsw_dev_batch *b);          /* enqueue kernels only        */
+int      bsw_sync(bsw_ctx *ctx);                            /* hipStreamSynchronize        */
+int      bsw_download(bsw_ctx *ctx, bsw_dev_batch *b, bsw_result *out); /* task order      */
+int      bsw_batch_info(const bsw_dev_batch *b, uint64_t *n_tasks, uint64_t *in_bytes, uint64_t *out_bytes, uint64_t *n_launches);
+/* time of the kernels of the last bsw_run, measured with hipEvents on the
+ * library's own stream; valid after bsw_sync.                                  */
+int      bsw_last_run_ms(bsw_ctx *ctx, float *ms);
+void     bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b);
+
+/* ---- reference wire format (bwa_mem_sw.v:163-170) ----------- */
+#define BSW_REFBATCH_IN_WORDS   65536   /* 256 KiB task batch (tbb.v:59)         */
+#define BSW_REFBATCH_OUT_WORDS  4096    /* 16 KiB result batch (rbb.v:59)        */
+#define BSW_REFBATCH_MAX_TASKS  819     /* floor(4096/5) five-word records       */
+/* Encode up to n tasks; returns the number of tasks that fit (>=0) or <0.
+ * Tasks whose fields exceed the RTL's port widths (quirk Q1) stop the batch.   */
+int      bsw_refbatch_encode(const bsw_params *p, const bsw_task *tasks, size_t n, uint32_t *words /*[65536]*/);
+/* Decode a task batch; sequences are unpacked into seqbuf (byte per base).     */
+int      bsw_refbatch_decode(const uint32_t *words, bsw_params *p, bsw_task *tasks, size_t max_tasks,
+                             uint8_t *seqbuf, size_t seqbuf_len);
+int      bsw_refbatch_encode_results(const bsw_result *res, size_t n, uint32_t *words /*[4096]*/);
+int      bsw_refbatch_decode_results(const uint32_t *words, size_t n, bsw_result *res);
+/* Run one 256 KiB task batch end to end on the GPU and fill the 16 KiB result
+ * batch — what one RTL PE array does between task_start and TestCmp.           */
+int      bsw_refbatch_run(bsw_ctx *ctx, const uint32_t *in_words, uint32_t *out_words, int variant, int zdrop);
+
+/* ---- synthetic workload generator (no genome in the image) --- */
+typedef struct bsw_synth_spec {
+    uint64_t seed;
+    int32_t  read_len;      /* 150 or 250                                        */
+    int32_t  seed_len_min, seed_len_max; /* seed length ~ U[min,max]             */
+    int32_t  seed_at_start; /* 1: seed = read[0:seed_len) (right extension only) */
+    double   sub_rate, indel_rate;       /* per-base                             */
+    double   n_rate;        /* fraction of bases turned into N                    */
+    double   junk_frac;     /* fraction of tasks whose flanks are unrelated       */
+    int32_t  a;             /* match score (for h0 = seed_len*a)                  */
+    int32_t  w;             /* band, caps tlen = qlen + min(max_gap, 2w)          */
+    int32_t  o, e;          /* gap penalties for cal_max_gap                      */
+} bsw_synth_spec;
+/* Fills tasks[0..n) and the arena; returns bytes of arena used or <0.          */
+int64_t  bsw_synth_generate(const bsw_synth_spec *s, size_t n, bsw_task *tasks, uint8_t *arena, size_t arena_len);
+size_t   bsw_synth_arena_bound(const bsw_synth_spec *s, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BWA_SW_MI355_H */

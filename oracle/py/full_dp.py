@@ -1,0 +1,57 @@
+"""Independent full-matrix DP for extension alignment (CPU ORACLE second opinion).
+
+Test infrastructure, NOT product code.  Written from the recurrence definitions
+(SURVEY.md §8a), not from the row-streaming C code: whole H/E/F matrices, no band,
+no beg/end trimming, no early break, no zdrop.  It therefore agrees with
+ksw_extend2 only on inputs where none of those can bind — in practice: band
+w >= max(qlen, tlen), zdrop = 0, and h0 large enough that every H stays > 0
+(tests construct exactly such inputs).
+
+Restates sw_pe_array_sw_extend.v K2/K4/K5/K7/K9 rows of SURVEY.md §8a.
+"""
+import numpy as np
+
+
+def full_dp(query, target, mat, o_del, e_del, o_ins, e_ins, h0, variant=0, m=5):
+    q = np.asarray(query, dtype=np.int64)
+    t = np.asarray(target, dtype=np.int64)
+    mat = np.asarray(mat, dtype=np.int64).reshape(m, m)
+    ql, tl = len(q), len(t)
+    oe_del, oe_ins = o_del + e_del, o_ins + e_ins
+    H = np.zeros((tl, ql), dtype=np.int64)
+    E = np.zeros((tl + 1, ql), dtype=np.int64)      # E[i][j] enters row i
+    top = [max(h0 - oe_ins - j * e_ins, 0) for j in range(ql)]       # H(-1, j)
+    left = [max(h0 - o_del - e_del * (i + 1), 0) for i in range(tl)]  # H(i, -1)
+    for i in range(tl):
+        f = 0
+        for j in range(ql):
+            if i == 0:
+                diag = h0 if j == 0 else top[j - 1]
+            else:
+                diag = left[i - 1] if j == 0 else H[i - 1][j - 1]
+            s = mat[t[i]][q[j]]
+            if variant == 1:
+                M = diag + s if diag != 0 else 0
+            else:
+                M = diag + s
+            h = max(M, E[i][j], f)
+            H[i][j] = h
+            base = M if variant == 1 else h
+            E[i + 1][j] = max(E[i][j] - e_del, max(base - oe_del, 0))
+            f = max(f - e_ins, max(base - oe_ins, 0))
+    # scalars with the tie-break rules of K5/K7
+    best, max_i, max_j, max_off = h0, -1, -1, 0
+    gscore, max_ie = -1, -1
+    for i in range(tl):
+        row = H[i]
+        mrow = int(row.max()) if ql else 0
+        mj = int(np.nonzero(row == mrow)[0][-1]) if ql else -1     # ties -> later j
+        if ql and not (gscore > row[ql - 1]):                       # ties -> later i
+            max_ie = i
+        if ql:
+            gscore = max(gscore, int(row[ql - 1]))
+        if mrow > best:
+            best, max_i, max_j = mrow, i, mj
+            max_off = max(max_off, abs(mj - i))
+    return dict(score=int(best), qle=max_j + 1, tle=max_i + 1, gtle=max_ie + 1,
+                gscore=int(gscore), max_off=int(max_off), minH=int(H.min()) if H.size else 0)

@@ -1,0 +1,85 @@
+"""ctypes binding of oracle/libksw_oracle.so (CPU ORACLE — test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.dirname(_HERE)
+_LIB_PATH = os.path.join(_ORACLE_DIR, "libksw_oracle.so")
+
+I32P = C.POINTER(C.c_int32)
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "libksw_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        ext_args = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                    I32P, I32P, I32P, I32P, I32P, C.c_int, C.POINTER(C.c_uint64)]
+        for name in ("ksw_extend2_ref", "ksw_extend2_rowsync_model"):
+            f = getattr(L, name)
+            f.argtypes = ext_args
+            f.restype = C.c_int
+        L.bsw_pair_ref.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bsw_pair_ref.restype = None
+        L.bsw_pair_batch_ref.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.bsw_pair_batch_ref.restype = None
+        L.bsw_ext_batch_ref.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.bsw_ext_batch_ref.restype = None
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data
+
+
+def extend2(query, target, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop, h0,
+            variant=0, model=False, m=5):
+    """One ksw_extend2 call on the oracle (or on the row-synchronous model)."""
+    q, qp = _u8(query)
+    t, tp = _u8(target)
+    mt = np.ascontiguousarray(mat, dtype=np.int8)
+    outs = [C.c_int32(0) for _ in range(5)]
+    cells = C.c_uint64(0)
+    f = lib().ksw_extend2_rowsync_model if model else lib().ksw_extend2_ref
+    score = f(len(q), qp, len(t), tp, m, mt.ctypes.data, o_del, e_del, o_ins, e_ins, w, end_bonus,
+              zdrop, h0, *[C.byref(o) for o in outs], variant, C.byref(cells))
+    return dict(score=score, qle=outs[0].value, tle=outs[1].value, gtle=outs[2].value,
+                gscore=outs[3].value, max_off=outs[4].value, cells=cells.value)
+
+
+def pair_batch(params, tasks, nthreads=1):
+    """params: 1-element PARAMS array; tasks: TASK array -> RESULT array."""
+    from_dtype = tasks.dtype
+    assert from_dtype.itemsize == 64
+    import importlib
+    host = importlib.import_module("bwa_mem_sw_amd.host")
+    out = np.zeros(len(tasks), dtype=host.RESULT)
+    lib().bsw_pair_batch_ref(params.ctypes.data, tasks.ctypes.data, len(tasks), out.ctypes.data, nthreads)
+    return out
+
+
+def ext_batch(params, etasks, nthreads=1):
+    import importlib
+    host = importlib.import_module("bwa_mem_sw_amd.host")
+    out = np.zeros(len(etasks), dtype=host.EXT)
+    lib().bsw_ext_batch_ref(params.ctypes.data, etasks.ctypes.data, len(etasks), out.ctypes.data, nthreads)
+    return out
