@@ -38,6 +38,10 @@ struct bsw_ctx {
     std::vector<hipStream_t> streams;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    /* per-run event pairs since the last bsw_run_history() call (kernel time of every bsw_run) */
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> hist;
+    size_t hist_used = 0;
+    hipEvent_t ev_last0 = nullptr, ev_last1 = nullptr;
     std::string err;
     /* async submit */
     std::thread worker;
@@ -157,6 +161,7 @@ extern "C" void bsw_destroy(bsw_ctx *ctx)
     for (auto s : ctx->streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    for (auto &pr : ctx->hist) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete ctx;
 }
 
@@ -374,11 +379,24 @@ extern "C" int bsw_run(bsw_ctx *ctx, bsw_dev_batch *b)
     if (!ctx || !b) return fail(ctx, BSW_E_INVAL, "bsw_run: NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->streams[0];
-    HIPCHK(ctx, hipEventRecord(ctx->ev_start, s));
+    hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
+    if (ctx->hist_used < 4096) {
+        if (ctx->hist_used == ctx->hist.size()) {
+            hipEvent_t a, c;
+            HIPCHK(ctx, hipEventCreate(&a));
+            HIPCHK(ctx, hipEventCreate(&c));
+            ctx->hist.emplace_back(a, c);
+        }
+        e0 = ctx->hist[ctx->hist_used].first;
+        e1 = ctx->hist[ctx->hist_used].second;
+        ++ctx->hist_used;
+    }
+    HIPCHK(ctx, hipEventRecord(e0, s));
     b->launches = 0;
     int rc = enqueue_batch(ctx, b->P, b->variant, b->d_seq, b->d_tasks, b->d_order, b->cls_start, b->d_out, s, &b->launches);
     if (rc) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev_stop, s));
+    HIPCHK(ctx, hipEventRecord(e1, s));
+    ctx->ev_last0 = e0; ctx->ev_last1 = e1;
     ctx->timed = true;
     return BSW_OK;
 }
@@ -394,9 +412,22 @@ extern "C" int bsw_sync(bsw_ctx *ctx)
 extern "C" int bsw_last_run_ms(bsw_ctx *ctx, float *ms)
 {
     if (!ctx || !ms || !ctx->timed) return BSW_E_INVAL;
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev_stop));
-    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_last1));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev_last0, ctx->ev_last1));
     return BSW_OK;
+}
+
+extern "C" int bsw_run_history(bsw_ctx *ctx, float *ms, int cap)
+{
+    if (!ctx || (!ms && cap > 0)) return BSW_E_INVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int n = 0;
+    for (size_t i = 0; i < ctx->hist_used && n < cap; ++i, ++n) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->hist[i].second));
+        HIPCHK(ctx, hipEventElapsedTime(&ms[n], ctx->hist[i].first, ctx->hist[i].second));
+    }
+    ctx->hist_used = 0;
+    return n;
 }
 
 extern "C" int bsw_download(bsw_ctx *ctx, bsw_dev_batch *b, bsw_result *out)

@@ -84,6 +84,7 @@ def lib():
             "bsw_batch_info": (C.c_int, [vp] + [C.POINTER(C.c_uint64)] * 4),
             "bsw_last_run_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
             "bsw_free_batch": (None, [vp, vp]),
+            "bsw_run_history": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int]),
             "bsw_refbatch_encode": (C.c_int, [vp, vp, sz, vp]),
             "bsw_refbatch_decode": (C.c_int, [vp, vp, vp, sz, vp, sz]),
             "bsw_refbatch_encode_results": (C.c_int, [vp, sz, vp]),
@@ -105,7 +106,7 @@ def lib():
 EXPORTS = ["ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_default_params", "bsw_default_config",
            "bsw_device_count", "bsw_create", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
-           "bsw_last_run_ms", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
+           "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
            "bsw_refbatch_encode_results", "bsw_refbatch_decode_results", "bsw_refbatch_run",
            "bsw_synth_generate", "bsw_synth_arena_bound"]
 
@@ -250,6 +251,13 @@ class BswContext:
         self._chk(lib().bsw_last_run_ms(self.handle, C.byref(ms)), "bsw_last_run_ms")
         return ms.value
 
+    def run_history(self, cap=4096):
+        buf = (C.c_float * cap)()
+        n = lib().bsw_run_history(self.handle, buf, cap)
+        if n < 0:
+            self._chk(n, "bsw_run_history")
+        return [buf[i] for i in range(n)]
+
     def download(self, batch):
         out = np.zeros(batch.n, dtype=RESULT)
         self._chk(lib().bsw_download(self.handle, batch.handle, out.ctypes.data), "bsw_download")
@@ -299,6 +307,13 @@ def refbatch_decode_results(words, n):
     if rc < 0:
         raise BswError(rc, "bsw_refbatch_decode_results")
     return res
+
+
+def shard_indices(n, world, rank, chunk=65536):
+    """Per-read task shard of rank `rank`: task k -> rank (k // chunk) % world (SURVEY.md §8e).
+    Tasks are independent, so there is no exchange step and no data-path collective."""
+    idx = np.arange(n, dtype=np.int64)
+    return idx[(idx // chunk) % world == rank]
 
 
 def task_seq(tasks, i, field, lenfield):

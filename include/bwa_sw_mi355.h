@@ -163,6 +163,9 @@ int      bsw_batch_info(const bsw_dev_batch *b, uint64_t *n_tasks, uint64_t *in_
 /* time of the kernels of the last bsw_run, measured with hipEvents on the
  * library's own stream; valid after bsw_sync.                                  */
 int      bsw_last_run_ms(bsw_ctx *ctx, float *ms);
+/* kernel time (ms) of every bsw_run since the previous call, oldest first; returns the
+ * count written (<= cap) and resets the history.  Synchronises on the recorded events.   */
+int      bsw_run_history(bsw_ctx *ctx, float *ms, int cap);
 void     bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b);
 
 /* ---- reference wire format (bwa_mem_sw.v:163-170) ----------- */

@@ -1,0 +1,123 @@
+"""C-ABI library on a CPU-only box: it loads, exports every symbol of include/bwa_sw_mi355.h,
+struct layouts match, host-only entry points work, GPU entry points fail loudly (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "bwa_sw_mi355.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:bsw|ksw)_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(host):
+    L = C.CDLL(host.lib_path())
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "libbwasw_mi355.so does not export %s" % n
+    assert set(names) == set(host.EXPORTS)
+
+
+def test_struct_sizes_match_header(host, tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "bwa_sw_mi355.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(bsw_params),sizeof(bsw_task),sizeof(bsw_ext),sizeof(bsw_result),sizeof(bsw_ext_task),'
+                   'sizeof(bsw_synth_spec),sizeof(bsw_config));return 0;}\n')
+    exe = tmp_path / "sz"
+    import subprocess
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [host.PARAMS.itemsize, host.TASK.itemsize, host.EXT.itemsize, host.RESULT.itemsize,
+                     host.EXT_TASK.itemsize, host.SYNTH.itemsize, host.CONFIG.itemsize]
+
+
+def test_default_params(host):
+    p = host.default_params()
+    assert (p["mat"][0] == host.bwa_matrix()).all()
+    assert (int(p["o_del"][0]), int(p["e_del"][0]), int(p["o_ins"][0]), int(p["e_ins"][0]), int(p["w"][0])) == (6, 1, 6, 1, 100)
+    assert (int(p["pen_clip5"][0]), int(p["pen_clip3"][0]), int(p["zdrop"][0]), int(p["max_band_try"][0]), int(p["variant"][0])) == (5, 5, 100, 2, 0)
+
+
+def test_synth_is_deterministic_and_shaped(host):
+    a, aa = host.synth_tasks(500, seed=3)
+    b, ab = host.synth_tasks(500, seed=3)
+    c, ac = host.synth_tasks(500, seed=4)
+    assert (a["rqlen"] == 131).all() and (a["rtlen"] == 257).all() and (a["lqlen"] == 0).all() and (a["h0"] == 19).all()
+    sa = [host.task_seq(a, i, "rquery", "rqlen").tobytes() + host.task_seq(a, i, "rtarget", "rtlen").tobytes() for i in range(500)]
+    sb = [host.task_seq(b, i, "rquery", "rqlen").tobytes() + host.task_seq(b, i, "rtarget", "rtlen").tobytes() for i in range(500)]
+    sc = [host.task_seq(c, i, "rquery", "rqlen").tobytes() + host.task_seq(c, i, "rtarget", "rtlen").tobytes() for i in range(500)]
+    assert sa == sb and sa != sc
+    m, am = host.synth_tasks(300, seed=9, seed_at_start=0, seed_len_min=19, seed_len_max=60, read_len=250, w=500)
+    assert ((m["lqlen"] + m["rqlen"] + m["h0"]) == 250).all()
+    assert (m["ltlen"] >= m["lqlen"]).all() and (m["rtlen"] >= m["rqlen"]).all()
+    assert (m["qbeg"] == m["lqlen"]).all()
+
+
+def test_no_gpu_means_loud_failure_not_fallback(host):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert host.lib().bsw_device_count() == 0
+    with pytest.raises(host.BswError) as ei:
+        host.BswContext(device=0)
+    assert ei.value.code == -1          # BSW_E_NODEVICE
+    # the drop-in scalar entry point must not silently compute on the CPU either
+    q = np.zeros(4, np.uint8)
+    m = host.bwa_matrix()
+    r = host.lib().ksw_extend2(4, q.ctypes.data, 4, q.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, 100, 5, 100, 10,
+                               None, None, None, None, None)
+    assert r == -1
+
+
+def test_refbatch_roundtrip(host, oracle):
+    tasks, arena = host.synth_tasks(900, seed=21, seed_at_start=0, seed_len_min=19, seed_len_max=60, indel_rate=0.01, n_rate=0.01)
+    p = host.default_params()
+    words, n = host.refbatch_encode(p, tasks)
+    assert 0 < n <= host.REFBATCH_MAX_TASKS and words[2] == n
+    p2, t2, seqbuf = host.refbatch_decode(words)
+    for f in ("o_del", "e_del", "o_ins", "e_ins", "w", "pen_clip5", "pen_clip3"):
+        assert int(p2[f][0]) == int(p[f][0])
+    assert int(p2["zdrop"][0]) == 0 and int(p2["max_band_try"][0]) == 2
+    for f in ("lqlen", "ltlen", "rqlen", "rtlen", "h0", "init_score", "qbeg", "tag"):
+        assert (t2[f] == tasks[f][:n]).all(), f
+    for i in range(0, n, 37):
+        for pf, lf in (("lquery", "lqlen"), ("ltarget", "ltlen"), ("rquery", "rqlen"), ("rtarget", "rtlen")):
+            assert (host.task_seq(t2, i, pf, lf) == host.task_seq(tasks, i, pf, lf)).all()
+    # MSB-first nibble order of the first data word (proc_element.v:1638,1677)
+    pos = int(words[8 + 2])
+    first = np.concatenate([host.task_seq(tasks, 0, pf, lf) for pf, lf in (("lquery", "lqlen"), ("rquery", "rqlen"), ("ltarget", "ltlen"), ("rtarget", "rtlen"))])[:8]
+    exp = 0
+    for k, b in enumerate(first):
+        exp |= int(b) << (28 - 4 * k)
+    assert int(words[pos]) == exp
+    # results
+    p2["zdrop"] = 0
+    res = oracle.pair_batch(p2, t2)
+    rw = host.refbatch_encode_results(res)
+    back = host.refbatch_decode_results(rw, n)
+    for f in ("tag", "qb", "qe", "rb", "re", "score", "truesc", "w"):
+        assert (back[f] == res[f]).all(), f
+
+
+def test_refbatch_limits(host):
+    p = host.default_params()
+    seeds = [dict(rq=np.zeros(300, np.uint8), rt=np.zeros(300, np.uint8), h0=10)]      # qlen > 255: does not fit (Q1)
+    t, a = host.make_tasks(seeds)
+    words, n = host.refbatch_encode(p, t)
+    assert n == 0
+    seeds = [dict(rq=np.zeros(30, np.uint8), rt=np.zeros(30, np.uint8), h0=200)]       # h0 > 127: int8 datapath
+    t, a = host.make_tasks(seeds)
+    assert host.refbatch_encode(p, t)[1] == 0
+    big = host.default_params(w=300)
+    with pytest.raises(host.BswError):
+        host.refbatch_encode(big, t)
+    many, am = host.synth_tasks(2000, seed=1)
+    words, n = host.refbatch_encode(p, many)
+    assert n == host.REFBATCH_MAX_TASKS                                                 # 819 five-word records (rbb.v)
