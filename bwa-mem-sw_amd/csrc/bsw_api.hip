@@ -27,10 +27,29 @@ namespace bsw {
 int wave_class_count();
 int wave_class_cols(int cls);
 hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
+                       const uint32_t *order, uint32_t n, const uint32_t *n_dev, bsw_result *out, hipStream_t s);
+int lane_class_count();
+int lane_class_cols(int cls);
+hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
                        const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
+hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
+                           bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, hipStream_t s);
 }  // namespace bsw
 
 #define MAX_CLASSES 8
+#define MAX_LANE_CLASSES 4
+#define LANE_AUTO_MIN 2048      /* BSW_KERNEL_AUTO: lane bins only pay off when they fill many waves */
+
+/* How one batch is cut into kernel launches (all offsets index the device `order` array).
+ *   [wave classes][lane seeds, any order][lane left sides by qlen][lane right sides by qlen][redo list] + counter */
+struct batch_plan {
+    uint32_t wave_start[MAX_CLASSES + 1] = {0};
+    uint32_t lane_all_off = 0, lane_all_cnt = 0;
+    uint32_t laneL_off[MAX_LANE_CLASSES + 1] = {0}, laneR_off[MAX_LANE_CLASSES + 1] = {0};
+    uint32_t redo_off = 0;
+    uint32_t order_len = 0;          /* entries before the redo counter */
+    int redo_cls = 0;
+};
 
 struct bsw_ctx {
     int device = 0;
@@ -58,7 +77,7 @@ struct bsw_dev_batch {
     uint32_t *d_order = nullptr;
     bsw_result *d_out = nullptr;
     uint64_t seq_words = 0;
-    uint32_t cls_start[MAX_CLASSES + 1] = {0};
+    batch_plan plan;
     uint64_t launches = 0;
 };
 
@@ -203,26 +222,43 @@ static inline int gap_limit(const bsw_params *p, int mx, int qlen, int end_bonus
 
 static inline size_t nwords(int len) { return (size_t)((len + 15) >> 4); }
 
-static void pack_seq(const uint8_t *s, int len, uint64_t *dst)
+/* returns non-zero when the sequence holds an N (code >= 4) */
+static unsigned pack_seq(const uint8_t *s, int len, uint64_t *dst)
 {
     const int nw = (len + 15) >> 4;
+    unsigned any_n = 0;
     for (int w = 0; w < nw; ++w) {
         uint64_t v = 0;
         const int lo = w << 4, hi = lo + 16 < len ? lo + 16 : len;
         for (int k = lo; k < hi; ++k) {
             const uint64_t b = s[k] > 4 ? 4 : s[k];
+            any_n |= (unsigned)(b >> 2);
             v |= b << ((k - lo) * 4);
         }
         dst[w] = v;
     }
+    return any_n;
+}
+
+/* lane kernel needs a bwa-style matrix: a on the diagonal, one mismatch score off it (N never occurs there) */
+static bool lane_matrix_ok(const bsw_params *p)
+{
+    const int a = p->mat[0], nb = p->mat[1];
+    if (a <= 0 || nb > 0) return false;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (p->mat[i * 5 + j] != (i == j ? a : nb)) return false;
+    return true;
 }
 
 struct packed_host {
     std::vector<uint64_t> seq;
     std::vector<bsw_dtask> tasks;
     std::vector<uint32_t> order;
-    uint32_t cls_start[MAX_CLASSES + 1];
+    batch_plan plan;
 };
+
+static size_t order_capacity(size_t n) { return 4 * n + 16; }   /* upper bound of plan.order_len + 1 */
 
 static int task_class(int qmax)
 {
@@ -232,15 +268,18 @@ static int task_class(int qmax)
     return -1;
 }
 
-/* validate, lay out and pack tasks[0..n) — `threads` host threads do the nibble packing */
+/* validate, lay out and pack tasks[0..n) — `threads` host threads do the nibble packing —
+ * then bin them: the batch manager's (qlen, tlen, w) bins of BASELINE.json.
+ *   - lane bins: seeds the lane-per-task kernel can take (bwa-style matrix, no N, short query,
+ *     16-bit score range), each side sorted by query length so a wave holds equal-length queries;
+ *   - wave classes: everything else, by the number of eh[] columns a lane must hold. */
 static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, int threads,
                       uint64_t *seq_dst /* may be NULL: use ph.seq */, size_t seq_cap, packed_host &ph,
                       bsw_dtask *task_dst, uint32_t *order_dst, size_t *seq_words_out)
 {
     const int mx = mat_max(p->mat);
     std::vector<uint64_t> off(n + 1);
-    std::vector<uint8_t> cls(n);
-    uint32_t count[MAX_CLASSES] = {0};
+    std::vector<uint8_t> has_n(n ? n : 1, 0);
     uint64_t acc = 0;
     for (size_t i = 0; i < n; ++i) {
         const bsw_task &t = tasks[i];
@@ -253,10 +292,6 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
             return fail(ctx, BSW_E_LIMIT, "task %zu: score range beyond BSW_MAX_SCORE", i);
         if ((t.lqlen && (!t.lquery || (t.ltlen && !t.ltarget))) || (t.rqlen && (!t.rquery || (t.rtlen && !t.rtarget))))
             return fail(ctx, BSW_E_INVAL, "task %zu: NULL sequence pointer", i);
-        const int c = task_class(t.lqlen > t.rqlen ? t.lqlen : t.rqlen);
-        if (c < 0) return fail(ctx, BSW_E_LIMIT, "task %zu: no kernel class", i);
-        cls[i] = (uint8_t)c;
-        ++count[c];
         off[i] = acc;
         acc += (t.lqlen ? nwords(t.lqlen) + nwords(t.ltlen) : 0) + (t.rqlen ? nwords(t.rqlen) + nwords(t.rtlen) : 0);
     }
@@ -268,29 +303,24 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
     bsw_dtask *dt = task_dst;
     if (!dt) { ph.tasks.resize(n); dt = ph.tasks.data(); }
     uint32_t *ord = order_dst;
-    if (!ord) { ph.order.resize(n ? n : 1); ord = ph.order.data(); }
-
-    /* counting sort by class -> launch order */
-    uint32_t pos[MAX_CLASSES];
-    ph.cls_start[0] = 0;
-    for (int c = 0; c < MAX_CLASSES; ++c) ph.cls_start[c + 1] = ph.cls_start[c] + count[c];
-    for (int c = 0; c < MAX_CLASSES; ++c) pos[c] = ph.cls_start[c];
-    for (size_t i = 0; i < n; ++i) ord[pos[cls[i]]++] = (uint32_t)i;
+    if (!ord) { ph.order.assign(order_capacity(n), 0); ord = ph.order.data(); }
 
     auto work = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const bsw_task &t = tasks[i];
             bsw_dtask &d = dt[i];
             uint64_t o = off[i];
+            unsigned nn = 0;
             memset(&d, 0, sizeof(d));
             if (t.lqlen) {
-                d.lq_off = (uint32_t)o; pack_seq(t.lquery, t.lqlen, seq + o); o += nwords(t.lqlen);
-                d.lt_off = (uint32_t)o; pack_seq(t.ltarget, t.ltlen, seq + o); o += nwords(t.ltlen);
+                d.lq_off = (uint32_t)o; nn |= pack_seq(t.lquery, t.lqlen, seq + o); o += nwords(t.lqlen);
+                d.lt_off = (uint32_t)o; nn |= pack_seq(t.ltarget, t.ltlen, seq + o); o += nwords(t.ltlen);
             }
             if (t.rqlen) {
-                d.rq_off = (uint32_t)o; pack_seq(t.rquery, t.rqlen, seq + o); o += nwords(t.rqlen);
-                d.rt_off = (uint32_t)o; pack_seq(t.rtarget, t.rtlen, seq + o); o += nwords(t.rtlen);
+                d.rq_off = (uint32_t)o; nn |= pack_seq(t.rquery, t.rqlen, seq + o); o += nwords(t.rqlen);
+                d.rt_off = (uint32_t)o; nn |= pack_seq(t.rtarget, t.rtlen, seq + o); o += nwords(t.rtlen);
             }
+            has_n[i] = (uint8_t)nn;
             d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
             d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
             d.wlim_l = (uint16_t)gap_limit(p, mx, t.lqlen, p->pen_clip5);
@@ -308,6 +338,85 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
         }
         for (auto &t : th) t.join();
     }
+
+    /* ---- binning ---- */
+    batch_plan &pl = ph.plan;
+    pl = batch_plan();
+    const int nlc = bsw::lane_class_count();
+    const int lane_cols = bsw::lane_class_cols(nlc - 1);
+    const int kern = ctx ? ctx->cfg.kernel : BSW_KERNEL_AUTO;
+    const bool lane_params = kern != BSW_KERNEL_WAVE && lane_matrix_ok(p);
+    const int a = p->mat[0];
+    std::vector<uint8_t> is_lane(n ? n : 1, 0);
+    uint32_t n_lane = 0;
+    if (lane_params) {
+        for (size_t i = 0; i < n; ++i) {
+            const bsw_task &t = tasks[i];
+            const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
+            if (!has_n[i] && qm + 1 <= lane_cols && (int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * a < 65000) {
+                is_lane[i] = 1;
+                ++n_lane;
+            }
+        }
+        if (kern == BSW_KERNEL_AUTO && n_lane < LANE_AUTO_MIN) {
+            std::fill(is_lane.begin(), is_lane.end(), 0);
+            n_lane = 0;
+        }
+    }
+    /* wave classes: counting sort by columns-per-lane class */
+    uint32_t count[MAX_CLASSES] = {0};
+    std::vector<uint8_t> cls(n ? n : 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        if (is_lane[i]) continue;
+        const bsw_task &t = tasks[i];
+        const int c = task_class(t.lqlen > t.rqlen ? t.lqlen : t.rqlen);
+        if (c < 0) return fail(ctx, BSW_E_LIMIT, "task %zu: no kernel class", i);
+        cls[i] = (uint8_t)c;
+        ++count[c];
+    }
+    uint32_t pos[MAX_CLASSES];
+    pl.wave_start[0] = 0;
+    for (int c = 0; c < MAX_CLASSES; ++c) pl.wave_start[c + 1] = pl.wave_start[c] + count[c];
+    for (int c = 0; c < MAX_CLASSES; ++c) pos[c] = pl.wave_start[c];
+    for (size_t i = 0; i < n; ++i)
+        if (!is_lane[i]) ord[pos[cls[i]]++] = (uint32_t)i;
+    uint32_t cur = pl.wave_start[MAX_CLASSES];
+    /* lane seeds (finalize pass) */
+    pl.lane_all_off = cur;
+    pl.lane_all_cnt = n_lane;
+    for (size_t i = 0; i < n; ++i)
+        if (is_lane[i]) ord[cur++] = (uint32_t)i;
+    /* per side: counting sort by query length, cut into lane classes */
+    for (int side = 0; side < 2; ++side) {
+        std::vector<uint32_t> hist((size_t)lane_cols + 1, 0);
+        for (uint32_t k = 0; k < n_lane; ++k) {
+            const bsw_task &t = tasks[ord[pl.lane_all_off + k]];
+            const int q = side ? t.rqlen : t.lqlen;
+            if (q > 0) ++hist[(size_t)q];
+        }
+        uint32_t *offs = side ? pl.laneR_off : pl.laneL_off;
+        std::vector<uint32_t> start((size_t)lane_cols + 1, 0);
+        uint32_t run = cur;
+        int c = 0;
+        offs[0] = cur;
+        for (int q = 1; q <= lane_cols; ++q) {
+            while (c < nlc && q + 1 > bsw::lane_class_cols(c)) offs[++c] = run;
+            start[(size_t)q] = run;
+            run += hist[(size_t)q];
+        }
+        while (c < nlc) offs[++c] = run;
+        for (int cc = nlc + 1; cc <= MAX_LANE_CLASSES; ++cc) offs[cc] = run;
+        for (uint32_t k = 0; k < n_lane; ++k) {
+            const uint32_t ti = ord[pl.lane_all_off + k];
+            const bsw_task &t = tasks[ti];
+            const int q = side ? t.rqlen : t.lqlen;
+            if (q > 0) ord[start[(size_t)q]++] = ti;
+        }
+        cur = run;
+    }
+    pl.redo_off = cur;
+    pl.order_len = cur + n_lane;
+    pl.redo_cls = task_class(lane_cols - 1);
     if (seq_words_out) *seq_words_out = (size_t)acc;
     return BSW_OK;
 }
@@ -339,11 +448,12 @@ extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tas
     HIPCHK(ctx, hipSetDevice(ctx->device));
     bsw_dev_batch *b = new bsw_dev_batch();
     b->n = n; b->P = dp; b->variant = p->variant; b->seq_words = words;
-    memcpy(b->cls_start, ph.cls_start, sizeof(b->cls_start));
+    b->plan = ph.plan;
+    const size_t olen = (size_t)ph.plan.order_len + 1;          /* + redo counter */
     hipError_t e = hipSuccess;
     if ((e = hipMalloc((void **)&b->d_seq, (words + 1) * sizeof(uint64_t))) != hipSuccess ||
         (e = hipMalloc((void **)&b->d_tasks, (n + 1) * sizeof(bsw_dtask))) != hipSuccess ||
-        (e = hipMalloc((void **)&b->d_order, (n + 1) * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&b->d_order, (olen + 1) * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&b->d_out, (n + 1) * sizeof(bsw_result))) != hipSuccess) {
         bsw_free_batch(ctx, b);
         return fail(ctx, BSW_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
@@ -351,7 +461,7 @@ extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tas
     hipStream_t s = ctx->streams[0];
     if ((e = hipMemcpyAsync(b->d_seq, ph.seq.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, s)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_tasks, ph.tasks.data(), n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s)) != hipSuccess ||
-        (e = hipMemcpyAsync(b->d_order, ph.order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s)) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_order, ph.order.data(), olen * sizeof(uint32_t), hipMemcpyHostToDevice, s)) != hipSuccess ||
         (e = hipMemsetAsync(b->d_out, 0xff, n * sizeof(bsw_result), s)) != hipSuccess ||
         (e = hipStreamSynchronize(s)) != hipSuccess) {
         bsw_free_batch(ctx, b);
@@ -362,14 +472,34 @@ extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tas
 }
 
 static int enqueue_batch(bsw_ctx *ctx, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
-                         const uint32_t *d_order, const uint32_t *cls_start, bsw_result *d_out, hipStream_t s, uint64_t *launches)
+                         uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches)
 {
     const int nc = bsw::wave_class_count();
     for (int c = 0; c < nc; ++c) {
-        const uint32_t cnt = cls_start[c + 1] - cls_start[c];
+        const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
         if (!cnt) continue;
-        HIPCHK(ctx, bsw::launch_wave(c, variant, P, d_seq, d_tasks, d_order + cls_start[c], cnt, d_out, s));
+        HIPCHK(ctx, bsw::launch_wave(c, variant, P, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, d_out, s));
         if (launches) ++*launches;
+    }
+    if (pl.lane_all_cnt) {
+        uint32_t *redo_cnt = d_order + pl.order_len;
+        HIPCHK(ctx, hipMemsetAsync(redo_cnt, 0, sizeof(uint32_t), s));
+        const int nlc = bsw::lane_class_count();
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t *offs = side ? pl.laneR_off : pl.laneL_off;
+            for (int c = 0; c < nlc; ++c) {
+                const uint32_t cnt = offs[c + 1] - offs[c];
+                if (!cnt) continue;
+                HIPCHK(ctx, bsw::launch_lane(c, variant, P, side, d_seq, d_tasks, d_order + offs[c], cnt, d_out, s));
+                if (launches) ++*launches;
+            }
+        }
+        HIPCHK(ctx, bsw::launch_finalize(P, d_tasks, d_order + pl.lane_all_off, pl.lane_all_cnt, d_out,
+                                         d_order + pl.redo_off, redo_cnt, s));
+        /* seeds whose first band try was not final: recompute from scratch, one wavefront each */
+        HIPCHK(ctx, bsw::launch_wave(pl.redo_cls, variant, P, d_seq, d_tasks, d_order + pl.redo_off, pl.lane_all_cnt,
+                                     redo_cnt, d_out, s));
+        if (launches) *launches += 2;
     }
     return BSW_OK;
 }
@@ -393,7 +523,7 @@ extern "C" int bsw_run(bsw_ctx *ctx, bsw_dev_batch *b)
     }
     HIPCHK(ctx, hipEventRecord(e0, s));
     b->launches = 0;
-    int rc = enqueue_batch(ctx, b->P, b->variant, b->d_seq, b->d_tasks, b->d_order, b->cls_start, b->d_out, s, &b->launches);
+    int rc = enqueue_batch(ctx, b->P, b->variant, b->d_seq, b->d_tasks, b->d_order, b->plan, b->d_out, s, &b->launches);
     if (rc) return rc;
     HIPCHK(ctx, hipEventRecord(e1, s));
     ctx->ev_last0 = e0; ctx->ev_last1 = e1;
@@ -443,7 +573,7 @@ extern "C" int bsw_batch_info(const bsw_dev_batch *b, uint64_t *n_tasks, uint64_
 {
     if (!b) return BSW_E_INVAL;
     if (n_tasks) *n_tasks = b->n;
-    if (in_bytes) *in_bytes = b->seq_words * 8 + b->n * (sizeof(bsw_dtask) + sizeof(uint32_t));
+    if (in_bytes) *in_bytes = b->seq_words * 8 + b->n * sizeof(bsw_dtask) + (uint64_t)b->plan.redo_off * sizeof(uint32_t);
     if (out_bytes) *out_bytes = b->n * sizeof(bsw_result);
     if (n_launches) *n_launches = b->launches;
     return BSW_OK;
@@ -517,8 +647,8 @@ static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, si
             s.task_cap = std::max(cnt, chunk);
             if ((e = hipHostMalloc((void **)&s.h_tasks, s.task_cap * sizeof(bsw_dtask), hipHostMallocDefault)) != hipSuccess ||
                 (e = hipMalloc((void **)&s.d_tasks, s.task_cap * sizeof(bsw_dtask))) != hipSuccess ||
-                (e = hipHostMalloc((void **)&s.h_order, s.task_cap * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&s.d_order, s.task_cap * sizeof(uint32_t))) != hipSuccess ||
+                (e = hipHostMalloc((void **)&s.h_order, order_capacity(s.task_cap) * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&s.d_order, order_capacity(s.task_cap) * sizeof(uint32_t))) != hipSuccess ||
                 (e = hipHostMalloc((void **)&s.h_out, s.task_cap * sizeof(bsw_result), hipHostMallocDefault)) != hipSuccess ||
                 (e = hipMalloc((void **)&s.d_out, s.task_cap * sizeof(bsw_result))) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_NOMEM, "staging: %s", hipGetErrorString(e)); }
         }
@@ -528,8 +658,8 @@ static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, si
         if (rc) { cleanup(); return rc; }
         if ((e = hipMemcpyAsync(s.d_seq, s.h_seq, w2 * 8, hipMemcpyHostToDevice, st)) != hipSuccess ||
             (e = hipMemcpyAsync(s.d_tasks, s.h_tasks, cnt * sizeof(bsw_dtask), hipMemcpyHostToDevice, st)) != hipSuccess ||
-            (e = hipMemcpyAsync(s.d_order, s.h_order, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_HIP, "H2D: %s", hipGetErrorString(e)); }
-        rc = enqueue_batch(ctx, dp, p.variant, s.d_seq, s.d_tasks, s.d_order, ph.cls_start, s.d_out, st, nullptr);
+            (e = hipMemcpyAsync(s.d_order, s.h_order, ((size_t)ph.plan.order_len + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_HIP, "H2D: %s", hipGetErrorString(e)); }
+        rc = enqueue_batch(ctx, dp, p.variant, s.d_seq, s.d_tasks, s.d_order, ph.plan, s.d_out, st, nullptr);
         if (rc) { cleanup(); return rc; }
         if ((e = hipMemcpyAsync(s.h_out, s.d_out, cnt * sizeof(bsw_result), hipMemcpyDeviceToHost, st)) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_HIP, "D2H: %s", hipGetErrorString(e)); }
         s.base = base; s.cnt = cnt; s.busy = true;

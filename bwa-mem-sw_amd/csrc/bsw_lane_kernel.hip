@@ -1,0 +1,295 @@
+/*
+ * bsw_lane_kernel.hip — gfx950 kernel: ONE LANE PER EXTENSION (inter-task SIMD), for bins of
+ * seeds with (nearly) equal query length — the batch manager's (qlen, tlen, w) bins.
+ *
+ * Each lane runs the scalar ksw_extend2 recurrence of one side of one seed verbatim
+ * (sw_pe_array_sw_extend.v:1639-1705, CPU semantics of SURVEY.md §8a); the 64 lanes of a wave
+ * walk DP row i together.  The lane's whole eh[] row lives in VGPRs as 16-bit pairs
+ * P[j] = (eh[j].e << 16) | eh[j].h, addressed statically because the column loop is fully
+ * unrolled (8-column blocks); blocks no live lane touches are skipped with scalar branches,
+ * blocks inside every live lane's [beg,end) run a mask-free "dense" body.
+ *   - score lookup: the query is held as two bit-planes per lane; per row the target base
+ *     selects a match mask, per cell one v_bfe_u32 + v_mad_u32_u24 gives +a / -b;
+ *   - only the first band try runs here.  A side that would need MAX_BAND_TRY's second pass
+ *     (sw_pe_array_sw_extend.v:1837,1859) marks its seed for the wave-per-task kernel, which
+ *     recomputes the seed from scratch (bsw_pair_finalize + redo list).
+ * Eligibility (enforced by the host): bwa-style matrix (a on the diagonal, -b off it, N row/col
+ * never used because the seed has no N), qlen < 8*QB, h0 + qlen*a < 32768.
+ */
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "bsw_device.h"
+
+namespace bsw {
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int ldpp(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ int wave_max_all(int x)
+{
+    x = max(x, ldpp<0x111>(INT_MIN, x));
+    x = max(x, ldpp<0x112>(INT_MIN, x));
+    x = max(x, ldpp<0x114>(INT_MIN, x));
+    x = max(x, ldpp<0x118>(INT_MIN, x));
+    x = max(x, ldpp<0x142, 0xa>(INT_MIN, x));
+    x = max(x, ldpp<0x143, 0xc>(INT_MIN, x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+/* every 4th bit of a 64-bit word (bit `b` of each nibble) gathered into 16 contiguous bits */
+__device__ __forceinline__ uint32_t nibble_plane(uint64_t w, int b)
+{
+    uint64_t x = (w >> b) & 0x1111111111111111ull;
+    x = (x | (x >> 3)) & 0x0303030303030303ull;
+    x = (x | (x >> 6)) & 0x000F000F000F000Full;
+    x = (x | (x >> 12)) & 0x000000FF000000FFull;
+    x = (x | (x >> 24)) & 0xFFFFull;
+    return (uint32_t)x;
+}
+
+struct lane_consts {
+    int ab, negb, oe_del, e_del, oe_ins, e_ins;      /* ab = a + b, negb = -b */
+};
+
+/* One DP cell of column J for every lane whose [beg,end) contains J (EDGE) or for all live lanes (dense). */
+template <int VAR, bool SYM, bool EDGE>
+__device__ __forceinline__ void lane_cell(uint32_t &Pj, const int J, const uint32_t rmw, const lane_consts &k,
+                                          const int beg, const int len, const int end,
+                                          int &h1, int &f, int &mk, int &fnz, int &lnz)
+{
+    bool inr = true;
+    if (EDGE) inr = (unsigned)(J - beg) < (unsigned)len;
+    if (inr) {
+        const uint32_t p = Pj;
+        const int hd = (int)(p & 0xffffu), e = (int)(p >> 16);       /* eh[j].h = H(i-1,j-1), eh[j].e */
+        const int bit = (int)((rmw >> (J & 31)) & 1u);                /* 1 on match (q_j == t_i)        */
+        int M = (hd + k.negb) + __mul24(bit, k.ab);                   /* H(i-1,j-1) + (+a | -b) (:1797,1915-1940) */
+        if (VAR == BSW_VARIANT_M) M = hd ? M : 0;
+        const int h = max(max(M, e), f);                              /* (:1798,1809)                   */
+        mk = max(mk, (h << 8) | J);                                   /* row max, ties -> later j       */
+        const int base = VAR == BSW_VARIANT_M ? M : h;
+        const int tD = base - k.oe_del;
+        const int tI = SYM ? tD : base - k.oe_ins;
+        const int en = max(max(e - k.e_del, tD), 0);                  /* (:1866,1770-1771)              */
+        f = max(max(f - k.e_ins, tI), 0);                             /* (:1863,1780-1781)              */
+        const uint32_t np = ((uint32_t)en << 16) | (uint32_t)h1;      /* eh[j] = {e', H(i,j-1)} (:1776) */
+        Pj = np;
+        h1 = h;
+        const bool nz = np != 0;
+        lnz = nz ? J : lnz;
+        fnz = min(fnz, nz ? J : INT_MAX);
+    }
+    if (EDGE) Pj = J == end ? (uint32_t)h1 : Pj;                      /* eh[end] = {0, h1} (:1775)      */
+}
+
+template <int QB, int VAR, bool SYM>
+__global__ __launch_bounds__(256, 2) void bsw_lane_kernel(const bsw_dparams P, const int side,
+                                                          const uint64_t *__restrict__ seq,
+                                                          const bsw_dtask *__restrict__ tasks,
+                                                          const uint32_t *__restrict__ order, const uint32_t n,
+                                                          bsw_result *__restrict__ out)
+{
+    constexpr int QMAX = QB * 8;
+    constexpr int NW = (QMAX + 31) / 32;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const bool valid = slot < n;
+    const uint32_t ti = valid ? order[slot] : order[0];
+    const bsw_dtask T = tasks[ti];
+    int qlen, tlen, wlim, h0;
+    uint32_t q_off, t_off;
+    if (side == 0) {
+        qlen = T.lqlen; tlen = T.ltlen; wlim = T.wlim_l; q_off = T.lq_off; t_off = T.lt_off; h0 = T.h0;
+    } else {
+        qlen = T.rqlen; tlen = T.rtlen; wlim = T.wlim_r; q_off = T.rq_off; t_off = T.rt_off;
+        h0 = T.lqlen > 0 ? out[ti].left.score : T.h0;                 /* h0 = score after the left ext (:1671) */
+    }
+    if (!valid) tlen = 0;
+    const int w = min(P.w, wlim);
+    lane_consts k;
+    k.negb = P.mat[1]; k.ab = P.mat[0] - P.mat[1];
+    k.oe_del = P.o_del + P.e_del; k.e_del = P.e_del; k.oe_ins = P.o_ins + P.e_ins; k.e_ins = P.e_ins;
+    const int o_del = P.o_del, e_del = P.e_del, zdrop = P.zdrop;
+
+    /* query -> two bit-planes (code bit 0, code bit 1), 32 columns per word */
+    uint32_t Q0[NW], Q1[NW];
+#pragma unroll
+    for (int wd = 0; wd < NW; ++wd) { Q0[wd] = 0; Q1[wd] = 0; }
+#pragma unroll
+    for (int v = 0; v < (QMAX + 15) / 16; ++v) {
+        const uint64_t qw = v * 16 < qlen ? seq[q_off + v] : 0ull;
+        Q0[v >> 1] |= nibble_plane(qw, 0) << ((v & 1) * 16);
+        Q1[v >> 1] |= nibble_plane(qw, 1) << ((v & 1) * 16);
+    }
+
+    /* K2 first row, closed form: eh[0]=h0, eh[j]=max(h0-oe_ins-(j-1)e_ins,0), e=0 */
+    uint32_t Pr[QMAX];
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) Pr[j] = (uint32_t)(j == 0 ? h0 : max(h0 - k.oe_ins - (j - 1) * k.e_ins, 0));
+
+    int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
+    unsigned cells = 0;
+    bool alive = tlen > 0;
+    uint64_t tw_next = alive ? seq[t_off] : 0ull, tw = 0;
+
+    for (int i = 0;; ++i) {
+        const bool act = alive && i < tlen;
+        if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+        if ((i & 15) == 0) {                                          /* 16 target bases per uint64, prefetched */
+            tw = tw_next;
+            const int nx = (i >> 4) + 1;
+            tw_next = (act && nx * 16 < tlen) ? seq[t_off + nx] : 0ull;
+        }
+        /* K3 band clamp, K4 column 0 (per lane) */
+        const int nb = max(beg, i - w), ne = min(min(end, i + w + 1), qlen);
+        beg = act ? nb : beg;
+        end = act ? ne : end;
+        const int len = max(end - beg, 0);
+        /* live column range of the wave: blocks outside are skipped, blocks inside every lane's range run dense */
+        const int jlo = -wave_max_all(act ? -beg : INT_MIN);
+        const int jhi = wave_max_all(act ? end : INT_MIN);
+        const int jbm = wave_max_all(act ? beg : INT_MIN);
+        const int jem = -wave_max_all(act ? -end : INT_MIN);
+        if (act) {
+            const int tb = (int)((tw >> ((i & 15) * 4)) & 3);
+            const uint32_t n0 = (uint32_t)((tb & 1) - 1), n1 = (uint32_t)(((tb >> 1) & 1) - 1);
+            uint32_t rm[NW];
+#pragma unroll
+            for (int wd = 0; wd < NW; ++wd) rm[wd] = (Q0[wd] ^ n0) & (Q1[wd] ^ n1);   /* 1 where q_j == t_i */
+            int h1 = beg == 0 ? max(h0 - (o_del + e_del * (i + 1)), 0) : 0;
+            int f = 0, mk = -1, fnz = INT_MAX, lnz = -1;
+            cells += (unsigned)len;
+#pragma unroll
+            for (int blk = 0; blk < QB; ++blk) {
+                const int j0 = blk * 8;
+                if (j0 + 8 <= jlo || j0 > jhi) continue;
+                if (j0 >= jbm && j0 + 8 <= jem) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        lane_cell<VAR, SYM, false>(Pr[j0 + c], j0 + c, rm[(j0 + c) >> 5], k, beg, len, end, h1, f, mk, fnz, lnz);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        lane_cell<VAR, SYM, true>(Pr[j0 + c], j0 + c, rm[(j0 + c) >> 5], k, beg, len, end, h1, f, mk, fnz, lnz);
+                }
+            }
+            /* K7 row tail */
+            if (max(beg, end) == qlen) {                              /* ties -> later i (:1829-1833) */
+                max_ie = gscore > h1 ? max_ie : i;
+                gscore = max(gscore, h1);
+            }
+            const int m = mk < 0 ? 0 : (mk >> 8), mj = mk < 0 ? -1 : (mk & 255);
+            bool stop = m == 0;                                       /* (:1942) */
+            if (m > mx) {
+                mx = m; max_i = i; max_j = mj;
+                max_off = max(max_off, abs(mj - i));
+            } else if (zdrop > 0) {
+                const int di = i - max_i, dj = mj - max_j;
+                const int pen = di > dj ? (di - dj) * e_del : (dj - di) * k.e_ins;
+                stop = stop || (mx - m - pen > zdrop);
+            }
+            /* K8 next-row range (CPU semantics) */
+            const int nbeg = fnz < end ? fnz : end;
+            const int last = h1 != 0 ? end : (lnz >= 0 ? lnz : nbeg - 1);
+            beg = nbeg;
+            end = min(last + 2, qlen);
+            alive = !stop;
+        }
+    }
+    if (valid) {
+        bsw_ext x;
+        x.score = mx; x.qle = max_j + 1; x.tle = max_i + 1; x.gtle = max_ie + 1;
+        x.gscore = gscore; x.max_off = max_off; x.aw = P.w; x.cells = cells;
+        if (side == 0) out[ti].left = x; else out[ti].right = x;
+    }
+}
+
+/* Pair-level decision for seeds whose sides came from the lane kernel (P2/P3:
+ * sw_pe_array_proc_element.v:1593-1685).  A seed whose first band try does not satisfy the
+ * MAX_BAND_TRY exit test goes to the redo list instead. */
+__global__ __launch_bounds__(256) void bsw_pair_finalize(const bsw_dparams P, const bsw_dtask *__restrict__ tasks,
+                                                         const uint32_t *__restrict__ order, const uint32_t n,
+                                                         bsw_result *__restrict__ out,
+                                                         uint32_t *__restrict__ redo, uint32_t *__restrict__ redo_cnt)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= n) return;
+    const uint32_t ti = order[slot];
+    const bsw_dtask T = tasks[ti];
+    bsw_result r = out[ti];
+    const int thr = (P.w >> 1) + (P.w >> 2);
+    bool retry = false;
+    int score = T.init_score, truesc, qb, rb, qe, re;
+    if (T.lqlen > 0) {
+        if (P.max_band_try > 1 && !(r.left.score == score || r.left.max_off < thr)) retry = true;
+        score = r.left.score;
+        if (r.left.gscore <= 0 || r.left.gscore <= score - P.pen_clip5) { qb = T.qbeg - r.left.qle; rb = -r.left.tle; truesc = score; }
+        else { qb = 0; rb = -r.left.gtle; truesc = r.left.gscore; }
+    } else {
+        score = truesc = T.h0; qb = 0; rb = 0;
+        r.left.score = 0; r.left.qle = r.left.tle = r.left.gtle = 0; r.left.gscore = 0; r.left.max_off = 0;
+        r.left.aw = P.w; r.left.cells = 0;
+    }
+    const int sc0 = score;
+    if (T.rqlen > 0) {
+        if (P.max_band_try > 1 && !(r.right.score == sc0 || r.right.max_off < thr)) retry = true;
+        score = r.right.score;
+        if (r.right.gscore <= 0 || r.right.gscore <= score - P.pen_clip3) { qe = r.right.qle; re = r.right.tle; truesc += score - sc0; }
+        else { qe = T.rqlen; re = r.right.gtle; truesc += r.right.gscore - sc0; }
+    } else {
+        qe = 0; re = 0;
+        r.right.score = 0; r.right.qle = r.right.tle = r.right.gtle = 0; r.right.gscore = 0; r.right.max_off = 0;
+        r.right.aw = P.w; r.right.cells = 0;
+    }
+    if (retry) {
+        redo[atomicAdd(redo_cnt, 1u)] = ti;
+        return;
+    }
+    r.tag = T.tag; r.qb = qb; r.qe = qe; r.rb = rb; r.re = re; r.score = score; r.truesc = truesc; r.w = P.w;
+    out[ti] = r;
+}
+
+static const int kLaneBlocks[] = {9, 13, 17};
+
+int lane_class_count() { return (int)(sizeof(kLaneBlocks) / sizeof(kLaneBlocks[0])); }
+int lane_class_cols(int cls) { return kLaneBlocks[cls] * 8; }
+
+template <int QB>
+static hipError_t launch_lane_qb(int variant, bool sym, const bsw_dparams &P, int side, const uint64_t *seq,
+                                 const bsw_dtask *tasks, const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
+{
+    const dim3 grid((n + 255u) / 256u), block(256);
+    if (variant == BSW_VARIANT_M) {
+        if (sym) hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_M, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+        else hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_M, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+    } else {
+        if (sym) hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_H, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+        else hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_H, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
+                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins;
+    switch (kLaneBlocks[cls]) {
+    case 9: return launch_lane_qb<9>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    case 13: return launch_lane_qb<13>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    default: return launch_lane_qb<17>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    }
+}
+
+hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
+                           bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(bsw_pair_finalize, dim3((n + 255u) / 256u), dim3(256), 0, s, P, tasks, order, n, out, redo, redo_cnt);
+    return hipGetLastError();
+}
+
+}  // namespace bsw

@@ -247,51 +247,55 @@ __device__ __forceinline__ void extend_side(const bsw_dparams &P, const uint64_t
 template <int C, int VAR>
 __global__ __launch_bounds__(256) void bsw_wave_kernel(const bsw_dparams P, const uint64_t *__restrict__ seq,
                                                        const bsw_dtask *__restrict__ tasks,
-                                                       const uint32_t *__restrict__ order, uint32_t n,
+                                                       const uint32_t *__restrict__ order, const uint32_t n_host,
+                                                       const uint32_t *__restrict__ n_dev,
                                                        bsw_result *__restrict__ out)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t slot = blockIdx.x * 4u + (uint32_t)sget((int)(threadIdx.x >> 6));
-    if (slot >= n) return;
-    const uint32_t ti = order[slot];
-    const bsw_dtask T = tasks[ti];
+    /* n_dev != NULL: the seed count is produced on the device (redo list of the lane kernel);
+     * the grid is then sized by an upper bound and strides over the list. */
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    for (uint32_t slot = blockIdx.x * 4u + (uint32_t)sget((int)(threadIdx.x >> 6)); slot < n; slot += gridDim.x * 4u) {
+        const uint32_t ti = order[slot];
+        const bsw_dtask T = tasks[ti];
 
-    side_out L, R;
-    L.score = 0; L.qle = L.tle = L.gtle = 0; L.gscore = 0; L.max_off = 0; L.aw = P.w; L.cells = 0;
-    R = L;
-    int score = T.init_score, truesc, qb, rb, qe, re;
-    if (T.lqlen > 0) {
-        extend_side<C, VAR>(P, seq, T.lq_off, T.lt_off, T.lqlen, T.ltlen, T.wlim_l, 0, T.h0, score, lane, L);
-        score = L.score;
-        if (L.gscore <= 0 || L.gscore <= score - P.pen_clip5) {     /* local (:1672,1674-1675) */
-            qb = T.qbeg - L.qle; rb = -L.tle; truesc = score;
-        } else {                                                    /* to-end */
-            qb = 0; rb = -L.gtle; truesc = L.gscore;
-        }
-    } else {
-        score = truesc = T.h0; qb = 0; rb = 0;
-    }
-    const int sc0 = score;                                          /* h0 of the right side (:1671) */
-    if (T.rqlen > 0) {
-        extend_side<C, VAR>(P, seq, T.rq_off, T.rt_off, T.rqlen, T.rtlen, T.wlim_r, 0, sc0, score, lane, R);
-        score = R.score;
-        if (R.gscore <= 0 || R.gscore <= score - P.pen_clip3) {
-            qe = R.qle; re = R.tle; truesc += score - sc0;
+        side_out L, R;
+        L.score = 0; L.qle = L.tle = L.gtle = 0; L.gscore = 0; L.max_off = 0; L.aw = P.w; L.cells = 0;
+        R = L;
+        int score = T.init_score, truesc, qb, rb, qe, re;
+        if (T.lqlen > 0) {
+            extend_side<C, VAR>(P, seq, T.lq_off, T.lt_off, T.lqlen, T.ltlen, T.wlim_l, 0, T.h0, score, lane, L);
+            score = L.score;
+            if (L.gscore <= 0 || L.gscore <= score - P.pen_clip5) {     /* local (:1672,1674-1675) */
+                qb = T.qbeg - L.qle; rb = -L.tle; truesc = score;
+            } else {                                                    /* to-end */
+                qb = 0; rb = -L.gtle; truesc = L.gscore;
+            }
         } else {
-            qe = T.rqlen; re = R.gtle; truesc += R.gscore - sc0;
+            score = truesc = T.h0; qb = 0; rb = 0;
         }
-    } else {
-        qe = 0; re = 0;
-    }
-    if (lane == 0) {
-        bsw_result r;
-        r.tag = T.tag; r.qb = qb; r.qe = qe; r.rb = rb; r.re = re;
-        r.score = score; r.truesc = truesc; r.w = max(L.aw, R.aw);   /* P3 (:1684,1669) */
-        r.left.score = L.score; r.left.qle = L.qle; r.left.tle = L.tle; r.left.gtle = L.gtle;
-        r.left.gscore = L.gscore; r.left.max_off = L.max_off; r.left.aw = L.aw; r.left.cells = L.cells;
-        r.right.score = R.score; r.right.qle = R.qle; r.right.tle = R.tle; r.right.gtle = R.gtle;
-        r.right.gscore = R.gscore; r.right.max_off = R.max_off; r.right.aw = R.aw; r.right.cells = R.cells;
-        out[ti] = r;
+        const int sc0 = score;                                          /* h0 of the right side (:1671) */
+        if (T.rqlen > 0) {
+            extend_side<C, VAR>(P, seq, T.rq_off, T.rt_off, T.rqlen, T.rtlen, T.wlim_r, 0, sc0, score, lane, R);
+            score = R.score;
+            if (R.gscore <= 0 || R.gscore <= score - P.pen_clip3) {
+                qe = R.qle; re = R.tle; truesc += score - sc0;
+            } else {
+                qe = T.rqlen; re = R.gtle; truesc += R.gscore - sc0;
+            }
+        } else {
+            qe = 0; re = 0;
+        }
+        if (lane == 0) {
+            bsw_result r;
+            r.tag = T.tag; r.qb = qb; r.qe = qe; r.rb = rb; r.re = re;
+            r.score = score; r.truesc = truesc; r.w = max(L.aw, R.aw);   /* P3 (:1684,1669) */
+            r.left.score = L.score; r.left.qle = L.qle; r.left.tle = L.tle; r.left.gtle = L.gtle;
+            r.left.gscore = L.gscore; r.left.max_off = L.max_off; r.left.aw = L.aw; r.left.cells = L.cells;
+            r.right.score = R.score; r.right.qle = R.qle; r.right.tle = R.tle; r.right.gtle = R.gtle;
+            r.right.gscore = R.gscore; r.right.max_off = R.max_off; r.right.aw = R.aw; r.right.cells = R.cells;
+            out[ti] = r;
+        }
     }
 }
 
@@ -302,27 +306,30 @@ int wave_class_cols(int cls) { return kWaveClasses[cls] * 64; }
 
 template <int C>
 static hipError_t launch_c(int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
-                           const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
+                           const uint32_t *order, uint32_t n, const uint32_t *n_dev, bsw_result *out, hipStream_t s)
 {
-    const dim3 grid((n + 3u) / 4u), block(256);
+    uint32_t blocks = (n + 3u) / 4u;
+    if (n_dev && blocks > 8192u) blocks = 8192u;        /* device-side count: stride over the list */
+    const dim3 grid(blocks), block(256);
     if (variant == BSW_VARIANT_M)
-        hipLaunchKernelGGL((bsw_wave_kernel<C, BSW_VARIANT_M>), grid, block, 0, s, P, seq, tasks, order, n, out);
+        hipLaunchKernelGGL((bsw_wave_kernel<C, BSW_VARIANT_M>), grid, block, 0, s, P, seq, tasks, order, n, n_dev, out);
     else
-        hipLaunchKernelGGL((bsw_wave_kernel<C, BSW_VARIANT_H>), grid, block, 0, s, P, seq, tasks, order, n, out);
+        hipLaunchKernelGGL((bsw_wave_kernel<C, BSW_VARIANT_H>), grid, block, 0, s, P, seq, tasks, order, n, n_dev, out);
     return hipGetLastError();
 }
 
+/* n = seed count (or an upper bound of *n_dev when n_dev != NULL) */
 hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
-                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
+                       const uint32_t *order, uint32_t n, const uint32_t *n_dev, bsw_result *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     switch (kWaveClasses[cls]) {
-    case 1: return launch_c<1>(variant, P, seq, tasks, order, n, out, s);
-    case 2: return launch_c<2>(variant, P, seq, tasks, order, n, out, s);
-    case 3: return launch_c<3>(variant, P, seq, tasks, order, n, out, s);
-    case 4: return launch_c<4>(variant, P, seq, tasks, order, n, out, s);
-    case 8: return launch_c<8>(variant, P, seq, tasks, order, n, out, s);
-    default: return launch_c<16>(variant, P, seq, tasks, order, n, out, s);
+    case 1: return launch_c<1>(variant, P, seq, tasks, order, n, n_dev, out, s);
+    case 2: return launch_c<2>(variant, P, seq, tasks, order, n, n_dev, out, s);
+    case 3: return launch_c<3>(variant, P, seq, tasks, order, n, n_dev, out, s);
+    case 4: return launch_c<4>(variant, P, seq, tasks, order, n, n_dev, out, s);
+    case 8: return launch_c<8>(variant, P, seq, tasks, order, n, n_dev, out, s);
+    default: return launch_c<16>(variant, P, seq, tasks, order, n, n_dev, out, s);
     }
 }
 

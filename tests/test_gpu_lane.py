@@ -1,0 +1,142 @@
+"""Lane-per-task kernel (inter-task SIMD bins) vs the CPU oracle, forced with BSW_KERNEL_LANE so even
+small batches go through it; the wave-per-task kernel handles what the lane bins cannot take
+(N, long queries, general matrices) and every seed whose first band try is not final (redo list)."""
+import numpy as np
+import pytest
+
+import _gen
+import _golden
+from test_gpu_parity import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lctx(host):
+    c = host.BswContext(device=0, kernel=host.KERNEL_LANE)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def wctx(host):
+    c = host.BswContext(device=0, kernel=host.KERNEL_WAVE)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("zdrop", [0, 100])
+def test_single_bin(host, oracle, lctx, variant, zdrop):
+    p = host.default_params(variant=variant, zdrop=zdrop)
+    tasks, arena = host.synth_tasks(6000, seed=40 + variant)
+    assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=8), tasks)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_mixed_bins_both_sides(host, oracle, lctx, wctx, variant):
+    p = host.default_params(variant=variant)
+    tasks, arena = host.synth_tasks(9000, seed=50 + variant, seed_len_min=19, seed_len_max=60, seed_at_start=0,
+                                    sub_rate=0.02, indel_rate=0.01, junk_frac=0.2, n_rate=0.001)
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    assert_same(lctx.extend_pairs(p, tasks), want, tasks)
+    assert_same(wctx.extend_pairs(p, tasks), want, tasks)
+
+
+@pytest.mark.parametrize("over", [
+    dict(w=1), dict(w=5, zdrop=0), dict(w=37, zdrop=7), dict(zdrop=1), dict(max_band_try=1), dict(max_band_try=3, w=8),
+    dict(o_del=0, e_del=1, o_ins=0, e_ins=1), dict(o_del=5, e_del=2, o_ins=7, e_ins=1), dict(o_del=11, e_del=3, o_ins=2, e_ins=4),
+    dict(pen_clip5=0, pen_clip3=0), dict(pen_clip5=20, pen_clip3=1),
+])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_parameter_space(host, oracle, lctx, over, variant):
+    rng = np.random.default_rng(1000 + len(str(over)) + variant)
+    seeds = _gen.random_seeds(rng, 900, qmax=134, indel=0.04, junk=0.15, nrate=0.0005)
+    tasks, arena = host.make_tasks(seeds)
+    p = host.default_params(variant=variant, **over)
+    assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=8), tasks)
+
+
+@pytest.mark.parametrize("ab", [(1, 4), (2, 3), (3, 0), (5, 9)])
+def test_match_mismatch_scores(host, oracle, lctx, ab):
+    rng = np.random.default_rng(sum(ab))
+    seeds = _gen.random_seeds(rng, 700, qmax=120, indel=0.03, h0max=200)
+    tasks, arena = host.make_tasks(seeds)
+    for variant in (0, 1):
+        p = host.default_params(variant=variant)
+        p["mat"][0] = host.bwa_matrix(a=ab[0], b=ab[1], n=-1)
+        assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=8), tasks)
+
+
+# lane classes hold qlen+1 <= 72 / 104 / 136 columns
+@pytest.mark.parametrize("qlen", [1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 70, 71, 72, 102, 103, 104, 134, 135, 136])
+def test_lane_class_boundaries(host, oracle, lctx, qlen):
+    rng = np.random.default_rng(500 + qlen)
+    seeds = []
+    for k in range(200):
+        tl = int(qlen * 1.5) + int(rng.integers(0, 20))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = _gen.mutate(rng, t, qlen, 0.03, 0.01 if k % 2 else 0.0)
+        s = {"rq": q, "rt": t, "h0": int(rng.integers(1, 60))}
+        if k % 3 == 0:
+            ql2 = int(rng.integers(1, qlen + 1))
+            s["lq"], s["lt"] = q[:ql2][::-1].copy(), t[::-1].copy()
+        seeds.append(s)
+    tasks, arena = host.make_tasks(seeds)
+    for variant in (0, 1):
+        p = host.default_params(variant=variant)
+        assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=4), tasks)
+
+
+def test_edge_shapes(host, oracle, lctx):
+    z = np.zeros(0, np.uint8)
+    a40 = (np.arange(40) % 4).astype(np.uint8)
+    seeds = [
+        dict(rq=a40, rt=z, h0=9), dict(rq=a40[:1], rt=a40[:1], h0=1), dict(lq=a40, lt=a40, h0=30),
+        dict(lq=a40, lt=z, rq=a40, rt=z, h0=3), dict(rq=a40, rt=np.tile(a40, 100), h0=10),
+        dict(rq=a40, rt=(a40 + 1) % 4, h0=1), dict(lq=a40, lt=a40, rq=a40, rt=a40, h0=19, init_score=59),
+        dict(rq=a40, rt=a40, h0=1000), dict(rq=np.tile(a40, 3), rt=np.tile(a40, 30), h0=60000),
+        dict(rq=np.tile(a40, 3), rt=np.tile(a40, 4), h0=64000),     # beyond the 16-bit bins -> wave kernel
+    ] * 7
+    tasks, arena = host.make_tasks(seeds)
+    for variant in (0, 1):
+        for zd in (0, 100):
+            p = host.default_params(variant=variant, zdrop=zd)
+            assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks), tasks)
+
+
+def test_band_retry_goes_through_redo_list(host, oracle, lctx):
+    rng = np.random.default_rng(7)
+    seeds = []
+    for k in range(600):
+        q = rng.integers(0, 4, 120).astype(np.uint8)
+        if k % 3 == 0:
+            seeds.append(dict(rq=q, rt=np.concatenate([q, rng.integers(0, 4, 80).astype(np.uint8)]), h0=40))   # no retry
+            continue
+        gap = int(rng.integers(50, 110))
+        if k % 2:
+            t = np.concatenate([q[:50], rng.integers(0, 4, gap).astype(np.uint8), q[50:], rng.integers(0, 4, 40).astype(np.uint8)])
+            seeds.append(dict(rq=q, rt=t, h0=60))
+        else:
+            qq = np.concatenate([q[:40], rng.integers(0, 4, gap // 3).astype(np.uint8), q[40:]])[:134]
+            seeds.append(dict(lq=qq, lt=np.concatenate([q, rng.integers(0, 4, 100).astype(np.uint8)]), rq=q[:30], rt=q[:50], h0=60))
+    tasks, arena = host.make_tasks(seeds)
+    p = host.default_params(w=50, zdrop=0)
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    assert (want["w"] == 100).sum() > 30 and (want["w"] == 50).sum() > 30
+    assert_same(lctx.extend_pairs(p, tasks), want, tasks)
+
+
+@pytest.mark.parametrize("name", _golden.names())
+def test_golden_fixtures(host, lctx, name):
+    tasks, arena, cases = _golden.load(host, name)
+    for pname, (params, expect) in cases.items():
+        assert_same(lctx.extend_pairs(params, tasks), expect, tasks)
+
+
+def test_ragged_last_wave_and_tiny_batches(host, oracle, lctx):
+    p = host.default_params()
+    tasks, arena = host.synth_tasks(1000, seed=77, seed_len_min=19, seed_len_max=50, seed_at_start=0)
+    want = oracle.pair_batch(p, tasks, nthreads=4)
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 1000):
+        assert_same(lctx.extend_pairs(p, tasks[:n]), want[:n], tasks[:n])
