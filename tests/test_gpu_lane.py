@@ -105,22 +105,27 @@ def test_edge_shapes(host, oracle, lctx):
             assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks), tasks)
 
 
-def test_band_retry_goes_through_redo_list(host, oracle, lctx):
+def _retry_seeds():
     rng = np.random.default_rng(7)
     seeds = []
     for k in range(600):
-        q = rng.integers(0, 4, 120).astype(np.uint8)
+        q = rng.integers(0, 4, 90).astype(np.uint8)
+        tail = rng.integers(0, 4, 60).astype(np.uint8)
         if k % 3 == 0:
-            seeds.append(dict(rq=q, rt=np.concatenate([q, rng.integers(0, 4, 80).astype(np.uint8)]), h0=40))   # no retry
+            seeds.append(dict(rq=q, rt=np.concatenate([q, tail]), h0=40))                       # no retry
             continue
-        gap = int(rng.integers(50, 110))
+        gap = int(rng.integers(38, 50))                                                         # >= 3/4 of w=50, inside the band
         if k % 2:
-            t = np.concatenate([q[:50], rng.integers(0, 4, gap).astype(np.uint8), q[50:], rng.integers(0, 4, 40).astype(np.uint8)])
+            t = np.concatenate([q[:45], rng.integers(0, 4, gap).astype(np.uint8), q[45:], tail])      # long deletion, right side
             seeds.append(dict(rq=q, rt=t, h0=60))
         else:
-            qq = np.concatenate([q[:40], rng.integers(0, 4, gap // 3).astype(np.uint8), q[40:]])[:134]
-            seeds.append(dict(lq=qq, lt=np.concatenate([q, rng.integers(0, 4, 100).astype(np.uint8)]), rq=q[:30], rt=q[:50], h0=60))
-    tasks, arena = host.make_tasks(seeds)
+            qq = np.concatenate([q[:40], rng.integers(0, 4, gap).astype(np.uint8), q[40:]])[:134]     # long insertion, left side
+            seeds.append(dict(lq=qq, lt=np.concatenate([q, tail]), rq=q[:30], rt=q[:50], h0=60))
+    return seeds
+
+
+def test_band_retry_goes_through_redo_list(host, oracle, lctx):
+    tasks, arena = host.make_tasks(_retry_seeds())
     p = host.default_params(w=50, zdrop=0)
     want = oracle.pair_batch(p, tasks, nthreads=8)
     assert (want["w"] == 100).sum() > 30 and (want["w"] == 50).sum() > 30
