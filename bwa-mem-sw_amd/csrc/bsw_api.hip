@@ -30,6 +30,7 @@ hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_
                        const uint32_t *order, uint32_t n, const uint32_t *n_dev, bsw_result *out, hipStream_t s);
 int lane_class_count();
 int lane_class_cols(int cls);
+int lane_class_bits(int cls);
 hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
                        const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
 hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
@@ -37,7 +38,7 @@ hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const u
 }  // namespace bsw
 
 #define MAX_CLASSES 8
-#define MAX_LANE_CLASSES 4
+#define MAX_LANE_CLASSES 8
 #define LANE_AUTO_MIN 2048      /* BSW_KERNEL_AUTO: lane bins only pay off when they fill many waves */
 
 /* How one batch is cut into kernel launches (all offsets index the device `order` array).
@@ -343,31 +344,41 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
     batch_plan &pl = ph.plan;
     pl = batch_plan();
     const int nlc = bsw::lane_class_count();
-    const int lane_cols = bsw::lane_class_cols(nlc - 1);
+    int cols8 = 0, cols16 = 0;                       /* widest lane class per value width */
+    for (int c = 0; c < nlc; ++c) {
+        if (bsw::lane_class_bits(c) == 8) cols8 = std::max(cols8, bsw::lane_class_cols(c));
+        else cols16 = std::max(cols16, bsw::lane_class_cols(c));
+    }
     const int kern = ctx ? ctx->cfg.kernel : BSW_KERNEL_AUTO;
     const bool lane_params = kern != BSW_KERNEL_WAVE && lane_matrix_ok(p);
     const int a = p->mat[0];
-    std::vector<uint8_t> is_lane(n ? n : 1, 0);
+    std::vector<uint8_t> lane_bits(n ? n : 1, 0);    /* 0 = wave kernel, 8 / 16 = lane kernel value width */
     uint32_t n_lane = 0;
     if (lane_params) {
         for (size_t i = 0; i < n; ++i) {
+            if (has_n[i]) continue;
             const bsw_task &t = tasks[i];
             const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
-            if (!has_n[i] && qm + 1 <= lane_cols && (int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * a < 65000) {
-                is_lane[i] = 1;
-                ++n_lane;
-            }
+            const int64_t top = (int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * a;     /* no H can exceed this */
+            if (top <= 255 && qm + 1 <= cols8) lane_bits[i] = 8;
+            else if (top < 65000 && qm + 1 <= cols16) lane_bits[i] = 16;
+            if (lane_bits[i]) ++n_lane;
         }
         if (kern == BSW_KERNEL_AUTO && n_lane < LANE_AUTO_MIN) {
-            std::fill(is_lane.begin(), is_lane.end(), 0);
+            std::fill(lane_bits.begin(), lane_bits.end(), 0);
             n_lane = 0;
         }
     }
+    auto side_class = [&](int bits, int q) {
+        for (int c = 0; c < nlc; ++c)
+            if (bsw::lane_class_bits(c) == bits && q + 1 <= bsw::lane_class_cols(c)) return c;
+        return nlc - 1;
+    };
     /* wave classes: counting sort by columns-per-lane class */
     uint32_t count[MAX_CLASSES] = {0};
     std::vector<uint8_t> cls(n ? n : 1, 0);
     for (size_t i = 0; i < n; ++i) {
-        if (is_lane[i]) continue;
+        if (lane_bits[i]) continue;
         const bsw_task &t = tasks[i];
         const int c = task_class(t.lqlen > t.rqlen ? t.lqlen : t.rqlen);
         if (c < 0) return fail(ctx, BSW_E_LIMIT, "task %zu: no kernel class", i);
@@ -379,44 +390,46 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
     for (int c = 0; c < MAX_CLASSES; ++c) pl.wave_start[c + 1] = pl.wave_start[c] + count[c];
     for (int c = 0; c < MAX_CLASSES; ++c) pos[c] = pl.wave_start[c];
     for (size_t i = 0; i < n; ++i)
-        if (!is_lane[i]) ord[pos[cls[i]]++] = (uint32_t)i;
+        if (!lane_bits[i]) ord[pos[cls[i]]++] = (uint32_t)i;
     uint32_t cur = pl.wave_start[MAX_CLASSES];
     /* lane seeds (finalize pass) */
     pl.lane_all_off = cur;
     pl.lane_all_cnt = n_lane;
     for (size_t i = 0; i < n; ++i)
-        if (is_lane[i]) ord[cur++] = (uint32_t)i;
-    /* per side: counting sort by query length, cut into lane classes */
+        if (lane_bits[i]) ord[cur++] = (uint32_t)i;
+    /* per side: counting sort by (lane class, query length) so a wave holds equal-length queries */
     for (int side = 0; side < 2; ++side) {
-        std::vector<uint32_t> hist((size_t)lane_cols + 1, 0);
-        for (uint32_t k = 0; k < n_lane; ++k) {
-            const bsw_task &t = tasks[ord[pl.lane_all_off + k]];
-            const int q = side ? t.rqlen : t.lqlen;
-            if (q > 0) ++hist[(size_t)q];
-        }
-        uint32_t *offs = side ? pl.laneR_off : pl.laneL_off;
-        std::vector<uint32_t> start((size_t)lane_cols + 1, 0);
-        uint32_t run = cur;
-        int c = 0;
-        offs[0] = cur;
-        for (int q = 1; q <= lane_cols; ++q) {
-            while (c < nlc && q + 1 > bsw::lane_class_cols(c)) offs[++c] = run;
-            start[(size_t)q] = run;
-            run += hist[(size_t)q];
-        }
-        while (c < nlc) offs[++c] = run;
-        for (int cc = nlc + 1; cc <= MAX_LANE_CLASSES; ++cc) offs[cc] = run;
-        for (uint32_t k = 0; k < n_lane; ++k) {
-            const uint32_t ti = ord[pl.lane_all_off + k];
+        std::vector<uint32_t> hist((size_t)nlc * 256 + 1, 0);
+        auto key = [&](uint32_t ti) -> int {
             const bsw_task &t = tasks[ti];
             const int q = side ? t.rqlen : t.lqlen;
-            if (q > 0) ord[start[(size_t)q]++] = ti;
+            return q > 0 ? side_class(lane_bits[ti], q) * 256 + q : -1;
+        };
+        for (uint32_t k = 0; k < n_lane; ++k) {
+            const int kk = key(ord[pl.lane_all_off + k]);
+            if (kk >= 0) ++hist[(size_t)kk];
+        }
+        uint32_t *offs = side ? pl.laneR_off : pl.laneL_off;
+        std::vector<uint32_t> start((size_t)nlc * 256 + 1, 0);
+        uint32_t run = cur;
+        for (int c = 0; c < nlc; ++c) {
+            offs[c] = run;
+            for (int q = 0; q < 256; ++q) {
+                start[(size_t)c * 256 + q] = run;
+                run += hist[(size_t)c * 256 + q];
+            }
+        }
+        for (int c = nlc; c <= MAX_LANE_CLASSES; ++c) offs[c] = run;
+        for (uint32_t k = 0; k < n_lane; ++k) {
+            const uint32_t ti = ord[pl.lane_all_off + k];
+            const int kk = key(ti);
+            if (kk >= 0) ord[start[(size_t)kk]++] = ti;
         }
         cur = run;
     }
     pl.redo_off = cur;
     pl.order_len = cur + n_lane;
-    pl.redo_cls = task_class(lane_cols - 1);
+    pl.redo_cls = task_class(std::max(cols8, cols16) - 1);
     if (seq_words_out) *seq_words_out = (size_t)acc;
     return BSW_OK;
 }

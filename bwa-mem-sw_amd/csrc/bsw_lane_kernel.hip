@@ -4,17 +4,21 @@
  *
  * Each lane runs the scalar ksw_extend2 recurrence of one side of one seed verbatim
  * (sw_pe_array_sw_extend.v:1639-1705, CPU semantics of SURVEY.md §8a); the 64 lanes of a wave
- * walk DP row i together.  The lane's whole eh[] row lives in VGPRs as 16-bit pairs
- * P[j] = (eh[j].e << 16) | eh[j].h, addressed statically because the column loop is fully
- * unrolled (8-column blocks); blocks no live lane touches are skipped with scalar branches,
- * blocks inside every live lane's [beg,end) run a mask-free "dense" body.
- *   - score lookup: the query is held as two bit-planes per lane; per row the target base
- *     selects a match mask, per cell one v_bfe_u32 + v_mad_u32_u24 gives +a / -b;
+ * walk DP row i together.  The lane's whole eh[] row lives in VGPRs, addressed statically
+ * because the column loop is fully unrolled in 8-column blocks:
+ *     B8  : two columns per VGPR, 8-bit h and e   (h0 + qlen*a <= 255 — the RTL's own int8
+ *           datapath, sw_pe_array_sw_extend.v:101-108, but unsigned and range-checked by the host)
+ *     !B8 : one column per VGPR, 16-bit h and e
+ * Blocks no live lane touches are skipped with scalar branches, blocks inside every live lane's
+ * [beg,end) run a mask-free "dense" body, the rest an exec-masked "edge" body.
+ *   - score lookup: the query is held as two bit-planes per lane in LDS; per row the target base
+ *     selects a 32-column match mask, per cell one bit extract gives +a / -b;
+ *   - the packed target (16 bases per uint64) is staged per wave in LDS, 128 rows at a time;
  *   - only the first band try runs here.  A side that would need MAX_BAND_TRY's second pass
  *     (sw_pe_array_sw_extend.v:1837,1859) marks its seed for the wave-per-task kernel, which
  *     recomputes the seed from scratch (bsw_pair_finalize + redo list).
  * Eligibility (enforced by the host): bwa-style matrix (a on the diagonal, -b off it, N row/col
- * never used because the seed has no N), qlen < 8*QB, h0 + qlen*a < 32768.
+ * never used because the seed has no N), qlen < 8*QB, score range as above.
  */
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -55,17 +59,21 @@ struct lane_consts {
     int ab, negb, oe_del, e_del, oe_ins, e_ins;      /* ab = a + b, negb = -b */
 };
 
-/* One DP cell of column J for every lane whose [beg,end) contains J (EDGE) or for all live lanes (dense). */
-template <int VAR, bool SYM, bool EDGE>
-__device__ __forceinline__ void lane_cell(uint32_t &Pj, const int J, const uint32_t rmw, const lane_consts &k,
+/* One DP cell of column J for every lane whose [beg,end) contains J (EDGE) or for all live lanes (dense).
+ * Pw is the VGPR holding eh[J]: B8 -> byte pair at bit (J&1)*16, else the whole word. */
+template <int VAR, bool SYM, bool EDGE, bool B8>
+__device__ __forceinline__ void lane_cell(uint32_t &Pw, const int J, const uint32_t rmw, const lane_consts &k,
                                           const int beg, const int len, const int end,
                                           int &h1, int &f, int &mk, int &fnz, int &lnz)
 {
+    constexpr uint32_t HM = B8 ? 0xffu : 0xffffu;
+    constexpr int HB = B8 ? 8 : 16;
+    const int sh = B8 ? (J & 1) * 16 : 0;
     bool inr = true;
     if (EDGE) inr = (unsigned)(J - beg) < (unsigned)len;
     if (inr) {
-        const uint32_t p = Pj;
-        const int hd = (int)(p & 0xffffu), e = (int)(p >> 16);       /* eh[j].h = H(i-1,j-1), eh[j].e */
+        const uint32_t p = Pw >> sh;
+        const int hd = (int)(p & HM), e = (int)((p >> HB) & HM);     /* eh[j].h = H(i-1,j-1), eh[j].e */
         const int bit = (int)((rmw >> (J & 31)) & 1u);                /* 1 on match (q_j == t_i)        */
         int M = (hd + k.negb) + __mul24(bit, k.ab);                   /* H(i-1,j-1) + (+a | -b) (:1797,1915-1940) */
         if (VAR == BSW_VARIANT_M) M = hd ? M : 0;
@@ -76,73 +84,104 @@ __device__ __forceinline__ void lane_cell(uint32_t &Pj, const int J, const uint3
         const int tI = SYM ? tD : base - k.oe_ins;
         const int en = max(max(e - k.e_del, tD), 0);                  /* (:1866,1770-1771)              */
         f = max(max(f - k.e_ins, tI), 0);                             /* (:1863,1780-1781)              */
-        const uint32_t np = ((uint32_t)en << 16) | (uint32_t)h1;      /* eh[j] = {e', H(i,j-1)} (:1776) */
-        Pj = np;
+        const uint32_t np = ((uint32_t)en << HB) | (uint32_t)h1;      /* eh[j] = {e', H(i,j-1)} (:1776) */
+        if (B8) Pw = (Pw & ~(0xffffu << sh)) | (np << sh);
+        else Pw = np;
         h1 = h;
         const bool nz = np != 0;
         lnz = nz ? J : lnz;
         fnz = min(fnz, nz ? J : INT_MAX);
     }
-    if (EDGE) Pj = J == end ? (uint32_t)h1 : Pj;                      /* eh[end] = {0, h1} (:1775)      */
+    if (EDGE) {                                                       /* eh[end] = {0, h1} (:1775)      */
+        const uint32_t pe = B8 ? ((Pw & ~(0xffffu << sh)) | ((uint32_t)h1 << sh)) : (uint32_t)h1;
+        Pw = J == end ? pe : Pw;
+    }
 }
 
-template <int QB, int VAR, bool SYM>
-__global__ __launch_bounds__(256, 2) void bsw_lane_kernel(const bsw_dparams P, const int side,
-                                                          const uint64_t *__restrict__ seq,
-                                                          const bsw_dtask *__restrict__ tasks,
-                                                          const uint32_t *__restrict__ order, const uint32_t n,
-                                                          bsw_result *__restrict__ out)
+#define BSW_LANE_TCHUNK 8       /* target words staged per wave in LDS = 128 DP rows */
+
+template <int QB, int VAR, bool SYM, bool B8, int WPS>
+__global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P, const int side,
+                                                            const uint64_t *__restrict__ seq,
+                                                            const bsw_dtask *__restrict__ tasks,
+                                                            const uint32_t *__restrict__ order, const uint32_t n,
+                                                            bsw_result *__restrict__ out)
 {
     constexpr int QMAX = QB * 8;
     constexpr int NW = (QMAX + 31) / 32;
+    constexpr int NP = B8 ? QMAX / 2 : QMAX;
+    __shared__ uint64_t lds_t[4][BSW_LANE_TCHUNK][64];              /* [wave][word][lane]          */
+    __shared__ uint32_t lds_q[4][2 * NW][64];                       /* query bit-planes            */
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     const bool valid = slot < n;
     const uint32_t ti = valid ? order[slot] : order[0];
-    const bsw_dtask T = tasks[ti];
-    int qlen, tlen, wlim, h0;
-    uint32_t q_off, t_off;
-    if (side == 0) {
-        qlen = T.lqlen; tlen = T.ltlen; wlim = T.wlim_l; q_off = T.lq_off; t_off = T.lt_off; h0 = T.h0;
-    } else {
-        qlen = T.rqlen; tlen = T.rtlen; wlim = T.wlim_r; q_off = T.rq_off; t_off = T.rt_off;
-        h0 = T.lqlen > 0 ? out[ti].left.score : T.h0;                 /* h0 = score after the left ext (:1671) */
+    int qlen, tlen, h0, w;
+    uint32_t t_off;
+    {
+        const bsw_dtask T = tasks[ti];
+        int wlim;
+        uint32_t q_off;
+        if (side == 0) {
+            qlen = T.lqlen; tlen = T.ltlen; wlim = T.wlim_l; q_off = T.lq_off; t_off = T.lt_off; h0 = T.h0;
+        } else {
+            qlen = T.rqlen; tlen = T.rtlen; wlim = T.wlim_r; q_off = T.rq_off; t_off = T.rt_off;
+            h0 = T.lqlen > 0 ? out[ti].left.score : T.h0;             /* h0 = score after the left ext (:1671) */
+        }
+        if (!valid) tlen = 0;
+        w = min(P.w, wlim);
+        /* query -> two bit-planes (code bit 0, code bit 1), 32 columns per word, parked in LDS */
+#pragma unroll
+        for (int wd = 0; wd < NW; ++wd) {
+            uint32_t q0 = 0, q1 = 0;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int v = wd * 2 + hlf;
+                if (v < (QMAX + 15) / 16) {
+                    const uint64_t qw = v * 16 < qlen ? seq[q_off + v] : 0ull;
+                    q0 |= nibble_plane(qw, 0) << (hlf * 16);
+                    q1 |= nibble_plane(qw, 1) << (hlf * 16);
+                }
+            }
+            lds_q[wv][2 * wd][lane] = q0;
+            lds_q[wv][2 * wd + 1][lane] = q1;
+        }
     }
-    if (!valid) tlen = 0;
-    const int w = min(P.w, wlim);
     lane_consts k;
     k.negb = P.mat[1]; k.ab = P.mat[0] - P.mat[1];
     k.oe_del = P.o_del + P.e_del; k.e_del = P.e_del; k.oe_ins = P.o_ins + P.e_ins; k.e_ins = P.e_ins;
     const int o_del = P.o_del, e_del = P.e_del, zdrop = P.zdrop;
-
-    /* query -> two bit-planes (code bit 0, code bit 1), 32 columns per word */
-    uint32_t Q0[NW], Q1[NW];
-#pragma unroll
-    for (int wd = 0; wd < NW; ++wd) { Q0[wd] = 0; Q1[wd] = 0; }
-#pragma unroll
-    for (int v = 0; v < (QMAX + 15) / 16; ++v) {
-        const uint64_t qw = v * 16 < qlen ? seq[q_off + v] : 0ull;
-        Q0[v >> 1] |= nibble_plane(qw, 0) << ((v & 1) * 16);
-        Q1[v >> 1] |= nibble_plane(qw, 1) << ((v & 1) * 16);
-    }
+    const int ntw = (tlen + 15) >> 4;
 
     /* K2 first row, closed form: eh[0]=h0, eh[j]=max(h0-oe_ins-(j-1)e_ins,0), e=0 */
-    uint32_t Pr[QMAX];
+    uint32_t Pr[NP];
 #pragma unroll
-    for (int j = 0; j < QMAX; ++j) Pr[j] = (uint32_t)(j == 0 ? h0 : max(h0 - k.oe_ins - (j - 1) * k.e_ins, 0));
+    for (int c = 0; c < NP; ++c) {
+        if (B8) {
+            const int j = 2 * c;
+            const uint32_t lo = (uint32_t)(j == 0 ? h0 : max(h0 - k.oe_ins - (j - 1) * k.e_ins, 0));
+            const uint32_t hi = (uint32_t)max(h0 - k.oe_ins - j * k.e_ins, 0);
+            Pr[c] = lo | (hi << 16);
+        } else {
+            Pr[c] = (uint32_t)(c == 0 ? h0 : max(h0 - k.oe_ins - (c - 1) * k.e_ins, 0));
+        }
+    }
 
     int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
     unsigned cells = 0;
     bool alive = tlen > 0;
-    uint64_t tw_next = alive ? seq[t_off] : 0ull, tw = 0;
+    uint64_t tw = 0;
 
     for (int i = 0;; ++i) {
         const bool act = alive && i < tlen;
         if (__builtin_amdgcn_ballot_w64(act) == 0) break;
-        if ((i & 15) == 0) {                                          /* 16 target bases per uint64, prefetched */
-            tw = tw_next;
-            const int nx = (i >> 4) + 1;
-            tw_next = (act && nx * 16 < tlen) ? seq[t_off + nx] : 0ull;
+        if ((i & (BSW_LANE_TCHUNK * 16 - 1)) == 0) {                  /* stage the next 128 target bases of every lane */
+            const int w0 = i >> 4;
+#pragma unroll
+            for (int x = 0; x < BSW_LANE_TCHUNK; ++x)
+                lds_t[wv][x][lane] = (act && w0 + x < ntw) ? seq[t_off + w0 + x] : 0ull;
         }
+        if ((i & 15) == 0) tw = lds_t[wv][(i >> 4) & (BSW_LANE_TCHUNK - 1)][lane];
         /* K3 band clamp, K4 column 0 (per lane) */
         const int nb = max(beg, i - w), ne = min(min(end, i + w + 1), qlen);
         beg = act ? nb : beg;
@@ -158,7 +197,8 @@ __global__ __launch_bounds__(256, 2) void bsw_lane_kernel(const bsw_dparams P, c
             const uint32_t n0 = (uint32_t)((tb & 1) - 1), n1 = (uint32_t)(((tb >> 1) & 1) - 1);
             uint32_t rm[NW];
 #pragma unroll
-            for (int wd = 0; wd < NW; ++wd) rm[wd] = (Q0[wd] ^ n0) & (Q1[wd] ^ n1);   /* 1 where q_j == t_i */
+            for (int wd = 0; wd < NW; ++wd)                            /* 1 where q_j == t_i */
+                rm[wd] = (lds_q[wv][2 * wd][lane] ^ n0) & (lds_q[wv][2 * wd + 1][lane] ^ n1);
             int h1 = beg == 0 ? max(h0 - (o_del + e_del * (i + 1)), 0) : 0;
             int f = 0, mk = -1, fnz = INT_MAX, lnz = -1;
             cells += (unsigned)len;
@@ -169,11 +209,11 @@ __global__ __launch_bounds__(256, 2) void bsw_lane_kernel(const bsw_dparams P, c
                 if (j0 >= jbm && j0 + 8 <= jem) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
-                        lane_cell<VAR, SYM, false>(Pr[j0 + c], j0 + c, rm[(j0 + c) >> 5], k, beg, len, end, h1, f, mk, fnz, lnz);
+                        lane_cell<VAR, SYM, false, B8>(Pr[B8 ? (j0 + c) / 2 : j0 + c], j0 + c, rm[(j0 + c) >> 5], k, beg, len, end, h1, f, mk, fnz, lnz);
                 } else {
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
-                        lane_cell<VAR, SYM, true>(Pr[j0 + c], j0 + c, rm[(j0 + c) >> 5], k, beg, len, end, h1, f, mk, fnz, lnz);
+                        lane_cell<VAR, SYM, true, B8>(Pr[B8 ? (j0 + c) / 2 : j0 + c], j0 + c, rm[(j0 + c) >> 5], k, beg, len, end, h1, f, mk, fnz, lnz);
                 }
             }
             /* K7 row tail */
@@ -252,22 +292,25 @@ __global__ __launch_bounds__(256) void bsw_pair_finalize(const bsw_dparams P, co
     out[ti] = r;
 }
 
-static const int kLaneBlocks[] = {9, 13, 17};
+/* lane classes: (bits per h/e value, 8-column blocks).  8-bit classes first. */
+struct lane_class_t { int bits, qb; };
+static const lane_class_t kLaneClasses[] = {{8, 9}, {8, 17}, {16, 9}, {16, 17}};
 
-int lane_class_count() { return (int)(sizeof(kLaneBlocks) / sizeof(kLaneBlocks[0])); }
-int lane_class_cols(int cls) { return kLaneBlocks[cls] * 8; }
+int lane_class_count() { return (int)(sizeof(kLaneClasses) / sizeof(kLaneClasses[0])); }
+int lane_class_cols(int cls) { return kLaneClasses[cls].qb * 8; }
+int lane_class_bits(int cls) { return kLaneClasses[cls].bits; }
 
-template <int QB>
+template <int QB, bool B8, int WPS>
 static hipError_t launch_lane_qb(int variant, bool sym, const bsw_dparams &P, int side, const uint64_t *seq,
                                  const bsw_dtask *tasks, const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
 {
     const dim3 grid((n + 255u) / 256u), block(256);
     if (variant == BSW_VARIANT_M) {
-        if (sym) hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_M, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
-        else hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_M, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+        if (sym) hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_M, true, B8, WPS>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+        else hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_M, false, B8, WPS>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
     } else {
-        if (sym) hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_H, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
-        else hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_H, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+        if (sym) hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_H, true, B8, WPS>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+        else hipLaunchKernelGGL((bsw_lane_kernel<QB, BSW_VARIANT_H, false, B8, WPS>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
     }
     return hipGetLastError();
 }
@@ -277,10 +320,11 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
 {
     if (n == 0) return hipSuccess;
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins;
-    switch (kLaneBlocks[cls]) {
-    case 9: return launch_lane_qb<9>(variant, sym, P, side, seq, tasks, order, n, out, s);
-    case 13: return launch_lane_qb<13>(variant, sym, P, side, seq, tasks, order, n, out, s);
-    default: return launch_lane_qb<17>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    switch (cls) {
+    case 0: return launch_lane_qb<9, true, 4>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    case 1: return launch_lane_qb<17, true, 4>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    case 2: return launch_lane_qb<9, false, 3>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    default: return launch_lane_qb<17, false, 2>(variant, sym, P, side, seq, tasks, order, n, out, s);
     }
 }
 
