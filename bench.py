@@ -35,8 +35,24 @@ WORKLOADS = {
 }
 
 VALU_OPS_PER_CELL = 15          # integer VALU ops of one DP cell
-PEAK_INT32_TOPS = 256 * 128 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops/s (MI355X_MICROARCH.md)
+# int32 VALU roof: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s.  (A wave64 integer
+# VALU op holds its SIMD for 4 cycles: measured, SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles in
+# profiles/r1/*_pmc_summary.json; the 157 TFLOP/s fp32 figure counts packed FMA.)
+PEAK_INT32_TOPS = 256 * 64 * 2.4e9 / 1e12
 PEAK_HBM_GBS = 8000.0
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # rocprofv3 --pmc summary of this same command
+
+
+def pmc_traffic(workload, tasks):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE in KiB;
+    gfx950 correction of MI355X_MICROARCH.md §HBM: FETCH_SIZE x 2), or None if no matching profile."""
+    try:
+        j = json.load(open(PMC_FILE))
+        if j.get("workload") != workload or j.get("seeds_per_gpu") != tasks:
+            return None
+        return int((2 * j["FETCH_SIZE_KiB"] + j["WRITE_SIZE_KiB"]) * 1024)
+    except Exception:
+        return None
 
 
 def main():
@@ -132,7 +148,8 @@ def main():
             "nominal_gcups_qlen_x_tlen": round(nominal_all * args.steps / dt_all / 1e9, 3),
             "roofline": {
                 "bound": "hbm", "achieved": round(alg_bytes / (kavg_ms * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,
-                "unit": "GB/s", "frac": round(alg_bytes / (kavg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6), "traffic": None,
+                "unit": "GB/s", "frac": round(alg_bytes / (kavg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
+                "traffic": pmc_traffic(args.workload, args.tasks),
                 "kernel_ms_avg": round(kavg_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "integer max/add DP at ~0.02 B/cell: neither HBM nor MFMA binds; see roofline_valu",
             },
