@@ -12,7 +12,7 @@
  * Blocks no live lane touches are skipped with scalar branches, blocks inside every live lane's
  * [beg,end) run a mask-free "dense" body, the rest an exec-masked "edge" body.
  *   - score lookup: the query is held as two bit-planes per lane in LDS; per row the target base
- *     selects a 32-column match mask, per cell one bit extract gives +a / -b;
+ *     selects a 32-column match mask, per cell v_bfe_i32 + v_bfi give +a / -b;
  *   - the packed target (16 bases per uint64) is staged per wave in LDS, 128 rows at a time;
  *   - only the first band try runs here.  A side that would need MAX_BAND_TRY's second pass
  *     (sw_pe_array_sw_extend.v:1837,1859) marks its seed for the wave-per-task kernel, which
@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <utility>
 
 #include "bsw_device.h"
 
@@ -55,47 +56,64 @@ __device__ __forceinline__ uint32_t nibble_plane(uint64_t w, int b)
     return (uint32_t)x;
 }
 
+/* compile-time loop: every index is a constant from the front end on, so the eh[] register array is
+ * scalarised by the first SROA pass instead of depending on the loop unroller */
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 struct lane_consts {
-    int ab, negb, oe_del, e_del, oe_ins, e_ins;      /* ab = a + b, negb = -b */
+    int va, vnegb;                                   /* +a, -b held in VGPRs (v_bfi takes one SGPR at most) */
+    int oe_del, e_del, oe_ins, e_ins;
 };
 
+template <bool B8>
+__device__ __forceinline__ uint32_t eh_put(uint32_t Pw, const int J, const uint32_t np16)
+{
+    if (!B8) return np16;
+    return (J & 1) ? ((Pw & 0x0000ffffu) | (np16 << 16)) : ((Pw & 0xffff0000u) | np16);
+}
+
 /* One DP cell of column J for every lane whose [beg,end) contains J (EDGE) or for all live lanes (dense).
- * Pw is the VGPR holding eh[J]: B8 -> byte pair at bit (J&1)*16, else the whole word. */
+ * Pw is the VGPR holding eh[J]: B8 -> byte pair at bit (J&1)*16, else the whole word.
+ * Returns true when the stored eh[J] is non-zero (for the next-row trimming, K8). */
 template <int VAR, bool SYM, bool EDGE, bool B8>
-__device__ __forceinline__ void lane_cell(uint32_t &Pw, const int J, const uint32_t rmw, const lane_consts &k,
-                                          const int beg, const int len, const int end,
-                                          int &h1, int &f, int &mk, int &fnz, int &lnz)
+__device__ __forceinline__ bool lane_cell(uint32_t &Pw, const int J, const uint32_t rmw, const lane_consts &k,
+                                          const int beg, const int len, int &h1, int &f, int &mk)
 {
     constexpr uint32_t HM = B8 ? 0xffu : 0xffffu;
     constexpr int HB = B8 ? 8 : 16;
     const int sh = B8 ? (J & 1) * 16 : 0;
-    bool inr = true;
+    bool inr = true, nz = false;
     if (EDGE) inr = (unsigned)(J - beg) < (unsigned)len;
     if (inr) {
         const uint32_t p = Pw >> sh;
         const int hd = (int)(p & HM), e = (int)((p >> HB) & HM);     /* eh[j].h = H(i-1,j-1), eh[j].e */
-        const int bit = (int)((rmw >> (J & 31)) & 1u);                /* 1 on match (q_j == t_i)        */
-        int M = (hd + k.negb) + __mul24(bit, k.ab);                   /* H(i-1,j-1) + (+a | -b) (:1797,1915-1940) */
+        const int x = __builtin_amdgcn_sbfe(rmw, J & 31, 1);          /* -1 on match (q_j == t_i), else 0 */
+        int s;                                                        /* +a | -b (:1915-1940): (x & a) | (~x & -b); hipcc expands */
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(s) : "v"(x), "v"(k.va), "v"(k.vnegb));   /* the C form into 5 ops */
+        int M = hd + s;                                               /* (:1797)                        */
         if (VAR == BSW_VARIANT_M) M = hd ? M : 0;
         const int h = max(max(M, e), f);                              /* (:1798,1809)                   */
-        mk = max(mk, (h << 8) | J);                                   /* row max, ties -> later j       */
+        mk = max(mk, (h << 8) | (J & 63));                            /* row max of this 64-column group, ties -> later j */
         const int base = VAR == BSW_VARIANT_M ? M : h;
         const int tD = base - k.oe_del;
         const int tI = SYM ? tD : base - k.oe_ins;
         const int en = max(max(e - k.e_del, tD), 0);                  /* (:1866,1770-1771)              */
         f = max(max(f - k.e_ins, tI), 0);                             /* (:1863,1780-1781)              */
         const uint32_t np = ((uint32_t)en << HB) | (uint32_t)h1;      /* eh[j] = {e', H(i,j-1)} (:1776) */
-        if (B8) Pw = (Pw & ~(0xffffu << sh)) | (np << sh);
-        else Pw = np;
+        Pw = eh_put<B8>(Pw, J, np);
         h1 = h;
-        const bool nz = np != 0;
-        lnz = nz ? J : lnz;
-        fnz = min(fnz, nz ? J : INT_MAX);
+        nz = np != 0;
     }
-    if (EDGE) {                                                       /* eh[end] = {0, h1} (:1775)      */
-        const uint32_t pe = B8 ? ((Pw & ~(0xffffu << sh)) | ((uint32_t)h1 << sh)) : (uint32_t)h1;
-        Pw = J == end ? pe : Pw;
-    }
+    return nz;
 }
 
 #define BSW_LANE_TCHUNK 8       /* target words staged per wave in LDS = 128 DP rows */
@@ -148,24 +166,25 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
         }
     }
     lane_consts k;
-    k.negb = P.mat[1]; k.ab = P.mat[0] - P.mat[1];
+    k.va = P.mat[0]; k.vnegb = P.mat[1];
+    asm volatile("" : "+v"(k.va), "+v"(k.vnegb));
     k.oe_del = P.o_del + P.e_del; k.e_del = P.e_del; k.oe_ins = P.o_ins + P.e_ins; k.e_ins = P.e_ins;
     const int o_del = P.o_del, e_del = P.e_del, zdrop = P.zdrop;
     const int ntw = (tlen + 15) >> 4;
 
     /* K2 first row, closed form: eh[0]=h0, eh[j]=max(h0-oe_ins-(j-1)e_ins,0), e=0 */
     uint32_t Pr[NP];
-#pragma unroll
-    for (int c = 0; c < NP; ++c) {
+    static_for<NP>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
         if (B8) {
-            const int j = 2 * c;
+            constexpr int j = 2 * c;
             const uint32_t lo = (uint32_t)(j == 0 ? h0 : max(h0 - k.oe_ins - (j - 1) * k.e_ins, 0));
             const uint32_t hi = (uint32_t)max(h0 - k.oe_ins - j * k.e_ins, 0);
             Pr[c] = lo | (hi << 16);
         } else {
             Pr[c] = (uint32_t)(c == 0 ? h0 : max(h0 - k.oe_ins - (c - 1) * k.e_ins, 0));
         }
-    }
+    });
 
     int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
     unsigned cells = 0;
@@ -200,21 +219,55 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
             for (int wd = 0; wd < NW; ++wd)                            /* 1 where q_j == t_i */
                 rm[wd] = (lds_q[wv][2 * wd][lane] ^ n0) & (lds_q[wv][2 * wd + 1][lane] ^ n1);
             int h1 = beg == 0 ? max(h0 - (o_del + e_del * (i + 1)), 0) : 0;
-            int f = 0, mk = -1, fnz = INT_MAX, lnz = -1;
+            /* Row max key and first/last non-zero column are kept per 64-column group, relative to the
+             * group: VOP3 forms take no 32-bit literal on gfx9, so absolute column numbers > 64 would
+             * each occupy a VGPR.  The groups are folded once per row. */
+            constexpr int NG = (QMAX + 63) / 64;
+            constexpr int NONE = 1 << 20;
+            int f = 0, mkg[NG], fnzg[NG], lnzg[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { mkg[g] = -NONE; fnzg[g] = NONE; lnzg[g] = -NONE; }
             cells += (unsigned)len;
-#pragma unroll
-            for (int blk = 0; blk < QB; ++blk) {
-                const int j0 = blk * 8;
-                if (j0 + 8 <= jlo || j0 > jhi) continue;
+            static_for<QB>([&](auto blki) {
+                constexpr int j0 = decltype(blki)::value * 8, g = j0 >> 6;
+                if (j0 + 8 <= jlo || j0 > jhi) return;
+                bool nz[8];
                 if (j0 >= jbm && j0 + 8 <= jem) {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        lane_cell<VAR, SYM, false, B8>(Pr[B8 ? (j0 + c) / 2 : j0 + c], j0 + c, rm[(j0 + c) >> 5], k, beg, len, end, h1, f, mk, fnz, lnz);
+                    static_for<8>([&](auto ci) {
+                        constexpr int J = j0 + decltype(ci)::value;
+                        nz[J - j0] = lane_cell<VAR, SYM, false, B8>(Pr[B8 ? J / 2 : J], J, rm[J >> 5], k, beg, len, h1, f, mkg[g]);
+                    });
                 } else {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        lane_cell<VAR, SYM, true, B8>(Pr[B8 ? (j0 + c) / 2 : j0 + c], j0 + c, rm[(j0 + c) >> 5], k, beg, len, end, h1, f, mk, fnz, lnz);
+                    static_for<8>([&](auto ci) {
+                        constexpr int J = j0 + decltype(ci)::value;
+                        nz[J - j0] = lane_cell<VAR, SYM, true, B8>(Pr[B8 ? J / 2 : J], J, rm[J >> 5], k, beg, len, h1, f, mkg[g]);
+                    });
+                    if (j0 + 8 > jem) {                               /* some lane's `end` is in this block: eh[end] = {0, h1} (:1775) */
+                        static_for<8>([&](auto ci) {
+                            constexpr int J = j0 + decltype(ci)::value;
+                            uint32_t &Pw = Pr[B8 ? J / 2 : J];
+                            Pw = J == end ? eh_put<B8>(Pw, J, (uint32_t)h1) : Pw;
+                        });
+                    }
                 }
+                /* first / last non-zero eh entry (K8) from the 8 compare masks of the block */
+                int fb = NONE;
+                static_for<8>([&](auto ci) {
+                    constexpr int c = 7 - decltype(ci)::value;
+                    fb = nz[c] ? ((j0 + c) & 63) : fb;
+                });
+                static_for<8>([&](auto ci) {
+                    constexpr int c = decltype(ci)::value;
+                    lnzg[g] = nz[c] ? ((j0 + c) & 63) : lnzg[g];
+                });
+                fnzg[g] = min(fnzg[g], fb);
+            });
+            int mk = mkg[0], fnz = fnzg[0], lnz = lnzg[0];
+#pragma unroll
+            for (int g = 1; g < NG; ++g) {
+                mk = max(mk, mkg[g] + 64 * g);
+                fnz = min(fnz, fnzg[g] + 64 * g);
+                lnz = max(lnz, lnzg[g] + 64 * g);
             }
             /* K7 row tail */
             if (max(beg, end) == qlen) {                              /* ties -> later i (:1829-1833) */
@@ -322,7 +375,7 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins;
     switch (cls) {
     case 0: return launch_lane_qb<9, true, 4>(variant, sym, P, side, seq, tasks, order, n, out, s);
-    case 1: return launch_lane_qb<17, true, 4>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    case 1: return launch_lane_qb<17, true, 3>(variant, sym, P, side, seq, tasks, order, n, out, s);
     case 2: return launch_lane_qb<9, false, 3>(variant, sym, P, side, seq, tasks, order, n, out, s);
     default: return launch_lane_qb<17, false, 2>(variant, sym, P, side, seq, tasks, order, n, out, s);
     }
