@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void bsw_pair_finalize(const bsw_dparams P, co
 
 /* lane classes: (bits per h/e value, 8-column blocks).  8-bit classes first. */
 struct lane_class_t { int bits, qb; };
-static const lane_class_t kLaneClasses[] = {{8, 9}, {8, 17}, {16, 9}, {16, 17}};
+static const lane_class_t kLaneClasses[] = {{8, 9}, {8, 17}, {8, 29}, {16, 9}, {16, 17}};
 
 int lane_class_count() { return (int)(sizeof(kLaneClasses) / sizeof(kLaneClasses[0])); }
 int lane_class_cols(int cls) { return kLaneClasses[cls].qb * 8; }
@@ -376,7 +376,8 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
     switch (cls) {
     case 0: return launch_lane_qb<9, true, 4>(variant, sym, P, side, seq, tasks, order, n, out, s);
     case 1: return launch_lane_qb<17, true, 3>(variant, sym, P, side, seq, tasks, order, n, out, s);
-    case 2: return launch_lane_qb<9, false, 3>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    case 2: return launch_lane_qb<29, true, 2>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    case 3: return launch_lane_qb<9, false, 3>(variant, sym, P, side, seq, tasks, order, n, out, s);
     default: return launch_lane_qb<17, false, 2>(variant, sym, P, side, seq, tasks, order, n, out, s);
     }
 }

@@ -88,6 +88,30 @@ def test_lane_class_boundaries(host, oracle, lctx, qlen):
         assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=4), tasks)
 
 
+# the 8-bit 232-column lane class (250 bp reads): h0 + qlen*a must stay <= 255
+@pytest.mark.parametrize("qlen", [136, 137, 180, 229, 230, 231])
+def test_lane_class_250bp(host, oracle, lctx, qlen):
+    rng = np.random.default_rng(900 + qlen)
+    seeds = []
+    for k in range(160):
+        tl = int(qlen * 1.4) + int(rng.integers(0, 30))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = _gen.mutate(rng, t, qlen, 0.04, 0.01 if k % 2 else 0.0)
+        seeds.append({"rq": q, "rt": t, "h0": int(rng.integers(1, 256 - qlen))})
+    tasks, arena = host.make_tasks(seeds)
+    for variant in (0, 1):
+        for w in (100, 500):
+            p = host.default_params(variant=variant, w=w)
+            assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=4), tasks)
+
+
+def test_250bp_w500_workload(host, oracle, lctx):
+    p = host.default_params(w=500)
+    tasks, arena = host.synth_tasks(5000, seed=18, read_len=250, seed_len_min=19, seed_len_max=40, seed_at_start=0,
+                                    sub_rate=0.04, indel_rate=0.01, junk_frac=0.05, n_rate=0.0005, w=500)
+    assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=8), tasks)
+
+
 def test_edge_shapes(host, oracle, lctx):
     z = np.zeros(0, np.uint8)
     a40 = (np.arange(40) % 4).astype(np.uint8)
