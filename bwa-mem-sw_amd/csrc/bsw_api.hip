@@ -52,6 +52,9 @@ struct batch_plan {
     int redo_cls = 0;
 };
 
+struct slot_t;
+static void slots_release(std::vector<slot_t> *v);
+
 struct bsw_ctx {
     int device = 0;
     bsw_config cfg{};
@@ -67,6 +70,7 @@ struct bsw_ctx {
     std::thread worker;
     bool worker_active = false;
     int worker_rc = 0;
+    std::vector<struct slot_t> *slots = nullptr;    /* pinned + device staging, kept across submits */
 };
 
 struct bsw_dev_batch {
@@ -182,6 +186,7 @@ extern "C" void bsw_destroy(bsw_ctx *ctx)
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     for (auto &pr : ctx->hist) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    slots_release(ctx->slots);
     delete ctx;
 }
 
@@ -223,22 +228,57 @@ static inline int gap_limit(const bsw_params *p, int mx, int qlen, int end_bonus
 
 static inline size_t nwords(int len) { return (size_t)((len + 15) >> 4); }
 
-/* returns non-zero when the sequence holds an N (code >= 4) */
+/* 8 base bytes (codes 0..4) -> 8 nibbles in the low 32 bits */
+static inline uint64_t squeeze8(uint64_t x)
+{
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return x;
+}
+
+/* byte-per-base -> 16 bases per uint64; returns non-zero when the sequence holds an N (code >= 4) */
 static unsigned pack_seq(const uint8_t *s, int len, uint64_t *dst)
 {
-    const int nw = (len + 15) >> 4;
-    unsigned any_n = 0;
-    for (int w = 0; w < nw; ++w) {
-        uint64_t v = 0;
-        const int lo = w << 4, hi = lo + 16 < len ? lo + 16 : len;
-        for (int k = lo; k < hi; ++k) {
-            const uint64_t b = s[k] > 4 ? 4 : s[k];
-            any_n |= (unsigned)(b >> 2);
-            v |= b << ((k - lo) * 4);
+    const int full = len >> 4;
+    uint64_t any = 0;
+    for (int w = 0; w < full; ++w) {
+        uint64_t lo, hi;
+        memcpy(&lo, s + 16 * w, 8);
+        memcpy(&hi, s + 16 * w + 8, 8);
+        if (((lo | hi) & 0xF8F8F8F8F8F8F8F8ull) != 0) {          /* a code > 7: clamp bytewise (never produced by bwa) */
+            uint64_t v = 0;
+            for (int k = 0; k < 16; ++k) {
+                const uint64_t b = s[16 * w + k] > 4 ? 4 : s[16 * w + k];
+                v |= b << (k * 4);
+            }
+            dst[w] = v;
+            any |= 4;
+            continue;
         }
-        dst[w] = v;
+        /* codes 5..7 -> 4 (N): bit2 set means N, clear the low two bits of such bytes */
+        uint64_t nl = lo & 0x0404040404040404ull, nh = hi & 0x0404040404040404ull;
+        lo &= ~((nl >> 1) | (nl >> 2));
+        hi &= ~((nh >> 1) | (nh >> 2));
+        any |= nl | nh;
+        dst[w] = squeeze8(lo) | (squeeze8(hi) << 32);
     }
-    return any_n;
+    if (len & 15) {
+        uint64_t v = 0;
+        for (int k = full * 16; k < len; ++k) {
+            const uint64_t b = s[k] > 4 ? 4 : s[k];
+            any |= b & 4;
+            v |= b << ((k & 15) * 4);
+        }
+        dst[full] = v;
+    }
+    return any != 0;
+}
+
+extern "C" int bsw_pack_bases(const uint8_t *bases, int len, uint64_t *words)
+{
+    if (len < 0 || (len > 0 && (!bases || !words))) return BSW_E_INVAL;
+    return (int)pack_seq(bases, len, words);
 }
 
 /* lane kernel needs a bwa-style matrix: a on the diagonal, one mismatch score off it (N never occurs there) */
@@ -616,6 +656,13 @@ static void slot_free(slot_t &s)
     s = slot_t();
 }
 
+static void slots_release(std::vector<slot_t> *v)
+{
+    if (!v) return;
+    for (auto &s : *v) slot_free(s);
+    delete v;
+}
+
 static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, size_t n, bsw_result *out)
 {
     bsw_dparams dp;
@@ -624,8 +671,12 @@ static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, si
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t chunk = ctx->cfg.chunk_tasks;
     const size_t nslots = ctx->streams.size();
-    std::vector<slot_t> slots(nslots);
-    auto cleanup = [&]() { for (auto &s : slots) slot_free(s); };
+    if (!ctx->slots) ctx->slots = new std::vector<slot_t>(nslots);
+    std::vector<slot_t> &slots = *ctx->slots;
+    /* on failure: drain what is in flight and mark every slot idle; the buffers stay for the next submit */
+    auto cleanup = [&]() {
+        for (size_t k = 0; k < nslots; ++k) { (void)hipStreamSynchronize(ctx->streams[k]); slots[k].busy = false; }
+    };
     auto drain = [&](size_t k) -> int {
         slot_t &s = slots[k];
         if (!s.busy) return BSW_OK;
@@ -679,7 +730,6 @@ static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, si
     }
     for (size_t k = 0; k < nslots; ++k)
         if ((rc = drain(k)) != BSW_OK) { cleanup(); return rc; }
-    cleanup();
     return BSW_OK;
 }
 

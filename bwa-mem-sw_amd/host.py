@@ -90,6 +90,7 @@ def lib():
             "bsw_refbatch_encode_results": (C.c_int, [vp, sz, vp]),
             "bsw_refbatch_decode_results": (C.c_int, [vp, sz, vp]),
             "bsw_refbatch_run": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+            "bsw_pack_bases": (C.c_int, [vp, C.c_int, vp]),
             "bsw_synth_generate": (C.c_int64, [vp, sz, vp, vp, sz]),
             "bsw_synth_arena_bound": (sz, [vp, sz]),
             "bsw_set_default_variant": (None, [C.c_int]),
@@ -108,7 +109,7 @@ EXPORTS = ["ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_default_
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
            "bsw_refbatch_encode_results", "bsw_refbatch_decode_results", "bsw_refbatch_run",
-           "bsw_synth_generate", "bsw_synth_arena_bound"]
+           "bsw_pack_bases", "bsw_synth_generate", "bsw_synth_arena_bound"]
 
 
 def default_params(**over):
@@ -307,6 +308,16 @@ def refbatch_decode_results(words, n):
     if rc < 0:
         raise BswError(rc, "bsw_refbatch_decode_results")
     return res
+
+
+def pack_bases(bases):
+    """Device sequence format of one sequence (see bsw_pack_bases).  Returns (uint64 words, has_N)."""
+    b = np.ascontiguousarray(bases, dtype=np.uint8)
+    words = np.zeros((len(b) + 15) // 16, dtype=np.uint64)
+    rc = lib().bsw_pack_bases(b.ctypes.data if len(b) else None, len(b), words.ctypes.data if len(words) else None)
+    if rc < 0:
+        raise BswError(rc, "bsw_pack_bases")
+    return words, bool(rc)
 
 
 def shard_indices(n, world, rank, chunk=65536):

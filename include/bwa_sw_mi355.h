@@ -184,6 +184,10 @@ int      bsw_refbatch_decode_results(const uint32_t *words, size_t n, bsw_result
  * batch — what one RTL PE array does between task_start and TestCmp.           */
 int      bsw_refbatch_run(bsw_ctx *ctx, const uint32_t *in_words, uint32_t *out_words, int variant, int zdrop);
 
+/* ---- device sequence format: 4 bits per base, 16 bases per uint64, base k of a word in bits [4k,4k+3];
+ * codes > 4 are stored as 4 (N).  words must hold (len+15)/16 entries.  Returns 1 if an N was seen. ---- */
+int      bsw_pack_bases(const uint8_t *bases, int len, uint64_t *words);
+
 /* ---- synthetic workload generator (no genome in the image) --- */
 typedef struct bsw_synth_spec {
     uint64_t seed;

@@ -121,3 +121,20 @@ def test_refbatch_limits(host):
     many, am = host.synth_tasks(2000, seed=1)
     words, n = host.refbatch_encode(p, many)
     assert n == host.REFBATCH_MAX_TASKS                                                 # 819 five-word records (rbb.v)
+
+
+def test_pack_bases_matches_reference_packer(host):
+    """16 bases per uint64, base k in bits [4k,4k+3], codes > 4 stored as N (4) — SWAR fast path and tails."""
+    rng = np.random.default_rng(12)
+    for trial in range(300):
+        n = int(rng.integers(0, 200))
+        hi = [4, 5, 8, 256][trial % 4]
+        b = rng.integers(0, hi, n).astype(np.uint8)
+        if trial % 7 == 0 and n:
+            b[rng.integers(0, n)] = 255
+        words, has_n = host.pack_bases(b)
+        ref = np.zeros((n + 15) // 16, dtype=np.uint64)
+        for k, v in enumerate(b):
+            ref[k >> 4] |= np.uint64(min(int(v), 4)) << np.uint64(4 * (k & 15))
+        assert (words == ref).all(), (trial, b)
+        assert has_n == bool((b >= 4).any())
