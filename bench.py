@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(affinity, 16): the 1-GPU box's CPU share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=2048, help="seeds spot-checked against the oracle after timing")
+    ap.add_argument("--spec", action="append", default=[], help="override a generator field, e.g. --spec n_rate=0 (experiments)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (batch manager picks per bin), 1 wave-per-task only, 2 force lane bins")
     args = ap.parse_args()
 
     import torch
@@ -86,10 +88,13 @@ def main():
     pkg = graft.load_package()
     host = pkg.host
     spec = dict(WORKLOADS[args.workload])
+    for kv in args.spec:
+        key, val = kv.split("=")
+        spec[key] = type(spec[key])(float(val))
     params = host.default_params(variant=args.variant, zdrop=args.zdrop, w=spec["w"])
     tasks, arena = host.synth_tasks(args.tasks, seed=1000 + rank, **spec)
 
-    ctx = host.BswContext(device=local_rank)
+    ctx = host.BswContext(device=local_rank, kernel=args.kernel)
     batch = ctx.upload(params, tasks)            # inputs resident in HBM before the timed region
 
     def barrier():

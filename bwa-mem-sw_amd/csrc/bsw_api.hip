@@ -281,14 +281,15 @@ extern "C" int bsw_pack_bases(const uint8_t *bases, int len, uint64_t *words)
     return (int)pack_seq(bases, len, words);
 }
 
-/* lane kernel needs a bwa-style matrix: a on the diagonal, one mismatch score off it (N never occurs there) */
+/* lane kernel needs a bwa-style matrix (bwa_fill_scmat): a on the diagonal, one mismatch score off it,
+ * one score for every pair that involves an N */
 static bool lane_matrix_ok(const bsw_params *p)
 {
-    const int a = p->mat[0], nb = p->mat[1];
-    if (a <= 0 || nb > 0) return false;
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-            if (p->mat[i * 5 + j] != (i == j ? a : nb)) return false;
+    const int a = p->mat[0], nb = p->mat[1], nn = p->mat[24];
+    if (a <= 0 || nb > 0 || nn > a) return false;
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 5; ++j)
+            if (p->mat[i * 5 + j] != ((i == 4 || j == 4) ? nn : (i == j ? a : nb))) return false;
     return true;
 }
 
@@ -396,7 +397,6 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
     uint32_t n_lane = 0;
     if (lane_params) {
         for (size_t i = 0; i < n; ++i) {
-            if (has_n[i]) continue;
             const bsw_task &t = tasks[i];
             const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
             const int64_t top = (int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * a;     /* no H can exceed this */

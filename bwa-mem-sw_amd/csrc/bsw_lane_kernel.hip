@@ -17,8 +17,8 @@
  *   - only the first band try runs here.  A side that would need MAX_BAND_TRY's second pass
  *     (sw_pe_array_sw_extend.v:1837,1859) marks its seed for the wave-per-task kernel, which
  *     recomputes the seed from scratch (bsw_pair_finalize + redo list).
- * Eligibility (enforced by the host): bwa-style matrix (a on the diagonal, -b off it, N row/col
- * never used because the seed has no N), qlen < 8*QB, score range as above.
+ * Eligibility (enforced by the host): bwa-style matrix (a on the diagonal, -b off it, one score for
+ * every pair that involves an N), qlen < 8*QB, score range as above.
  */
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -70,7 +70,7 @@ __device__ __forceinline__ void static_for(F &&f)
 }
 
 struct lane_consts {
-    int va, vnegb;                                   /* +a, -b held in VGPRs (v_bfi takes one SGPR at most) */
+    int va, vnegb, vn;                               /* +a, -b, N score held in VGPRs (v_bfi takes one SGPR at most) */
     int oe_del, e_del, oe_ins, e_ins;
 };
 
@@ -83,9 +83,12 @@ __device__ __forceinline__ uint32_t eh_put(uint32_t Pw, const int J, const uint3
 
 /* One DP cell of column J for every lane whose [beg,end) contains J (EDGE) or for all live lanes (dense).
  * Pw is the VGPR holding eh[J]: B8 -> byte pair at bit (J&1)*16, else the whole word.
- * Returns true when the stored eh[J] is non-zero (for the next-row trimming, K8). */
-template <int VAR, bool SYM, bool EDGE, bool B8>
-__device__ __forceinline__ bool lane_cell(uint32_t &Pw, const int J, const uint32_t rmw, const lane_consts &k,
+ * Returns true when the stored eh[J] is non-zero (for the next-row trimming, K8).
+ * NQ: some lane of the wave has an N in this block of the query -> rnw marks those columns and they
+ * score k.vn whatever the target base is (mat[.][4], sw_pe_array_sw_extend.v:1915-1940). */
+template <int VAR, bool SYM, bool EDGE, bool B8, bool NQ>
+__device__ __forceinline__ bool lane_cell(uint32_t &Pw, const int J, const uint32_t rmw, const uint32_t rnw,
+                                          const int vmis, const lane_consts &k,
                                           const int beg, const int len, int &h1, int &f, int &mk)
 {
     constexpr uint32_t HM = B8 ? 0xffu : 0xffffu;
@@ -98,7 +101,11 @@ __device__ __forceinline__ bool lane_cell(uint32_t &Pw, const int J, const uint3
         const int hd = (int)(p & HM), e = (int)((p >> HB) & HM);     /* eh[j].h = H(i-1,j-1), eh[j].e */
         const int x = __builtin_amdgcn_sbfe(rmw, J & 31, 1);          /* -1 on match (q_j == t_i), else 0 */
         int s;                                                        /* +a | -b (:1915-1940): (x & a) | (~x & -b); hipcc expands */
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(s) : "v"(x), "v"(k.va), "v"(k.vnegb));   /* the C form into 5 ops */
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(s) : "v"(x), "v"(k.va), "v"(vmis));      /* the C form into 5 ops */
+        if (NQ) {
+            const int y = __builtin_amdgcn_sbfe(rnw, J & 31, 1);      /* -1 where q_j is N */
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(s) : "v"(y), "v"(k.vn), "v"(s));
+        }
         int M = hd + s;                                               /* (:1797)                        */
         if (VAR == BSW_VARIANT_M) M = hd ? M : 0;
         const int h = max(max(M, e), f);                              /* (:1798,1809)                   */
@@ -129,13 +136,13 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
     constexpr int NW = (QMAX + 31) / 32;
     constexpr int NP = B8 ? QMAX / 2 : QMAX;
     __shared__ uint64_t lds_t[4][BSW_LANE_TCHUNK][64];              /* [wave][word][lane]          */
-    __shared__ uint32_t lds_q[4][2 * NW][64];                       /* query bit-planes            */
+    __shared__ uint32_t lds_q[4][3 * NW][64];                       /* query bit-planes: code bit 0, bit 1, N */
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     const bool valid = slot < n;
     const uint32_t ti = valid ? order[slot] : order[0];
     int qlen, tlen, h0, w;
-    uint32_t t_off;
+    uint32_t t_off, nblk = 0;
     {
         const bsw_dtask T = tasks[ti];
         int wlim;
@@ -148,26 +155,32 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
         }
         if (!valid) tlen = 0;
         w = min(P.w, wlim);
-        /* query -> two bit-planes (code bit 0, code bit 1), 32 columns per word, parked in LDS */
+        /* query -> three bit-planes (code bit 0, code bit 1, N), 32 columns per word, parked in LDS;
+         * nblk: bit b set when some lane of the wave has an N in columns [8b, 8b+8) */
 #pragma unroll
         for (int wd = 0; wd < NW; ++wd) {
-            uint32_t q0 = 0, q1 = 0;
+            uint32_t q0 = 0, q1 = 0, q2 = 0;
 #pragma unroll
             for (int hlf = 0; hlf < 2; ++hlf) {
                 const int v = wd * 2 + hlf;
                 if (v < (QMAX + 15) / 16) {
-                    const uint64_t qw = v * 16 < qlen ? seq[q_off + v] : 0ull;
+                    const uint64_t qw = (valid && v * 16 < qlen) ? seq[q_off + v] : 0ull;
                     q0 |= nibble_plane(qw, 0) << (hlf * 16);
                     q1 |= nibble_plane(qw, 1) << (hlf * 16);
+                    q2 |= nibble_plane(qw, 2) << (hlf * 16);
                 }
             }
-            lds_q[wv][2 * wd][lane] = q0;
-            lds_q[wv][2 * wd + 1][lane] = q1;
+            lds_q[wv][3 * wd][lane] = q0;
+            lds_q[wv][3 * wd + 1][lane] = q1;
+            lds_q[wv][3 * wd + 2][lane] = q2;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (wd * 4 + b < QB && __builtin_amdgcn_ballot_w64(((q2 >> (8 * b)) & 0xffu) != 0) != 0) nblk |= 1u << (wd * 4 + b);
         }
     }
     lane_consts k;
-    k.va = P.mat[0]; k.vnegb = P.mat[1];
-    asm volatile("" : "+v"(k.va), "+v"(k.vnegb));
+    k.va = P.mat[0]; k.vnegb = P.mat[1]; k.vn = P.mat[24];
+    asm volatile("" : "+v"(k.va), "+v"(k.vnegb), "+v"(k.vn));
     k.oe_del = P.o_del + P.e_del; k.e_del = P.e_del; k.oe_ins = P.o_ins + P.e_ins; k.e_ins = P.e_ins;
     const int o_del = P.o_del, e_del = P.e_del, zdrop = P.zdrop;
     const int ntw = (tlen + 15) >> 4;
@@ -212,12 +225,16 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
         const int jbm = wave_max_all(act ? beg : INT_MIN);
         const int jem = -wave_max_all(act ? -end : INT_MIN);
         if (act) {
-            const int tb = (int)((tw >> ((i & 15) * 4)) & 3);
+            const int tb = (int)((tw >> ((i & 15) * 4)) & 7);
             const uint32_t n0 = (uint32_t)((tb & 1) - 1), n1 = (uint32_t)(((tb >> 1) & 1) - 1);
-            uint32_t rm[NW];
+            const uint32_t tn = (uint32_t)((tb >> 2) - 1);             /* 0 when the target base is N, else ~0 */
+            const int vmis = tn ? k.vnegb : k.vn;                      /* a row against N scores mat[4][.] everywhere */
+            uint32_t rm[NW], rn[NW];
 #pragma unroll
-            for (int wd = 0; wd < NW; ++wd)                            /* 1 where q_j == t_i */
-                rm[wd] = (lds_q[wv][2 * wd][lane] ^ n0) & (lds_q[wv][2 * wd + 1][lane] ^ n1);
+            for (int wd = 0; wd < NW; ++wd) {                          /* rm: 1 where q_j == t_i; rn: 1 where q_j is N */
+                rn[wd] = lds_q[wv][3 * wd + 2][lane];
+                rm[wd] = (lds_q[wv][3 * wd][lane] ^ n0) & (lds_q[wv][3 * wd + 1][lane] ^ n1) & tn & ~rn[wd];
+            }
             int h1 = beg == 0 ? max(h0 - (o_del + e_del * (i + 1)), 0) : 0;
             /* Row max key and first/last non-zero column are kept per 64-column group, relative to the
              * group: VOP3 forms take no 32-bit literal on gfx9, so absolute column numbers > 64 would
@@ -232,16 +249,24 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
                 constexpr int j0 = decltype(blki)::value * 8, g = j0 >> 6;
                 if (j0 + 8 <= jlo || j0 > jhi) return;
                 bool nz[8];
-                if (j0 >= jbm && j0 + 8 <= jem) {
+                const bool dense = j0 >= jbm && j0 + 8 <= jem;
+                if ((nblk >> (j0 / 8)) & 1u) {                        /* rare: a query N somewhere in this block */
                     static_for<8>([&](auto ci) {
                         constexpr int J = j0 + decltype(ci)::value;
-                        nz[J - j0] = lane_cell<VAR, SYM, false, B8>(Pr[B8 ? J / 2 : J], J, rm[J >> 5], k, beg, len, h1, f, mkg[g]);
+                        nz[J - j0] = lane_cell<VAR, SYM, true, B8, true>(Pr[B8 ? J / 2 : J], J, rm[J >> 5], rn[J >> 5], vmis, k, beg, len, h1, f, mkg[g]);
+                    });
+                } else if (dense) {
+                    static_for<8>([&](auto ci) {
+                        constexpr int J = j0 + decltype(ci)::value;
+                        nz[J - j0] = lane_cell<VAR, SYM, false, B8, false>(Pr[B8 ? J / 2 : J], J, rm[J >> 5], 0u, vmis, k, beg, len, h1, f, mkg[g]);
                     });
                 } else {
                     static_for<8>([&](auto ci) {
                         constexpr int J = j0 + decltype(ci)::value;
-                        nz[J - j0] = lane_cell<VAR, SYM, true, B8>(Pr[B8 ? J / 2 : J], J, rm[J >> 5], k, beg, len, h1, f, mkg[g]);
+                        nz[J - j0] = lane_cell<VAR, SYM, true, B8, false>(Pr[B8 ? J / 2 : J], J, rm[J >> 5], 0u, vmis, k, beg, len, h1, f, mkg[g]);
                     });
+                }
+                if (!dense) {
                     if (j0 + 8 > jem) {                               /* some lane's `end` is in this block: eh[end] = {0, h1} (:1775) */
                         static_for<8>([&](auto ci) {
                             constexpr int J = j0 + decltype(ci)::value;

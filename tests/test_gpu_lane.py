@@ -112,6 +112,21 @@ def test_250bp_w500_workload(host, oracle, lctx):
     assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=8), tasks)
 
 
+@pytest.mark.parametrize("nscore", [-1, -3, 0, 1])
+def test_n_bases_in_lane_bins(host, oracle, lctx, nscore):
+    """N in query and/or target: every pair involving an N scores mat[4][.] (K6)."""
+    rng = np.random.default_rng(70 + nscore)
+    seeds = _gen.random_seeds(rng, 800, qmax=134, indel=0.02, junk=0.1, nrate=0.03)
+    seeds += [dict(rq=np.full(100, 4, np.uint8), rt=np.full(150, 4, np.uint8), h0=50),          # all N
+              dict(rq=np.full(60, 4, np.uint8), rt=rng.integers(0, 4, 90).astype(np.uint8), h0=70),
+              dict(lq=rng.integers(0, 4, 60).astype(np.uint8), lt=np.full(90, 4, np.uint8), h0=70)]
+    tasks, arena = host.make_tasks(seeds)
+    for variant in (0, 1):
+        p = host.default_params(variant=variant)
+        p["mat"][0] = host.bwa_matrix(a=1, b=4, n=nscore)
+        assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=8), tasks)
+
+
 def test_edge_shapes(host, oracle, lctx):
     z = np.zeros(0, np.uint8)
     a40 = (np.arange(40) % 4).astype(np.uint8)
