@@ -29,6 +29,9 @@ EXT_TASK = np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tle
 SYNTH = np.dtype([("seed", "<u8"), ("read_len", "<i4"), ("seed_len_min", "<i4"), ("seed_len_max", "<i4"),
                   ("seed_at_start", "<i4"), ("sub_rate", "<f8"), ("indel_rate", "<f8"), ("n_rate", "<f8"),
                   ("junk_frac", "<f8"), ("a", "<i4"), ("w", "<i4"), ("o", "<i4"), ("e", "<i4")])
+SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
+ALNREG = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("score", "<i4"), ("truesc", "<i4"),
+                   ("w", "<i4"), ("_pad", "<i4")])
 CONFIG = np.dtype([("device", "<i4"), ("kernel", "<i4"), ("streams", "<i4"), ("pack_threads", "<i4"),
                    ("chunk_tasks", "<u8")])
 assert PARAMS.itemsize == 68 and TASK.itemsize == 64 and EXT.itemsize == 32 and RESULT.itemsize == 96
@@ -91,6 +94,12 @@ def lib():
             "bsw_refbatch_decode_results": (C.c_int, [vp, sz, vp]),
             "bsw_refbatch_run": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
             "bsw_pack_bases": (C.c_int, [vp, C.c_int, vp]),
+            "bsw_cal_max_gap": (C.c_int, [vp, C.c_int]),
+            "bsw_chain_window": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
+            "bsw_seed_scratch_bytes": (sz, [vp, C.c_int64]),
+            "bsw_seed_to_task": (C.c_int, [vp, vp, C.c_int, vp, C.c_int64, C.c_int64, vp, vp, sz, C.c_uint32, vp]),
+            "bsw_result_to_alnreg": (C.c_int, [vp, vp, vp]),
+            "bsw_pac_get_seq": (C.c_int64, [C.c_int64, vp, C.c_int64, C.c_int64, vp]),
             "bsw_synth_generate": (C.c_int64, [vp, sz, vp, vp, sz]),
             "bsw_synth_arena_bound": (sz, [vp, sz]),
             "bsw_set_default_variant": (None, [C.c_int]),
@@ -109,7 +118,8 @@ EXPORTS = ["ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_default_
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
            "bsw_refbatch_encode_results", "bsw_refbatch_decode_results", "bsw_refbatch_run",
-           "bsw_pack_bases", "bsw_synth_generate", "bsw_synth_arena_bound"]
+           "bsw_pack_bases", "bsw_cal_max_gap", "bsw_chain_window", "bsw_seed_scratch_bytes", "bsw_seed_to_task",
+           "bsw_result_to_alnreg", "bsw_pac_get_seq", "bsw_synth_generate", "bsw_synth_arena_bound"]
 
 
 def default_params(**over):
@@ -318,6 +328,54 @@ def pack_bases(bases):
     if rc < 0:
         raise BswError(rc, "bsw_pack_bases")
     return words, bool(rc)
+
+
+def pac_get_seq(pac, l_pac, beg, end):
+    """bns_get_seq on a 2-bit packed reference (numpy uint8 array)."""
+    dst = np.zeros(max(abs(end - beg), 1), dtype=np.uint8)
+    n = lib().bsw_pac_get_seq(l_pac, pac.ctypes.data, beg, end, dst.ctypes.data)
+    if n < 0:
+        raise BswError(int(n), "bsw_pac_get_seq")
+    return dst[:n]
+
+
+def pack_pac(bases):
+    """ACGT codes -> bwa .pac layout (4 bases per byte, first base in the top two bits)."""
+    b = np.asarray(bases, dtype=np.uint8)
+    pad = (-len(b)) % 4
+    b4 = np.concatenate([b, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    return (b4[:, 0] << 6 | b4[:, 1] << 4 | b4[:, 2] << 2 | b4[:, 3]).astype(np.uint8)
+
+
+def seeds_to_tasks(params, pac, l_pac, reads, seeds):
+    """mem_chain2aln glue for single-seed chains: reads = list of base arrays, seeds = SEED array (one per read).
+    Returns (tasks, keepalive) with the sequences laid out by bsw_seed_to_task."""
+    L = lib()
+    n = len(reads)
+    tasks = np.zeros(n, dtype=TASK)
+    keep = []
+    for i in range(n):
+        q = np.ascontiguousarray(reads[i], dtype=np.uint8)
+        rmax = np.zeros(2, dtype=np.int64)
+        rc = L.bsw_chain_window(params.ctypes.data, seeds[i:i + 1].ctypes.data, 1, len(q), l_pac, rmax.ctypes.data)
+        if rc:
+            raise BswError(rc, "bsw_chain_window")
+        rseq = pac_get_seq(pac, l_pac, int(rmax[0]), int(rmax[1]))
+        rseq = np.ascontiguousarray(rseq)
+        scratch = np.zeros(L.bsw_seed_scratch_bytes(seeds[i:i + 1].ctypes.data, int(rmax[0])) + 8, dtype=np.uint8)
+        rc = L.bsw_seed_to_task(params.ctypes.data, seeds[i:i + 1].ctypes.data, len(q), q.ctypes.data, int(rmax[0]), int(rmax[1]),
+                                rseq.ctypes.data, scratch.ctypes.data, scratch.size, i, tasks[i:i + 1].ctypes.data)
+        if rc:
+            raise BswError(rc, "bsw_seed_to_task")
+        keep.append((q, rseq, scratch))
+    return tasks, keep
+
+
+def results_to_alnregs(seeds, results):
+    out = np.zeros(len(seeds), dtype=ALNREG)
+    for i in range(len(seeds)):
+        lib().bsw_result_to_alnreg(seeds[i:i + 1].ctypes.data, results[i:i + 1].ctypes.data, out[i:i + 1].ctypes.data)
+    return out
 
 
 def shard_indices(n, world, rank, chunk=65536):

@@ -184,6 +184,34 @@ int      bsw_refbatch_decode_results(const uint32_t *words, size_t n, bsw_result
  * batch — what one RTL PE array does between task_start and TestCmp.           */
 int      bsw_refbatch_run(bsw_ctx *ctx, const uint32_t *in_words, uint32_t *out_words, int variant, int zdrop);
 
+/* ---- mem_chain2aln caller glue: what bwamem.c does either side of ksw_extend2.
+ * Reference coordinates are bwa's: [0, l_pac) forward strand, [l_pac, 2*l_pac) reverse complement. ---- */
+typedef struct bsw_seed {           /* mem_seed_t */
+    int64_t rbeg;
+    int32_t qbeg, len;
+} bsw_seed;
+typedef struct bsw_alnreg {         /* the fields of mem_alnreg_t this path produces */
+    int64_t rb, re;
+    int32_t qb, qe;
+    int32_t score, truesc, w;
+} bsw_alnreg;
+/* cal_max_gap(opt, qlen): longest gap a qlen-base flank can pay for, capped at 2w */
+int      bsw_cal_max_gap(const bsw_params *p, int qlen);
+/* the chain's reference window [rmax[0], rmax[1]) as mem_chain2aln computes it from all seeds of a chain */
+int      bsw_chain_window(const bsw_params *p, const bsw_seed *seeds, int n_seeds, int l_query, int64_t l_pac, int64_t rmax[2]);
+/* bytes of scratch bsw_seed_to_task needs for the reversed left query + left target */
+size_t   bsw_seed_scratch_bytes(const bsw_seed *s, int64_t rmax0);
+/* one seed -> one task.  rseq = reference bases of [rmax0, rmax1) (bns_get_seq), query = the read (codes 0..4).
+ * The left query/target are written reversed into scratch; right ones point into query / rseq. */
+int      bsw_seed_to_task(const bsw_params *p, const bsw_seed *s, int l_query, const uint8_t *query,
+                          int64_t rmax0, int64_t rmax1, const uint8_t *rseq,
+                          uint8_t *scratch, size_t scratch_len, uint32_t tag, bsw_task *t);
+/* result record -> alignment region in read / reference coordinates */
+int      bsw_result_to_alnreg(const bsw_seed *s, const bsw_result *r, bsw_alnreg *a);
+/* bns_get_seq: bases of [beg, end) from a 2-bit packed reference (4 bases per byte, first base in the top bits);
+ * returns the number of bases written, 0 if the range bridges the forward/reverse boundary */
+int64_t  bsw_pac_get_seq(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t end, uint8_t *dst);
+
 /* ---- device sequence format: 4 bits per base, 16 bases per uint64, base k of a word in bits [4k,4k+3];
  * codes > 4 are stored as 4 (N).  words must hold (len+15)/16 entries.  Returns 1 if an N was seen. ---- */
 int      bsw_pack_bases(const uint8_t *bases, int len, uint64_t *words);
