@@ -35,7 +35,13 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
                        const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
 hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
                            bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, hipStream_t s);
+hipError_t launch_fetch(const uint8_t *pac, int64_t l_pac, const bsw_fetch_desc *desc, uint32_t nd, uint64_t *seq, hipStream_t s);
 }  // namespace bsw
+
+struct bsw_ref {
+    uint8_t *d_pac = nullptr;
+    int64_t l_pac = 0;
+};
 
 #define MAX_CLASSES 8
 #define MAX_LANE_CLASSES 8
@@ -84,6 +90,7 @@ struct bsw_dev_batch {
     uint64_t seq_words = 0;
     batch_plan plan;
     uint64_t launches = 0;
+    uint64_t h2d_bytes = 0;      /* bytes the upload moved over PCIe */
 };
 
 static int fail(bsw_ctx *ctx, int code, const char *fmt, ...)
@@ -317,7 +324,8 @@ static int task_class(int qmax)
  *   - wave classes: everything else, by the number of eh[] columns a lane must hold. */
 static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, int threads,
                       uint64_t *seq_dst /* may be NULL: use ph.seq */, size_t seq_cap, packed_host &ph,
-                      bsw_dtask *task_dst, uint32_t *order_dst, size_t *seq_words_out)
+                      bsw_dtask *task_dst, uint32_t *order_dst, size_t *seq_words_out,
+                      bool dev_targets = false /* targets are fetched on the device: leave their words alone */)
 {
     const int mx = mat_max(p->mat);
     std::vector<uint64_t> off(n + 1);
@@ -332,7 +340,8 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
         if (t.h0 <= 0) return fail(ctx, BSW_E_INVAL, "task %zu: h0 must be > 0", i);
         if ((int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * mx >= BSW_MAX_SCORE)
             return fail(ctx, BSW_E_LIMIT, "task %zu: score range beyond BSW_MAX_SCORE", i);
-        if ((t.lqlen && (!t.lquery || (t.ltlen && !t.ltarget))) || (t.rqlen && (!t.rquery || (t.rtlen && !t.rtarget))))
+        if ((t.lqlen && (!t.lquery || (t.ltlen && !t.ltarget && !dev_targets))) ||
+            (t.rqlen && (!t.rquery || (t.rtlen && !t.rtarget && !dev_targets))))
             return fail(ctx, BSW_E_INVAL, "task %zu: NULL sequence pointer", i);
         off[i] = acc;
         acc += (t.lqlen ? nwords(t.lqlen) + nwords(t.ltlen) : 0) + (t.rqlen ? nwords(t.rqlen) + nwords(t.rtlen) : 0);
@@ -356,11 +365,11 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
             memset(&d, 0, sizeof(d));
             if (t.lqlen) {
                 d.lq_off = (uint32_t)o; nn |= pack_seq(t.lquery, t.lqlen, seq + o); o += nwords(t.lqlen);
-                d.lt_off = (uint32_t)o; nn |= pack_seq(t.ltarget, t.ltlen, seq + o); o += nwords(t.ltlen);
+                d.lt_off = (uint32_t)o; if (!dev_targets) nn |= pack_seq(t.ltarget, t.ltlen, seq + o); o += nwords(t.ltlen);
             }
             if (t.rqlen) {
                 d.rq_off = (uint32_t)o; nn |= pack_seq(t.rquery, t.rqlen, seq + o); o += nwords(t.rqlen);
-                d.rt_off = (uint32_t)o; nn |= pack_seq(t.rtarget, t.rtlen, seq + o); o += nwords(t.rtlen);
+                d.rt_off = (uint32_t)o; if (!dev_targets) nn |= pack_seq(t.rtarget, t.rtlen, seq + o); o += nwords(t.rtlen);
             }
             has_n[i] = (uint8_t)nn;
             d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
@@ -486,9 +495,9 @@ extern "C" void bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b)
     delete b;
 }
 
-extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out)
+static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out,
+                         const bsw_ref *ref /* NULL: targets come from the host */, const bsw_ref_task *rtasks)
 {
-    if (!ctx || !out || (!tasks && n)) return fail(ctx, BSW_E_INVAL, "bsw_upload: NULL argument");
     *out = nullptr;
     if (n >= (1ull << 32)) return fail(ctx, BSW_E_LIMIT, "more than 2^32-1 tasks in one batch");
     bsw_dparams dp;
@@ -496,18 +505,30 @@ extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tas
     if (rc) return rc;
     packed_host ph;
     size_t words = 0;
-    rc = pack_tasks(ctx, p, tasks, n, ctx->cfg.pack_threads, nullptr, 0, ph, nullptr, nullptr, &words);
+    rc = pack_tasks(ctx, p, tasks, n, ctx->cfg.pack_threads, nullptr, 0, ph, nullptr, nullptr, &words, ref != nullptr);
     if (rc) return rc;
+    std::vector<bsw_fetch_desc> descs;
+    if (ref) {
+        descs.reserve(2 * n);
+        for (size_t i = 0; i < n; ++i) {
+            const bsw_dtask &d = ph.tasks[i];
+            const bsw_seed &sd = rtasks[i].seed;
+            if (d.lqlen && d.ltlen) descs.push_back(bsw_fetch_desc{sd.rbeg - 1, d.lt_off, d.ltlen, -1, 0});
+            if (d.rqlen && d.rtlen) descs.push_back(bsw_fetch_desc{sd.rbeg + sd.len, d.rt_off, d.rtlen, 1, 0});
+        }
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     bsw_dev_batch *b = new bsw_dev_batch();
     b->n = n; b->P = dp; b->variant = p->variant; b->seq_words = words;
     b->plan = ph.plan;
     const size_t olen = (size_t)ph.plan.order_len + 1;          /* + redo counter */
     hipError_t e = hipSuccess;
+    bsw_fetch_desc *d_desc = nullptr;
     if ((e = hipMalloc((void **)&b->d_seq, (words + 1) * sizeof(uint64_t))) != hipSuccess ||
         (e = hipMalloc((void **)&b->d_tasks, (n + 1) * sizeof(bsw_dtask))) != hipSuccess ||
         (e = hipMalloc((void **)&b->d_order, (olen + 1) * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&b->d_out, (n + 1) * sizeof(bsw_result))) != hipSuccess) {
+        (e = hipMalloc((void **)&b->d_out, (n + 1) * sizeof(bsw_result))) != hipSuccess ||
+        (!descs.empty() && (e = hipMalloc((void **)&d_desc, descs.size() * sizeof(bsw_fetch_desc))) != hipSuccess)) {
         bsw_free_batch(ctx, b);
         return fail(ctx, BSW_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
     }
@@ -516,12 +537,97 @@ extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tas
         (e = hipMemcpyAsync(b->d_tasks, ph.tasks.data(), n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_order, ph.order.data(), olen * sizeof(uint32_t), hipMemcpyHostToDevice, s)) != hipSuccess ||
         (e = hipMemsetAsync(b->d_out, 0xff, n * sizeof(bsw_result), s)) != hipSuccess ||
+        (!descs.empty() && ((e = hipMemcpyAsync(d_desc, descs.data(), descs.size() * sizeof(bsw_fetch_desc), hipMemcpyHostToDevice, s)) != hipSuccess ||
+                            (e = bsw::launch_fetch(ref->d_pac, ref->l_pac, d_desc, (uint32_t)descs.size(), b->d_seq, s)) != hipSuccess)) ||
         (e = hipStreamSynchronize(s)) != hipSuccess) {
+        if (d_desc) (void)hipFree(d_desc);
         bsw_free_batch(ctx, b);
         return fail(ctx, BSW_E_HIP, "upload: %s", hipGetErrorString(e));
     }
+    if (d_desc) (void)hipFree(d_desc);
+    b->h2d_bytes = words * 8 + n * sizeof(bsw_dtask) + olen * 4 + descs.size() * sizeof(bsw_fetch_desc);
     *out = b;
     return BSW_OK;
+}
+
+extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out)
+{
+    if (!ctx || !out || (!tasks && n)) return fail(ctx, BSW_E_INVAL, "bsw_upload: NULL argument");
+    return upload_common(ctx, p, tasks, n, out, nullptr, nullptr);
+}
+
+/* ---- device-resident reference (F3) ------------------------------------------------ */
+extern "C" int bsw_ref_upload(bsw_ctx *ctx, const uint8_t *pac, int64_t l_pac, bsw_ref **out)
+{
+    if (!ctx || !pac || !out || l_pac <= 0) return fail(ctx, BSW_E_INVAL, "bsw_ref_upload: bad argument");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    bsw_ref *r = new bsw_ref();
+    r->l_pac = l_pac;
+    const size_t bytes = (size_t)((l_pac + 3) >> 2);
+    hipError_t e;
+    if ((e = hipMalloc((void **)&r->d_pac, bytes + 8)) != hipSuccess) { delete r; return fail(ctx, BSW_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    if ((e = hipMemcpy(r->d_pac, pac, bytes, hipMemcpyHostToDevice)) != hipSuccess) {
+        (void)hipFree(r->d_pac); delete r;
+        return fail(ctx, BSW_E_HIP, "pac upload: %s", hipGetErrorString(e));
+    }
+    *out = r;
+    return BSW_OK;
+}
+
+extern "C" void bsw_ref_free(bsw_ctx *ctx, bsw_ref *ref)
+{
+    if (!ref) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (ref->d_pac) (void)hipFree(ref->d_pac);
+    delete ref;
+}
+
+extern "C" int bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rt, size_t n, bsw_dev_batch **out)
+{
+    if (!ctx || !p || !ref || !out || (!rt && n)) return fail(ctx, BSW_E_INVAL, "bsw_upload_ref: NULL argument");
+    /* mem_chain2aln's task extraction minus the target bases, which stay on the device */
+    std::vector<bsw_task> tasks(n ? n : 1);
+    size_t scratch_len = 0;
+    for (size_t i = 0; i < n; ++i) scratch_len += (size_t)(rt[i].seed.qbeg > 0 ? rt[i].seed.qbeg : 0);
+    std::vector<uint8_t> scratch(scratch_len + 1);
+    size_t so = 0;
+    const int64_t two = ref->l_pac << 1;
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_ref_task &r = rt[i];
+        const bsw_seed &sd = r.seed;
+        if (!r.query || r.l_query < 1 || sd.qbeg < 0 || sd.len < 1 || sd.qbeg + sd.len > r.l_query)
+            return fail(ctx, BSW_E_INVAL, "ref task %zu: bad seed / read", i);
+        if (r.rmax0 < 0 || r.rmax1 > two || r.rmax0 > sd.rbeg || r.rmax1 < sd.rbeg + sd.len ||
+            (r.rmax0 < ref->l_pac && ref->l_pac < r.rmax1))
+            return fail(ctx, BSW_E_INVAL, "ref task %zu: window outside the reference or bridging the strands", i);
+        const int64_t lt = sd.rbeg - r.rmax0, rtl = r.rmax1 - (sd.rbeg + sd.len);
+        if (lt > BSW_MAX_TLEN || rtl > BSW_MAX_TLEN) return fail(ctx, BSW_E_LIMIT, "ref task %zu: window beyond BSW_MAX_TLEN", i);
+        bsw_task &t = tasks[i];
+        memset(&t, 0, sizeof(t));
+        if (sd.qbeg > 0) {
+            for (int k = 0; k < sd.qbeg; ++k) scratch[so + (size_t)k] = r.query[sd.qbeg - 1 - k];
+            t.lquery = scratch.data() + so; t.lqlen = sd.qbeg; t.ltlen = (int32_t)lt;
+            so += (size_t)sd.qbeg;
+        }
+        if (sd.qbeg + sd.len != r.l_query) {
+            t.rquery = r.query + sd.qbeg + sd.len; t.rqlen = r.l_query - (sd.qbeg + sd.len); t.rtlen = (int32_t)rtl;
+        }
+        t.h0 = sd.len * p->mat[0]; t.init_score = r.init_score; t.qbeg = sd.qbeg; t.tag = r.tag;
+    }
+    return upload_common(ctx, p, tasks.data(), n, out, ref, rt);
+}
+
+extern "C" int bsw_extend_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rt, size_t n, bsw_result *out)
+{
+    if (!ctx || (!out && n)) return fail(ctx, BSW_E_INVAL, "bsw_extend_ref: NULL argument");
+    bsw_dev_batch *b = nullptr;
+    int rc = bsw_upload_ref(ctx, p, ref, rt, n, &b);
+    if (rc) return rc;
+    rc = bsw_run(ctx, b);
+    if (!rc) rc = bsw_download(ctx, b, out);
+    bsw_free_batch(ctx, b);
+    return rc;
 }
 
 static int enqueue_batch(bsw_ctx *ctx, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,

@@ -33,6 +33,15 @@ typedef struct bsw_dparams {
     int32_t w, pen_clip5, pen_clip3, zdrop, max_band_try;
 } bsw_dparams;
 
+/* one target to fetch from the device-resident 2-bit reference (bsw_fetch_kernel.hip) */
+typedef struct bsw_fetch_desc {
+    int64_t  x0;          /* coordinate of base 0 in bwa's [0, 2*l_pac) space */
+    uint32_t dst_word;    /* word offset into seq */
+    uint32_t tlen;
+    int32_t  dir;         /* +1 right-extension target, -1 left-extension target (reversed) */
+    int32_t  pad;
+} bsw_fetch_desc;
+
 #define BSW_KEY_BITS 10                        /* column index bits in the arg-max key */
 
 #endif

@@ -32,10 +32,12 @@ SYNTH = np.dtype([("seed", "<u8"), ("read_len", "<i4"), ("seed_len_min", "<i4"),
 SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
 ALNREG = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("score", "<i4"), ("truesc", "<i4"),
                    ("w", "<i4"), ("_pad", "<i4")])
+REF_TASK = np.dtype([("query", "<u8"), ("l_query", "<i4"), ("init_score", "<i4"), ("seed", SEED),
+                     ("rmax0", "<i8"), ("rmax1", "<i8"), ("tag", "<u4"), ("_pad", "<u4")])
 CONFIG = np.dtype([("device", "<i4"), ("kernel", "<i4"), ("streams", "<i4"), ("pack_threads", "<i4"),
                    ("chunk_tasks", "<u8")])
 assert PARAMS.itemsize == 68 and TASK.itemsize == 64 and EXT.itemsize == 32 and RESULT.itemsize == 96
-assert EXT_TASK.itemsize == 40 and SYNTH.itemsize == 72 and CONFIG.itemsize == 24
+assert EXT_TASK.itemsize == 40 and SYNTH.itemsize == 72 and CONFIG.itemsize == 24 and REF_TASK.itemsize == 56
 
 REFBATCH_IN_WORDS, REFBATCH_OUT_WORDS, REFBATCH_MAX_TASKS = 65536, 4096, 819
 KERNEL_AUTO, KERNEL_WAVE, KERNEL_LANE = 0, 1, 2
@@ -93,6 +95,10 @@ def lib():
             "bsw_refbatch_encode_results": (C.c_int, [vp, sz, vp]),
             "bsw_refbatch_decode_results": (C.c_int, [vp, sz, vp]),
             "bsw_refbatch_run": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+            "bsw_ref_upload": (C.c_int, [vp, vp, C.c_int64, C.POINTER(vp)]),
+            "bsw_ref_free": (None, [vp, vp]),
+            "bsw_upload_ref": (C.c_int, [vp, vp, vp, vp, sz, C.POINTER(vp)]),
+            "bsw_extend_ref": (C.c_int, [vp, vp, vp, vp, sz, vp]),
             "bsw_pack_bases": (C.c_int, [vp, C.c_int, vp]),
             "bsw_cal_max_gap": (C.c_int, [vp, C.c_int]),
             "bsw_chain_window": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
@@ -118,6 +124,7 @@ EXPORTS = ["ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_default_
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
            "bsw_refbatch_encode_results", "bsw_refbatch_decode_results", "bsw_refbatch_run",
+           "bsw_ref_upload", "bsw_ref_free", "bsw_upload_ref", "bsw_extend_ref",
            "bsw_pack_bases", "bsw_cal_max_gap", "bsw_chain_window", "bsw_seed_scratch_bytes", "bsw_seed_to_task",
            "bsw_result_to_alnreg", "bsw_pac_get_seq", "bsw_synth_generate", "bsw_synth_arena_bound"]
 
@@ -272,6 +279,21 @@ class BswContext:
     def download(self, batch):
         out = np.zeros(batch.n, dtype=RESULT)
         self._chk(lib().bsw_download(self.handle, batch.handle, out.ctypes.data), "bsw_download")
+        return out
+
+    # seeds against a device-resident 2-bit reference (F3)
+    def ref_upload(self, pac, l_pac):
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        h = C.c_void_p()
+        self._chk(lib().bsw_ref_upload(self.handle, pac.ctypes.data, l_pac, C.byref(h)), "bsw_ref_upload")
+        return h
+
+    def ref_free(self, ref):
+        lib().bsw_ref_free(self.handle, ref)
+
+    def extend_ref(self, params, ref, rtasks):
+        out = np.zeros(len(rtasks), dtype=RESULT)
+        self._chk(lib().bsw_extend_ref(self.handle, params.ctypes.data, ref, rtasks.ctypes.data, len(rtasks), out.ctypes.data), "bsw_extend_ref")
         return out
 
     def refbatch_run(self, in_words, variant=VARIANT_H, zdrop=0):

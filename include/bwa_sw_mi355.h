@@ -212,6 +212,26 @@ int      bsw_result_to_alnreg(const bsw_seed *s, const bsw_result *r, bsw_alnreg
  * returns the number of bases written, 0 if the range bridges the forward/reverse boundary */
 int64_t  bsw_pac_get_seq(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t end, uint8_t *dst);
 
+/* ---- seeds against a DEVICE-RESIDENT reference: the 2-bit pac is uploaded once, the
+ * extension targets are fetched on the GPU (bns_get_seq semantics, both strands, left side reversed),
+ * so only the reads travel over PCIe. ---- */
+typedef struct bsw_ref bsw_ref;
+typedef struct bsw_ref_task {
+    const uint8_t *query;   /* the whole read, codes 0..4                                  */
+    int32_t  l_query;
+    int32_t  init_score;    /* -1 in bwa                                                    */
+    bsw_seed seed;          /* rbeg in [0, 2*l_pac), qbeg, len                              */
+    int64_t  rmax0, rmax1;  /* reference window of the chain (bsw_chain_window)             */
+    uint32_t tag;
+    uint32_t _pad;
+} bsw_ref_task;
+int      bsw_ref_upload(bsw_ctx *ctx, const uint8_t *pac, int64_t l_pac, bsw_ref **out);
+void     bsw_ref_free(bsw_ctx *ctx, bsw_ref *ref);
+/* device-resident batch whose targets come from `ref`; then bsw_run / bsw_download as usual */
+int      bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *tasks, size_t n, bsw_dev_batch **out);
+/* convenience: upload_ref + run + download + free (synchronous) */
+int      bsw_extend_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *tasks, size_t n, bsw_result *out);
+
 /* ---- device sequence format: 4 bits per base, 16 bases per uint64, base k of a word in bits [4k,4k+3];
  * codes > 4 are stored as 4 (N).  words must hold (len+15)/16 entries.  Returns 1 if an N was seen. ---- */
 int      bsw_pack_bases(const uint8_t *bases, int len, uint64_t *words);

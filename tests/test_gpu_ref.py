@@ -1,0 +1,68 @@
+"""Seeds against a device-resident 2-bit reference: the GPU fetches the extension targets itself
+(bns_get_seq semantics, both strands, left side reversed).  The result batch must equal, byte for byte, the one
+obtained from host-side extraction (F2 glue) — on the GPU and on the CPU oracle."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads_and_seeds(host, rng, genome, n, rl=150):
+    lp = len(genome)
+    both = np.concatenate([genome, 3 - genome[::-1]])
+    reads, seeds = [], np.zeros(n, dtype=host.SEED)
+    for i in range(n):
+        strand = i % 2
+        pos = int(rng.integers(400, lp - 400)) + strand * lp
+        read = both[pos:pos + rl].copy()
+        sl = int(rng.integers(19, 60))
+        qb = int(rng.integers(0, rl - sl + 1)) if i % 11 else 0
+        if i % 13 == 0:
+            qb = rl - sl                                                    # no right side
+        for x in np.nonzero(rng.random(rl) < 0.02)[0]:                      # substitutions / N outside the seed
+            if not (qb <= x < qb + sl):
+                read[x] = 4 if rng.random() < 0.1 else (read[x] + 1 + rng.integers(0, 3)) % 4
+        if i % 7 == 0 and qb + sl + 20 < rl:                                # a deletion in the read (right flank)
+            cut = int(rng.integers(qb + sl + 5, rl - 10))
+            read = np.concatenate([read[:cut], read[cut + 3:], both[pos + rl:pos + rl + 3]])
+        reads.append(read.astype(np.uint8))
+        seeds[i] = (pos + qb, qb, sl)
+    return reads, seeds
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_device_fetch_equals_host_extraction(host, oracle, kernel):
+    rng = np.random.default_rng(100 + kernel)
+    lp = 50000
+    genome = rng.integers(0, 4, lp).astype(np.uint8)
+    pac = host.pack_pac(genome)
+    n = 3000
+    reads, seeds = _reads_and_seeds(host, rng, genome, n)
+    p = host.default_params()
+    tasks, keep = host.seeds_to_tasks(p, pac, lp, reads, seeds)             # host-side extraction (F2)
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    rt = np.zeros(n, dtype=host.REF_TASK)
+    rmax = np.zeros(2, dtype=np.int64)
+    qkeep = []
+    for i in range(n):
+        q = np.ascontiguousarray(reads[i])
+        qkeep.append(q)
+        host.lib().bsw_chain_window(p.ctypes.data, seeds[i:i + 1].ctypes.data, 1, len(q), lp, rmax.ctypes.data)
+        rt[i]["query"], rt[i]["l_query"], rt[i]["init_score"] = q.ctypes.data, len(q), -1
+        rt[i]["seed"] = seeds[i]
+        rt[i]["rmax0"], rt[i]["rmax1"], rt[i]["tag"] = rmax[0], rmax[1], i
+    with host.BswContext(device=0, kernel=kernel) as ctx:
+        ref = ctx.ref_upload(pac, lp)
+        got = ctx.extend_ref(p, ref, rt)
+        assert_same(got, want, tasks)
+        assert_same(ctx.extend_pairs(p, tasks), want, tasks)                # same seeds, targets shipped from the host
+        # errors, not fallbacks
+        bad = rt[:1].copy()
+        bad["rmax0"], bad["rmax1"] = lp - 5, lp + 5                         # bridges the strands
+        with pytest.raises(host.BswError):
+            ctx.extend_ref(p, ref, bad)
+        ctx.ref_free(ref)
+    aln = host.results_to_alnregs(seeds, got)
+    assert ((aln["re"] - aln["rb"]) > 0).all() and (aln["qe"] > aln["qb"]).all()
