@@ -483,6 +483,30 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
     return BSW_OK;
 }
 
+extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, size_t n, int kernel, int pack_threads,
+                                  uint32_t *order, uint32_t *seg)
+{
+    if (!p || (!tasks && n) || !order || !seg) return BSW_E_INVAL;
+    bsw_ctx tmp;                                   /* carries only the kernel choice; no device is touched */
+    tmp.cfg.kernel = kernel;
+    bsw_dparams dp;
+    int rc = check_params(&tmp, p, &dp);
+    if (rc) return rc;
+    packed_host ph;
+    size_t words = 0;
+    rc = pack_tasks(&tmp, p, tasks, n, pack_threads > 0 ? pack_threads : 1, nullptr, 0, ph, nullptr, order, &words);
+    if (rc) return rc;
+    const batch_plan &pl = ph.plan;
+    int k = 0;
+    for (int c = 0; c < MAX_CLASSES; ++c) seg[k++] = pl.wave_start[c];
+    seg[k++] = pl.lane_all_off;                    /* 8 */
+    for (int c = 0; c < MAX_LANE_CLASSES; ++c) seg[k++] = pl.laneL_off[c];    /* 9..16 */
+    for (int c = 0; c < MAX_LANE_CLASSES; ++c) seg[k++] = pl.laneR_off[c];    /* 17..24 */
+    seg[k++] = pl.redo_off;                        /* 25 */
+    seg[k++] = pl.order_len;                       /* 26 */
+    return (int64_t)words;
+}
+
 /* ---- device-resident batches ------------------------------------------------ */
 extern "C" void bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b)
 {

@@ -99,6 +99,7 @@ def lib():
             "bsw_ref_free": (None, [vp, vp]),
             "bsw_upload_ref": (C.c_int, [vp, vp, vp, vp, sz, C.POINTER(vp)]),
             "bsw_extend_ref": (C.c_int, [vp, vp, vp, vp, sz, vp]),
+            "bsw_plan_batch": (C.c_int64, [vp, vp, sz, C.c_int, C.c_int, vp, vp]),
             "bsw_pack_bases": (C.c_int, [vp, C.c_int, vp]),
             "bsw_cal_max_gap": (C.c_int, [vp, C.c_int]),
             "bsw_chain_window": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
@@ -125,7 +126,7 @@ EXPORTS = ["ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_default_
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
            "bsw_refbatch_encode_results", "bsw_refbatch_decode_results", "bsw_refbatch_run",
            "bsw_ref_upload", "bsw_ref_free", "bsw_upload_ref", "bsw_extend_ref",
-           "bsw_pack_bases", "bsw_cal_max_gap", "bsw_chain_window", "bsw_seed_scratch_bytes", "bsw_seed_to_task",
+           "bsw_plan_batch", "bsw_pack_bases", "bsw_cal_max_gap", "bsw_chain_window", "bsw_seed_scratch_bytes", "bsw_seed_to_task",
            "bsw_result_to_alnreg", "bsw_pac_get_seq", "bsw_synth_generate", "bsw_synth_arena_bound"]
 
 
@@ -340,6 +341,19 @@ def refbatch_decode_results(words, n):
     if rc < 0:
         raise BswError(rc, "bsw_refbatch_decode_results")
     return res
+
+
+PLAN_SEGS = 26
+
+
+def plan_batch(params, tasks, kernel=KERNEL_AUTO, pack_threads=1):
+    """Batch manager's launch plan for a task batch (host only).  Returns (order, seg, seq_words)."""
+    order = np.zeros(4 * len(tasks) + 16, dtype=np.uint32)
+    seg = np.zeros(PLAN_SEGS + 1, dtype=np.uint32)
+    w = lib().bsw_plan_batch(params.ctypes.data, tasks.ctypes.data, len(tasks), kernel, pack_threads, order.ctypes.data, seg.ctypes.data)
+    if w < 0:
+        raise BswError(int(w), "bsw_plan_batch")
+    return order, seg, int(w)
 
 
 def pack_bases(bases):

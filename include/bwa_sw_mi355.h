@@ -168,6 +168,15 @@ int      bsw_last_run_ms(bsw_ctx *ctx, float *ms);
 int      bsw_run_history(bsw_ctx *ctx, float *ms, int cap);
 void     bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b);
 
+/* ---- batch plan (host only, no GPU needed): how the batch manager would cut tasks[0..n) into launches.
+ * order[] (capacity 4*n+16) receives the launch order; seg[] receives BSW_PLAN_SEGS+1 offsets into order[]:
+ * segments 0..7 = wave-per-task classes (64,128,192,256,512,1024 columns, then 2 unused), 8 = all lane seeds,
+ * 9..16 = lane left sides per lane class, 17..24 = lane right sides per lane class, 25 = redo list space.
+ * kernel = BSW_KERNEL_*.  Returns the number of sequence words the batch needs, or <0. ---- */
+#define BSW_PLAN_SEGS 26
+int64_t  bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, size_t n, int kernel, int pack_threads,
+                        uint32_t *order, uint32_t *seg /*[BSW_PLAN_SEGS+1]*/);
+
 /* ---- reference wire format (bwa_mem_sw.v:163-170) ----------- */
 #define BSW_REFBATCH_IN_WORDS   65536   /* 256 KiB task batch (tbb.v:59)         */
 #define BSW_REFBATCH_OUT_WORDS  4096    /* 16 KiB result batch (rbb.v:59)        */

@@ -138,3 +138,52 @@ def test_pack_bases_matches_reference_packer(host):
             ref[k >> 4] |= np.uint64(min(int(v), 4)) << np.uint64(4 * (k & 15))
         assert (words == ref).all(), (trial, b)
         assert has_n == bool((b >= 4).any())
+
+
+def test_batch_plan_bins(host):
+    """Host batch manager (no GPU): every seed lands in exactly one kernel bin; lane bins hold each side once,
+    sorted by query length inside a class; N-rich, long or wide-score seeds go to the wave classes."""
+    import _gen
+    rng = np.random.default_rng(3)
+    seeds = _gen.random_seeds(rng, 5000, qmax=300, nrate=0.002, h0max=80)
+    seeds += [dict(rq=np.zeros(100, np.uint8), rt=np.zeros(120, np.uint8), h0=70000)]       # beyond 16-bit bins
+    tasks, arena = host.make_tasks(seeds)
+    n = len(tasks)
+    p = host.default_params()
+    lane_cols = [(8, 72), (8, 136), (8, 232), (16, 72), (16, 136)]
+    for kernel in (host.KERNEL_AUTO, host.KERNEL_LANE, host.KERNEL_WAVE):
+        order, seg, words = host.plan_batch(p, tasks, kernel=kernel, pack_threads=3)
+        exp_words = int((((tasks["lqlen"] + 15) // 16 + (tasks["ltlen"] + 15) // 16) * (tasks["lqlen"] > 0)
+                         + ((tasks["rqlen"] + 15) // 16 + (tasks["rtlen"] + 15) // 16) * (tasks["rqlen"] > 0)).sum())
+        assert words == exp_words
+        wave = order[seg[0]:seg[8]]
+        lane = order[seg[8]:seg[9]]
+        assert len(wave) + len(lane) == n and len(np.unique(np.concatenate([wave, lane]))) == n
+        if kernel == host.KERNEL_WAVE:
+            assert len(lane) == 0
+        else:
+            assert len(lane) > 2048
+        # wave classes by columns per lane
+        cols = [64, 128, 192, 256, 512, 1024]
+        for c in range(6):
+            t = tasks[order[seg[c]:seg[c + 1]]]
+            qm = np.maximum(t["lqlen"], t["rqlen"])
+            assert (qm + 1 <= cols[c]).all() and (c == 0 or (qm + 1 > cols[c - 1]).all())
+        top = tasks["h0"].astype(np.int64) + tasks["lqlen"] + tasks["rqlen"]
+        qmax = np.maximum(tasks["lqlen"], tasks["rqlen"])
+        assert (top[lane] < 65000).all() and (qmax[lane] + 1 <= 232).all()
+        for side, base, qf in ((0, 9, "lqlen"), (1, 17, "rqlen")):
+            allside = order[seg[base]:seg[base + 8]]
+            assert sorted(allside) == sorted(lane[tasks[qf][lane] > 0])
+            for c, (bits, ncol) in enumerate(lane_cols):
+                t = tasks[order[seg[base + c]:seg[base + c + 1]]]
+                if len(t) == 0:
+                    continue
+                q = t[qf]
+                assert (np.diff(q) >= 0).all() and (q + 1 <= ncol).all()
+                tt = t["h0"].astype(np.int64) + t["lqlen"] + t["rqlen"]
+                assert ((tt <= 255) if bits == 8 else (tt > 255) | (np.maximum(t["lqlen"], t["rqlen"]) + 1 > 232)).all()
+        assert seg[26] - seg[25] == len(lane)                                 # redo list space
+    # AUTO keeps small batches on the wave kernel
+    order, seg, words = host.plan_batch(p, tasks[:500], kernel=host.KERNEL_AUTO)
+    assert seg[9] - seg[8] == 0
