@@ -145,7 +145,7 @@ def test_batch_plan_bins(host):
     sorted by query length inside a class; N-rich, long or wide-score seeds go to the wave classes."""
     import _gen
     rng = np.random.default_rng(3)
-    seeds = _gen.random_seeds(rng, 5000, qmax=300, nrate=0.002, h0max=80)
+    seeds = _gen.random_seeds(rng, 8000, qmax=300, nrate=0.002, h0max=80)
     seeds += [dict(rq=np.zeros(100, np.uint8), rt=np.zeros(120, np.uint8), h0=70000)]       # beyond 16-bit bins
     tasks, arena = host.make_tasks(seeds)
     n = len(tasks)
