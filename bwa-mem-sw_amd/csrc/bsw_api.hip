@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -328,6 +329,9 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
                       bool dev_targets = false /* targets are fetched on the device: leave their words alone */)
 {
     const int mx = mat_max(p->mat);
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_a = dbg ? tnow() : 0;
     std::vector<uint64_t> off(n + 1);
     std::vector<uint8_t> has_n(n ? n : 1, 0);
     uint64_t acc = 0;
@@ -356,6 +360,7 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
     uint32_t *ord = order_dst;
     if (!ord) { ph.order.assign(order_capacity(n), 0); ord = ph.order.data(); }
 
+    double t_b = dbg ? tnow() : 0;
     auto work = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const bsw_task &t = tasks[i];
@@ -390,6 +395,7 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
         for (auto &t : th) t.join();
     }
 
+    double t_c = dbg ? tnow() : 0;
     /* ---- binning ---- */
     batch_plan &pl = ph.plan;
     pl = batch_plan();
@@ -479,6 +485,7 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
     pl.redo_off = cur;
     pl.order_len = cur + n_lane;
     pl.redo_cls = task_class(std::max(cols8, cols16) - 1);
+    if (dbg) fprintf(stderr, "[bsw] pack_tasks n=%zu: validate+alloc %.2f ms, pack %.2f ms, bin %.2f ms\n", n, t_b - t_a, t_c - t_b, tnow() - t_c);
     if (seq_words_out) *seq_words_out = (size_t)acc;
     return BSW_OK;
 }
