@@ -300,3 +300,22 @@ def test_full_size_properties(host, oracle, ctx):
     idx = np.arange(0, n, 97)
     want = oracle.pair_batch(p, tasks[idx].copy(), nthreads=8)
     assert_same(res[idx], want, tasks[idx])
+
+
+def test_config2_10m_mixed_bins_streaming(host, oracle):
+    """BASELINE configs[2] size: 10M 150 bp PE seeds, mixed bins, through the streaming batch manager
+    (host buffers in, host buffers out); oracle parity on a strided sample + size-independent properties."""
+    n = 10_000_000
+    tasks, arena = host.synth_tasks(n, seed=77, seed_len_min=19, seed_len_max=60, seed_at_start=0,
+                                    junk_frac=0.05, n_rate=0.0005)
+    p = host.default_params()
+    with host.BswContext(device=0, streams=3, chunk_tasks=65536, pack_threads=8) as c:
+        res = c.extend_pairs(p, tasks)
+    assert (res["tag"] == np.arange(n, dtype=np.uint32)).all()
+    assert (res["score"] >= tasks["h0"]).all() and (res["score"] <= 150).all()
+    assert (res["qb"] >= 0).all() and (res["qb"] <= tasks["qbeg"]).all() and (res["qe"] <= tasks["rqlen"]).all()
+    assert (res["left"]["cells"][tasks["lqlen"] == 0] == 0).all()
+    assert ((res["w"] == 100) | (res["w"] == 200)).all()
+    idx = np.arange(0, n, 997)
+    want = oracle.pair_batch(p, tasks[idx].copy(), nthreads=16)
+    assert_same(res[idx], want, tasks[idx])
