@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=2048, help="seeds spot-checked against the oracle after timing")
     ap.add_argument("--spec", action="append", default=[], help="override a generator field, e.g. --spec n_rate=0 (experiments)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / timing reduction (nccl = RCCL; gloo only to rehearse N>1 on a 1-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses device 0 (needs --backend gloo)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto (batch manager picks per bin), 1 wave-per-task only, 2 force lane bins")
     args = ap.parse_args()
 
@@ -77,13 +80,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if args.share_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU path)"
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     pkg = graft.load_package()
     host = pkg.host
@@ -124,7 +133,7 @@ def main():
     nominal = int((tasks["lqlen"].astype(np.int64) * tasks["ltlen"]).sum() + (tasks["rqlen"].astype(np.int64) * tasks["rtlen"]).sum())
 
     if dist is not None:
-        v = torch.tensor([dt, float(cells), float(ext_calls), float(len(tasks)), float(nominal)], dtype=torch.float64, device="cuda")
+        v = torch.tensor([dt, float(cells), float(ext_calls), float(len(tasks)), float(nominal)], dtype=torch.float64, device=red_dev)
         tmax = v[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
