@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
     }
 }
 
+#if !defined(BSW_LANE_TU) || BSW_LANE_TU < 0
 /* Pair-level decision for seeds whose sides came from the lane kernel (P2/P3:
  * sw_pe_array_proc_element.v:1593-1685).  A seed whose first band try does not satisfy the
  * MAX_BAND_TRY exit test goes to the redo list instead. */
@@ -369,15 +370,11 @@ __global__ __launch_bounds__(256) void bsw_pair_finalize(const bsw_dparams P, co
     r.tag = T.tag; r.qb = qb; r.qe = qe; r.rb = rb; r.re = re; r.score = score; r.truesc = truesc; r.w = P.w;
     out[ti] = r;
 }
+#endif
 
-/* lane classes: (bits per h/e value, 8-column blocks).  8-bit classes first. */
-struct lane_class_t { int bits, qb; };
-static const lane_class_t kLaneClasses[] = {{8, 9}, {8, 17}, {8, 29}, {16, 9}, {16, 17}};
-
-int lane_class_count() { return (int)(sizeof(kLaneClasses) / sizeof(kLaneClasses[0])); }
-int lane_class_cols(int cls) { return kLaneClasses[cls].qb * 8; }
-int lane_class_bits(int cls) { return kLaneClasses[cls].bits; }
-
+/* lane classes: (bits per h/e value, 8-column blocks).  8-bit classes first.
+ * The file is compiled once per class (-DBSW_LANE_TU=k, see Makefile) so the five sets of unrolled
+ * kernels build in parallel; -DBSW_LANE_TU=-1 builds the class table, finalize kernel and dispatcher. */
 template <int QB, bool B8, int WPS>
 static hipError_t launch_lane_qb(int variant, bool sym, const bsw_dparams &P, int side, const uint64_t *seq,
                                  const bsw_dtask *tasks, const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
@@ -393,17 +390,52 @@ static hipError_t launch_lane_qb(int variant, bool sym, const bsw_dparams &P, in
     return hipGetLastError();
 }
 
+#define BSW_LANE_ARGS int variant, bool sym, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks, \
+                      const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s
+hipError_t launch_lane_c0(BSW_LANE_ARGS);
+hipError_t launch_lane_c1(BSW_LANE_ARGS);
+hipError_t launch_lane_c2(BSW_LANE_ARGS);
+hipError_t launch_lane_c3(BSW_LANE_ARGS);
+hipError_t launch_lane_c4(BSW_LANE_ARGS);
+
+#ifndef BSW_LANE_TU
+#define BSW_LANE_TU -2      /* single translation unit: everything */
+#endif
+#if BSW_LANE_TU == 0 || BSW_LANE_TU == -2
+hipError_t launch_lane_c0(BSW_LANE_ARGS) { return launch_lane_qb<9, true, 4>(variant, sym, P, side, seq, tasks, order, n, out, s); }
+#endif
+#if BSW_LANE_TU == 1 || BSW_LANE_TU == -2
+hipError_t launch_lane_c1(BSW_LANE_ARGS) { return launch_lane_qb<17, true, 3>(variant, sym, P, side, seq, tasks, order, n, out, s); }
+#endif
+#if BSW_LANE_TU == 2 || BSW_LANE_TU == -2
+hipError_t launch_lane_c2(BSW_LANE_ARGS) { return launch_lane_qb<29, true, 2>(variant, sym, P, side, seq, tasks, order, n, out, s); }
+#endif
+#if BSW_LANE_TU == 3 || BSW_LANE_TU == -2
+hipError_t launch_lane_c3(BSW_LANE_ARGS) { return launch_lane_qb<9, false, 3>(variant, sym, P, side, seq, tasks, order, n, out, s); }
+#endif
+#if BSW_LANE_TU == 4 || BSW_LANE_TU == -2
+hipError_t launch_lane_c4(BSW_LANE_ARGS) { return launch_lane_qb<17, false, 2>(variant, sym, P, side, seq, tasks, order, n, out, s); }
+#endif
+
+#if BSW_LANE_TU < 0
+struct lane_class_t { int bits, qb; };
+static const lane_class_t kLaneClasses[] = {{8, 9}, {8, 17}, {8, 29}, {16, 9}, {16, 17}};   /* = launch_lane_c0..c4 */
+
+int lane_class_count() { return (int)(sizeof(kLaneClasses) / sizeof(kLaneClasses[0])); }
+int lane_class_cols(int cls) { return kLaneClasses[cls].qb * 8; }
+int lane_class_bits(int cls) { return kLaneClasses[cls].bits; }
+
 hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
                        const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins;
     switch (cls) {
-    case 0: return launch_lane_qb<9, true, 4>(variant, sym, P, side, seq, tasks, order, n, out, s);
-    case 1: return launch_lane_qb<17, true, 3>(variant, sym, P, side, seq, tasks, order, n, out, s);
-    case 2: return launch_lane_qb<29, true, 2>(variant, sym, P, side, seq, tasks, order, n, out, s);
-    case 3: return launch_lane_qb<9, false, 3>(variant, sym, P, side, seq, tasks, order, n, out, s);
-    default: return launch_lane_qb<17, false, 2>(variant, sym, P, side, seq, tasks, order, n, out, s);
+    case 0: return launch_lane_c0(variant, sym, P, side, seq, tasks, order, n, out, s);
+    case 1: return launch_lane_c1(variant, sym, P, side, seq, tasks, order, n, out, s);
+    case 2: return launch_lane_c2(variant, sym, P, side, seq, tasks, order, n, out, s);
+    case 3: return launch_lane_c3(variant, sym, P, side, seq, tasks, order, n, out, s);
+    default: return launch_lane_c4(variant, sym, P, side, seq, tasks, order, n, out, s);
     }
 }
 
@@ -414,5 +446,6 @@ hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const u
     hipLaunchKernelGGL(bsw_pair_finalize, dim3((n + 255u) / 256u), dim3(256), 0, s, P, tasks, order, n, out, redo, redo_cnt);
     return hipGetLastError();
 }
+#endif
 
 }  // namespace bsw

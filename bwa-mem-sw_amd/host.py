@@ -60,7 +60,7 @@ def lib_path():
 def build_library(force=False):
     """Compile csrc/ for gfx950 into libbwasw_mi355.so (hipcc cross-compiles without a GPU)."""
     if force or not os.path.exists(_LIB):
-        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-j6", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.DEVNULL)
     return _LIB
 
 
