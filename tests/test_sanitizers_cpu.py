@@ -18,3 +18,26 @@ def test_host_c_code_under_asan_ubsan(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout[-2000:], out.stderr[-4000:])
     assert "asan_host ok" in out.stdout
+
+
+def test_batch_manager_host_logic_under_asan_ubsan(tmp_path):
+    """bsw_api.hip compiled host-only with sanitizers, kernel launchers stubbed: validation, SWAR packing, binning."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    inc = ["-I", os.path.join(ROOT, "include")]
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
+    objs = []
+    for name, src, cc in (("api", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_api.hip"), "hip"),
+                          ("plan", os.path.join(ROOT, "tests", "asan_plan.cpp"), "hip"),
+                          ("synth", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_synth.c"), "c"),
+                          ("refbatch", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_refbatch.c"), "c")):
+        obj = str(tmp_path / (name + ".o"))
+        if cc == "hip":
+            subprocess.check_call([hipcc, "--cuda-host-only", "-x", "hip", "-std=c++17"] + san + inc + ["-c", src, "-o", obj])
+        else:
+            subprocess.check_call(["gcc"] + san + inc + ["-c", src, "-o", obj])
+        objs.append(obj)
+    exe = str(tmp_path / "asan_plan")
+    subprocess.check_call([hipcc, "-fsanitize=address,undefined"] + objs + ["-o", exe, "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout[-2000:], out.stderr[-4000:])
+    assert "asan_plan ok" in out.stdout
