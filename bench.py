@@ -188,7 +188,7 @@ def main():
             c1 = int(ref["left"]["cells"][:n1].astype(np.int64).sum() + ref["right"]["cells"][:n1].astype(np.int64).sum())
             out["cpu_baseline"] = {
                 "value": round(ccells / dcpu / 1e9, 4), "unit": "GCUPS", "cores": ncpu, "kind": "port",
-                "sample": "first %d seeds of the same batch, scalar C oracle (-O3 -march=native), %d pthreads" % (ns, ncpu),
+                "sample": "first %d seeds of the same batch, scalar C oracle (-O3 -march=x86-64-v3), %d pthreads" % (ns, ncpu),
                 "single_thread_gcups": round(c1 / d1 / 1e9, 4),
             }
             nchk = min(args.check, ns)
