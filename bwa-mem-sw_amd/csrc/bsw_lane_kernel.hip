@@ -229,12 +229,10 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
             const uint32_t n0 = (uint32_t)((tb & 1) - 1), n1 = (uint32_t)(((tb >> 1) & 1) - 1);
             const uint32_t tn = (uint32_t)((tb >> 2) - 1);             /* 0 when the target base is N, else ~0 */
             const int vmis = tn ? k.vnegb : k.vn;                      /* a row against N scores mat[4][.] everywhere */
-            uint32_t rm[NW], rn[NW];
+            uint32_t rm[NW];
 #pragma unroll
-            for (int wd = 0; wd < NW; ++wd) {                          /* rm: 1 where q_j == t_i; rn: 1 where q_j is N */
-                rn[wd] = lds_q[wv][3 * wd + 2][lane];
-                rm[wd] = (lds_q[wv][3 * wd][lane] ^ n0) & (lds_q[wv][3 * wd + 1][lane] ^ n1) & tn & ~rn[wd];
-            }
+            for (int wd = 0; wd < NW; ++wd)                            /* rm: 1 where q_j == t_i (and neither is N) */
+                rm[wd] = (lds_q[wv][3 * wd][lane] ^ n0) & (lds_q[wv][3 * wd + 1][lane] ^ n1) & tn & ~lds_q[wv][3 * wd + 2][lane];
             int h1 = beg == 0 ? max(h0 - (o_del + e_del * (i + 1)), 0) : 0;
             /* Row max key and first/last non-zero column are kept per 64-column group, relative to the
              * group: VOP3 forms take no 32-bit literal on gfx9, so absolute column numbers > 64 would
@@ -251,9 +249,10 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
                 bool nz[8];
                 const bool dense = j0 >= jbm && j0 + 8 <= jem;
                 if ((nblk >> (j0 / 8)) & 1u) {                        /* rare: a query N somewhere in this block */
+                    const uint32_t rnw = lds_q[wv][3 * (j0 >> 5) + 2][lane];   /* 1 where q_j is N; fetched on demand */
                     static_for<8>([&](auto ci) {
                         constexpr int J = j0 + decltype(ci)::value;
-                        nz[J - j0] = lane_cell<VAR, SYM, true, B8, true>(Pr[B8 ? J / 2 : J], J, rm[J >> 5], rn[J >> 5], vmis, k, beg, len, h1, f, mkg[g]);
+                        nz[J - j0] = lane_cell<VAR, SYM, true, B8, true>(Pr[B8 ? J / 2 : J], J, rm[J >> 5], rnw, vmis, k, beg, len, h1, f, mkg[g]);
                     });
                 } else if (dense) {
                     static_for<8>([&](auto ci) {
