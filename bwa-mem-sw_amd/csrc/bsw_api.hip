@@ -452,7 +452,7 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
     pl.lane_all_cnt = n_lane;
     for (size_t i = 0; i < n; ++i)
         if (lane_bits[i]) ord[cur++] = (uint32_t)i;
-    /* per side: counting sort by (lane class, query length) so a wave holds equal-length queries */
+    /* per side: counting sort by (lane class, query length descending) so a wave holds equal-length queries */
     for (int side = 0; side < 2; ++side) {
         std::vector<uint32_t> hist((size_t)nlc * 256 + 1, 0);
         auto key = [&](uint32_t ti) -> int {
@@ -467,9 +467,9 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
         uint32_t *offs = side ? pl.laneR_off : pl.laneL_off;
         std::vector<uint32_t> start((size_t)nlc * 256 + 1, 0);
         uint32_t run = cur;
-        for (int c = 0; c < nlc; ++c) {
+        for (int c = 0; c < nlc; ++c) {                 /* inside a class: longest queries (most work) first */
             offs[c] = run;
-            for (int q = 0; q < 256; ++q) {
+            for (int q = 255; q >= 0; --q) {
                 start[(size_t)c * 256 + q] = run;
                 run += hist[(size_t)c * 256 + q];
             }

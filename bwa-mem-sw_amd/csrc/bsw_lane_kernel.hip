@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void bsw_pair_finalize(const bsw_dparams P, co
 #endif
 
 /* lane classes: (bits per h/e value, 8-column blocks).  8-bit classes first.
- * The file is compiled once per class (-DBSW_LANE_TU=k, see Makefile) so the five sets of unrolled
+ * The file is compiled once per class (-DBSW_LANE_TU=k, see Makefile) so the three sets of unrolled
  * kernels build in parallel; -DBSW_LANE_TU=-1 builds the class table, finalize kernel and dispatcher. */
 template <int QB, bool B8, int WPS>
 static hipError_t launch_lane_qb(int variant, bool sym, const bsw_dparams &P, int side, const uint64_t *seq,
@@ -394,31 +394,25 @@ static hipError_t launch_lane_qb(int variant, bool sym, const bsw_dparams &P, in
 hipError_t launch_lane_c0(BSW_LANE_ARGS);
 hipError_t launch_lane_c1(BSW_LANE_ARGS);
 hipError_t launch_lane_c2(BSW_LANE_ARGS);
-hipError_t launch_lane_c3(BSW_LANE_ARGS);
-hipError_t launch_lane_c4(BSW_LANE_ARGS);
 
 #ifndef BSW_LANE_TU
 #define BSW_LANE_TU -2      /* single translation unit: everything */
 #endif
 #if BSW_LANE_TU == 0 || BSW_LANE_TU == -2
-hipError_t launch_lane_c0(BSW_LANE_ARGS) { return launch_lane_qb<9, true, 4>(variant, sym, P, side, seq, tasks, order, n, out, s); }
+hipError_t launch_lane_c0(BSW_LANE_ARGS) { return launch_lane_qb<17, true, 3>(variant, sym, P, side, seq, tasks, order, n, out, s); }
 #endif
 #if BSW_LANE_TU == 1 || BSW_LANE_TU == -2
-hipError_t launch_lane_c1(BSW_LANE_ARGS) { return launch_lane_qb<17, true, 3>(variant, sym, P, side, seq, tasks, order, n, out, s); }
+hipError_t launch_lane_c1(BSW_LANE_ARGS) { return launch_lane_qb<29, true, 2>(variant, sym, P, side, seq, tasks, order, n, out, s); }
 #endif
 #if BSW_LANE_TU == 2 || BSW_LANE_TU == -2
-hipError_t launch_lane_c2(BSW_LANE_ARGS) { return launch_lane_qb<29, true, 2>(variant, sym, P, side, seq, tasks, order, n, out, s); }
-#endif
-#if BSW_LANE_TU == 3 || BSW_LANE_TU == -2
-hipError_t launch_lane_c3(BSW_LANE_ARGS) { return launch_lane_qb<9, false, 3>(variant, sym, P, side, seq, tasks, order, n, out, s); }
-#endif
-#if BSW_LANE_TU == 4 || BSW_LANE_TU == -2
-hipError_t launch_lane_c4(BSW_LANE_ARGS) { return launch_lane_qb<17, false, 2>(variant, sym, P, side, seq, tasks, order, n, out, s); }
+hipError_t launch_lane_c2(BSW_LANE_ARGS) { return launch_lane_qb<17, false, 2>(variant, sym, P, side, seq, tasks, order, n, out, s); }
 #endif
 
 #if BSW_LANE_TU < 0
 struct lane_class_t { int bits, qb; };
-static const lane_class_t kLaneClasses[] = {{8, 9}, {8, 17}, {8, 29}, {16, 9}, {16, 17}};   /* = launch_lane_c0..c4 */
+/* A narrower class (72 columns) was measured and dropped: the unrolled blocks beyond a wave's live range are skipped
+ * by scalar branches anyway, and one launch per side has one tail instead of two (+8 % on the mixed-bin workload). */
+static const lane_class_t kLaneClasses[] = {{8, 17}, {8, 29}, {16, 17}};   /* = launch_lane_c0..c2 */
 
 int lane_class_count() { return (int)(sizeof(kLaneClasses) / sizeof(kLaneClasses[0])); }
 int lane_class_cols(int cls) { return kLaneClasses[cls].qb * 8; }
@@ -432,9 +426,7 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
     switch (cls) {
     case 0: return launch_lane_c0(variant, sym, P, side, seq, tasks, order, n, out, s);
     case 1: return launch_lane_c1(variant, sym, P, side, seq, tasks, order, n, out, s);
-    case 2: return launch_lane_c2(variant, sym, P, side, seq, tasks, order, n, out, s);
-    case 3: return launch_lane_c3(variant, sym, P, side, seq, tasks, order, n, out, s);
-    default: return launch_lane_c4(variant, sym, P, side, seq, tasks, order, n, out, s);
+    default: return launch_lane_c2(variant, sym, P, side, seq, tasks, order, n, out, s);
     }
 }
 

@@ -12,8 +12,8 @@ namespace bsw {
 static const int kW[] = {1, 2, 3, 4, 8, 16};
 int wave_class_count() { return 6; }
 int wave_class_cols(int c) { return kW[c] * 64; }
-static const int kLb[] = {8, 8, 8, 16, 16}, kLc[] = {72, 136, 232, 72, 136};
-int lane_class_count() { return 5; }
+static const int kLb[] = {8, 8, 16}, kLc[] = {136, 232, 136};
+int lane_class_count() { return 3; }
 int lane_class_cols(int c) { return kLc[c]; }
 int lane_class_bits(int c) { return kLb[c]; }
 hipError_t launch_wave(int, int, const bsw_dparams &, const uint64_t *, const bsw_dtask *, const uint32_t *, uint32_t, const uint32_t *, bsw_result *, hipStream_t) { return hipSuccess; }

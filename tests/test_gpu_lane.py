@@ -68,7 +68,7 @@ def test_match_mismatch_scores(host, oracle, lctx, ab):
         assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=8), tasks)
 
 
-# lane classes hold qlen+1 <= 72 / 104 / 136 columns
+# lane classes hold qlen+1 <= 136 / 232 columns; the narrow values exercise block skipping
 @pytest.mark.parametrize("qlen", [1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 70, 71, 72, 102, 103, 104, 134, 135, 136])
 def test_lane_class_boundaries(host, oracle, lctx, qlen):
     rng = np.random.default_rng(500 + qlen)
