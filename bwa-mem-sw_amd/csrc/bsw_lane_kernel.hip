@@ -399,10 +399,10 @@ hipError_t launch_lane_c2(BSW_LANE_ARGS);
 #define BSW_LANE_TU -2      /* single translation unit: everything */
 #endif
 #if BSW_LANE_TU == 0 || BSW_LANE_TU == -2
-hipError_t launch_lane_c0(BSW_LANE_ARGS) { return launch_lane_qb<17, true, 3>(variant, sym, P, side, seq, tasks, order, n, out, s); }
+hipError_t launch_lane_c0(BSW_LANE_ARGS) { return launch_lane_qb<17, true, 4>(variant, sym, P, side, seq, tasks, order, n, out, s); }
 #endif
 #if BSW_LANE_TU == 1 || BSW_LANE_TU == -2
-hipError_t launch_lane_c1(BSW_LANE_ARGS) { return launch_lane_qb<29, true, 2>(variant, sym, P, side, seq, tasks, order, n, out, s); }
+hipError_t launch_lane_c1(BSW_LANE_ARGS) { return launch_lane_qb<29, true, 3>(variant, sym, P, side, seq, tasks, order, n, out, s); }
 #endif
 #if BSW_LANE_TU == 2 || BSW_LANE_TU == -2
 hipError_t launch_lane_c2(BSW_LANE_ARGS) { return launch_lane_qb<17, false, 2>(variant, sym, P, side, seq, tasks, order, n, out, s); }
