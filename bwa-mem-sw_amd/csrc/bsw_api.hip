@@ -333,7 +333,6 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_a = dbg ? tnow() : 0;
     std::vector<uint64_t> off(n + 1);
-    std::vector<uint8_t> has_n(n ? n : 1, 0);
     uint64_t acc = 0;
     for (size_t i = 0; i < n; ++i) {
         const bsw_task &t = tasks[i];
@@ -376,7 +375,7 @@ static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, 
                 d.rq_off = (uint32_t)o; nn |= pack_seq(t.rquery, t.rqlen, seq + o); o += nwords(t.rqlen);
                 d.rt_off = (uint32_t)o; if (!dev_targets) nn |= pack_seq(t.rtarget, t.rtlen, seq + o); o += nwords(t.rtlen);
             }
-            has_n[i] = (uint8_t)nn;
+            (void)nn;                               /* N-bearing seeds are fine for both kernels */
             d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
             d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
             d.wlim_l = (uint16_t)gap_limit(p, mx, t.lqlen, p->pen_clip5);

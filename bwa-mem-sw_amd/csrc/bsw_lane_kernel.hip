@@ -11,7 +11,7 @@
  *     !B8 : one column per VGPR, 16-bit h and e
  * Blocks no live lane touches are skipped with scalar branches, blocks inside every live lane's
  * [beg,end) run a mask-free "dense" body, the rest an exec-masked "edge" body.
- *   - score lookup: the query is held as two bit-planes per lane in LDS; per row the target base
+ *   - score lookup: the query is held as three bit-planes per lane in LDS (code bit 0, bit 1, N); per row the target base
  *     selects a 32-column match mask, per cell v_bfe_i32 + v_bfi give +a / -b;
  *   - the packed target (16 bases per uint64) is staged per wave in LDS, 128 rows at a time;
  *   - only the first band try runs here.  A side that would need MAX_BAND_TRY's second pass
