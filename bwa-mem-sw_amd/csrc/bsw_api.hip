@@ -46,7 +46,9 @@ struct bsw_ref {
 
 #define MAX_CLASSES 8
 #define MAX_LANE_CLASSES 8
-#define LANE_AUTO_MIN 2048      /* BSW_KERNEL_AUTO: lane bins only pay off when they fill many waves */
+/* BSW_KERNEL_AUTO: a lane launch costs one wave's full duration (~1.3 ms for 150 bp seeds) however few seeds it
+ * holds, the wave-per-task kernel scales with the seed count; measured crossover ~22k seeds (tools/crossover.py) */
+#define LANE_AUTO_MIN 20000
 
 /* How one batch is cut into kernel launches (all offsets index the device `order` array).
  *   [wave classes][lane seeds, any order][lane left sides by qlen][lane right sides by qlen][redo list] + counter */

@@ -159,7 +159,7 @@ def test_batch_plan_bins(host):
         wave = order[seg[0]:seg[8]]
         lane = order[seg[8]:seg[9]]
         assert len(wave) + len(lane) == n and len(np.unique(np.concatenate([wave, lane]))) == n
-        if kernel == host.KERNEL_WAVE:
+        if kernel == host.KERNEL_WAVE or kernel == host.KERNEL_AUTO:     # AUTO: too few eligible seeds for a lane launch
             assert len(lane) == 0
         else:
             assert len(lane) > 2048
@@ -184,6 +184,9 @@ def test_batch_plan_bins(host):
                 tt = t["h0"].astype(np.int64) + t["lqlen"] + t["rqlen"]
                 assert ((tt <= 255) if bits == 8 else (tt > 255) | (np.maximum(t["lqlen"], t["rqlen"]) + 1 > 232)).all()
         assert seg[26] - seg[25] == len(lane)                                 # redo list space
-    # AUTO keeps small batches on the wave kernel
+    # AUTO: small batches stay on the wave kernel, big eligible ones go to the lane bins
     order, seg, words = host.plan_batch(p, tasks[:500], kernel=host.KERNEL_AUTO)
     assert seg[9] - seg[8] == 0
+    big, abig = host.synth_tasks(host.LANE_AUTO_MIN + 5000, seed=2)
+    order, seg, words = host.plan_batch(p, big, kernel=host.KERNEL_AUTO, pack_threads=4)
+    assert seg[9] - seg[8] == len(big) and seg[8] == 0
