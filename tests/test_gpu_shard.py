@@ -1,0 +1,64 @@
+"""N>1 path on a real GPU: two processes (gloo for coordination), each with its own library context, extend disjoint
+per-read shards of one task pool — no data-path collective — and the gathered result batch must equal the oracle's.
+(Both ranks use device 0 here: the box has one GPU; on an 8-GPU node each rank takes its LOCAL_RANK device.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    host = graft.load_package().host
+    tasks, arena = host.synth_tasks(n, seed=9, seed_at_start=0, seed_len_min=19, seed_len_max=60, junk_frac=0.1, n_rate=0.0005)
+    p = host.default_params()
+    mine = host.shard_indices(n, world, rank, chunk=4096)
+    ndev = torch.cuda.device_count()
+    with host.BswContext(device=rank % max(ndev, 1), kernel=host.KERNEL_LANE) as ctx:
+        res = ctx.extend_pairs(p, tasks[mine].copy())
+    cells = int(res["left"]["cells"].astype(np.int64).sum() + res["right"]["cells"].astype(np.int64).sum())
+    v = torch.tensor([float(cells), float(len(mine))], dtype=torch.float64)
+    dist.all_reduce(v)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, res.tobytes()))
+    if rank == 0:
+        orc = graft.load_oracle()
+        full = np.zeros(n, dtype=host.RESULT)
+        for idx, blob in gathered:
+            full[idx] = np.frombuffer(blob, dtype=host.RESULT)
+        ref = orc.pair_batch(p, tasks, nthreads=8)
+        q.put((full.tobytes() == ref.tobytes(), v.tolist(),
+               int(ref["left"]["cells"].astype(np.int64).sum() + ref["right"]["cells"].astype(np.int64).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_task_pool_on_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n = 40000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    same, agg, ref_cells = q.get(timeout=300)
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    assert same
+    assert int(agg[0]) == ref_cells and int(agg[1]) == n
