@@ -319,3 +319,18 @@ def test_config2_10m_mixed_bins_streaming(host, oracle):
     idx = np.arange(0, n, 997)
     want = oracle.pair_batch(p, tasks[idx].copy(), nthreads=16)
     assert_same(res[idx], want, tasks[idx])
+
+
+def test_extend_batch_large_goes_through_lane_bins(host, oracle, ctx):
+    """Batched plain ksw_extend2 above the BSW_KERNEL_AUTO threshold: served by the lane-per-extension kernel."""
+    n = host.LANE_AUTO_MIN + 4000
+    tasks, arena = host.synth_tasks(n, seed=61, seed_len_min=19, seed_len_max=50, seed_at_start=1, indel_rate=0.01)
+    et = np.zeros(n, dtype=host.EXT_TASK)
+    et["query"], et["target"], et["qlen"], et["tlen"] = tasks["rquery"], tasks["rtarget"], tasks["rqlen"], tasks["rtlen"]
+    et["w"], et["end_bonus"], et["h0"] = 100, 5, tasks["h0"]
+    for variant in (0, 1):
+        p = host.default_params(variant=variant)
+        got = ctx.extend_batch(p, et)
+        want = oracle.ext_batch(p, et, nthreads=8)
+        for f in EXTF:
+            assert (got[f] == want[f]).all(), f
