@@ -134,8 +134,8 @@ extern "C" void bsw_default_config(bsw_config *c)
     memset(c, 0, sizeof(*c));
     c->device = 0;
     c->kernel = BSW_KERNEL_AUTO;
-    c->streams = 2;
-    c->pack_threads = 4;
+    c->streams = 4;
+    c->pack_threads = 16;
     c->chunk_tasks = 65536;
 }
 
@@ -801,6 +801,63 @@ static void slots_release(std::vector<slot_t> *v)
     delete v;
 }
 
+/* One staging slot = one stream = one host thread: chunk ci is handled by slot ci % nslots (validate, pack into
+ * pinned staging, H2D, kernels, D2H, copy-out), so host packing of several chunks and the GPU work of several
+ * chunks overlap — the round-robin of the reference's four TBB/RBB pairs (batch_manager.v:418,745-773). */
+static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp, const bsw_task *tasks, size_t n,
+                       bsw_result *out, size_t k, size_t nslots, int threads, std::atomic<int> &abort_flag, std::string &err)
+{
+    bsw_ctx local;                       /* error text + kernel choice for this thread (ctx->err is not thread-safe) */
+    local.cfg = ctx->cfg;
+    auto failed = [&](int rc) { err = local.err; abort_flag = 1; return rc; };
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) { local.err = hipGetErrorString(e); return failed(BSW_E_HIP); }
+    const size_t chunk = ctx->cfg.chunk_tasks;
+    slot_t &s = (*ctx->slots)[k];
+    hipStream_t st = ctx->streams[k];
+    for (size_t base = k * chunk; base < n && !abort_flag; base += nslots * chunk) {
+        const size_t cnt = std::min(chunk, n - base);
+        size_t words = 0;
+        for (size_t i = base; i < base + cnt; ++i) {
+            const bsw_task &t = tasks[i];
+            if (t.lqlen < 0 || t.rqlen < 0 || t.ltlen < 0 || t.rtlen < 0) { fail(&local, BSW_E_INVAL, "task %zu: negative length", i); return failed(BSW_E_INVAL); }
+            words += (t.lqlen ? nwords(t.lqlen) + nwords(t.ltlen) : 0) + (t.rqlen ? nwords(t.rqlen) + nwords(t.rtlen) : 0);
+        }
+        if (s.seq_cap < words + 1) {
+            if (s.h_seq) (void)hipHostFree(s.h_seq);
+            if (s.d_seq) (void)hipFree(s.d_seq);
+            s.h_seq = nullptr; s.d_seq = nullptr;
+            s.seq_cap = (words + 1) * 5 / 4;
+            if ((e = hipHostMalloc((void **)&s.h_seq, s.seq_cap * 8, hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&s.d_seq, s.seq_cap * 8)) != hipSuccess) { s.seq_cap = 0; fail(&local, BSW_E_NOMEM, "staging: %s", hipGetErrorString(e)); return failed(BSW_E_NOMEM); }
+        }
+        if (s.task_cap < cnt) {
+            if (s.h_tasks) { (void)hipHostFree(s.h_tasks); (void)hipFree(s.d_tasks); (void)hipHostFree(s.h_order); (void)hipFree(s.d_order); (void)hipHostFree(s.h_out); (void)hipFree(s.d_out); }
+            s.h_tasks = nullptr; s.d_tasks = nullptr; s.h_order = nullptr; s.d_order = nullptr; s.h_out = nullptr; s.d_out = nullptr;
+            s.task_cap = std::max(cnt, chunk);
+            if ((e = hipHostMalloc((void **)&s.h_tasks, s.task_cap * sizeof(bsw_dtask), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&s.d_tasks, s.task_cap * sizeof(bsw_dtask))) != hipSuccess ||
+                (e = hipHostMalloc((void **)&s.h_order, order_capacity(s.task_cap) * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&s.d_order, order_capacity(s.task_cap) * sizeof(uint32_t))) != hipSuccess ||
+                (e = hipHostMalloc((void **)&s.h_out, s.task_cap * sizeof(bsw_result), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&s.d_out, s.task_cap * sizeof(bsw_result))) != hipSuccess) { s.task_cap = 0; fail(&local, BSW_E_NOMEM, "staging: %s", hipGetErrorString(e)); return failed(BSW_E_NOMEM); }
+        }
+        packed_host ph;
+        size_t w2 = 0;
+        int rc = pack_tasks(&local, &p, tasks + base, cnt, threads, s.h_seq, s.seq_cap, ph, s.h_tasks, s.h_order, &w2);
+        if (rc) return failed(rc);
+        if ((e = hipMemcpyAsync(s.d_seq, s.h_seq, w2 * 8, hipMemcpyHostToDevice, st)) != hipSuccess ||
+            (e = hipMemcpyAsync(s.d_tasks, s.h_tasks, cnt * sizeof(bsw_dtask), hipMemcpyHostToDevice, st)) != hipSuccess ||
+            (e = hipMemcpyAsync(s.d_order, s.h_order, ((size_t)ph.plan.order_len + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) { fail(&local, BSW_E_HIP, "H2D: %s", hipGetErrorString(e)); return failed(BSW_E_HIP); }
+        rc = enqueue_batch(&local, dp, p.variant, s.d_seq, s.d_tasks, s.d_order, ph.plan, s.d_out, st, nullptr);
+        if (rc) return failed(rc);
+        if ((e = hipMemcpyAsync(s.h_out, s.d_out, cnt * sizeof(bsw_result), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+            (e = hipStreamSynchronize(st)) != hipSuccess) { fail(&local, BSW_E_HIP, "D2H: %s", hipGetErrorString(e)); return failed(BSW_E_HIP); }
+        memcpy(out + base, s.h_out, cnt * sizeof(bsw_result));
+    }
+    return BSW_OK;
+}
+
 static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, size_t n, bsw_result *out)
 {
     bsw_dparams dp;
@@ -810,64 +867,19 @@ static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, si
     const size_t chunk = ctx->cfg.chunk_tasks;
     const size_t nslots = ctx->streams.size();
     if (!ctx->slots) ctx->slots = new std::vector<slot_t>(nslots);
-    std::vector<slot_t> &slots = *ctx->slots;
-    /* on failure: drain what is in flight and mark every slot idle; the buffers stay for the next submit */
-    auto cleanup = [&]() {
-        for (size_t k = 0; k < nslots; ++k) { (void)hipStreamSynchronize(ctx->streams[k]); slots[k].busy = false; }
-    };
-    auto drain = [&](size_t k) -> int {
-        slot_t &s = slots[k];
-        if (!s.busy) return BSW_OK;
-        HIPCHK(ctx, hipStreamSynchronize(ctx->streams[k]));
-        memcpy(out + s.base, s.h_out, s.cnt * sizeof(bsw_result));
-        s.busy = false;
-        return BSW_OK;
-    };
-    size_t ci = 0;
-    for (size_t base = 0; base < n; base += chunk, ++ci) {
-        const size_t k = ci % nslots, cnt = std::min(chunk, n - base);
-        slot_t &s = slots[k];
-        hipStream_t st = ctx->streams[k];
-        if ((rc = drain(k)) != BSW_OK) { cleanup(); return rc; }
-        /* size the slot */
-        size_t words = 0;
-        for (size_t i = base; i < base + cnt; ++i) {
-            const bsw_task &t = tasks[i];
-            if (t.lqlen < 0 || t.rqlen < 0 || t.ltlen < 0 || t.rtlen < 0) { cleanup(); return fail(ctx, BSW_E_INVAL, "task %zu: negative length", i); }
-            words += (t.lqlen ? nwords(t.lqlen) + nwords(t.ltlen) : 0) + (t.rqlen ? nwords(t.rqlen) + nwords(t.rtlen) : 0);
-        }
-        hipError_t e = hipSuccess;
-        if (s.seq_cap < words + 1) {
-            if (s.h_seq) (void)hipHostFree(s.h_seq);
-            if (s.d_seq) (void)hipFree(s.d_seq);
-            s.seq_cap = (words + 1) * 5 / 4;
-            if ((e = hipHostMalloc((void **)&s.h_seq, s.seq_cap * 8, hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&s.d_seq, s.seq_cap * 8)) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_NOMEM, "staging: %s", hipGetErrorString(e)); }
-        }
-        if (s.task_cap < cnt) {
-            if (s.h_tasks) { (void)hipHostFree(s.h_tasks); (void)hipFree(s.d_tasks); (void)hipHostFree(s.h_order); (void)hipFree(s.d_order); (void)hipHostFree(s.h_out); (void)hipFree(s.d_out); }
-            s.task_cap = std::max(cnt, chunk);
-            if ((e = hipHostMalloc((void **)&s.h_tasks, s.task_cap * sizeof(bsw_dtask), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&s.d_tasks, s.task_cap * sizeof(bsw_dtask))) != hipSuccess ||
-                (e = hipHostMalloc((void **)&s.h_order, order_capacity(s.task_cap) * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&s.d_order, order_capacity(s.task_cap) * sizeof(uint32_t))) != hipSuccess ||
-                (e = hipHostMalloc((void **)&s.h_out, s.task_cap * sizeof(bsw_result), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&s.d_out, s.task_cap * sizeof(bsw_result))) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_NOMEM, "staging: %s", hipGetErrorString(e)); }
-        }
-        packed_host ph;
-        size_t w2 = 0;
-        rc = pack_tasks(ctx, &p, tasks + base, cnt, ctx->cfg.pack_threads, s.h_seq, s.seq_cap, ph, s.h_tasks, s.h_order, &w2);
-        if (rc) { cleanup(); return rc; }
-        if ((e = hipMemcpyAsync(s.d_seq, s.h_seq, w2 * 8, hipMemcpyHostToDevice, st)) != hipSuccess ||
-            (e = hipMemcpyAsync(s.d_tasks, s.h_tasks, cnt * sizeof(bsw_dtask), hipMemcpyHostToDevice, st)) != hipSuccess ||
-            (e = hipMemcpyAsync(s.d_order, s.h_order, ((size_t)ph.plan.order_len + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_HIP, "H2D: %s", hipGetErrorString(e)); }
-        rc = enqueue_batch(ctx, dp, p.variant, s.d_seq, s.d_tasks, s.d_order, ph.plan, s.d_out, st, nullptr);
-        if (rc) { cleanup(); return rc; }
-        if ((e = hipMemcpyAsync(s.h_out, s.d_out, cnt * sizeof(bsw_result), hipMemcpyDeviceToHost, st)) != hipSuccess) { cleanup(); return fail(ctx, BSW_E_HIP, "D2H: %s", hipGetErrorString(e)); }
-        s.base = base; s.cnt = cnt; s.busy = true;
-    }
-    for (size_t k = 0; k < nslots; ++k)
-        if ((rc = drain(k)) != BSW_OK) { cleanup(); return rc; }
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    const size_t nworkers = std::min(nslots, nchunks ? nchunks : 1);
+    const int threads = std::max(1, ctx->cfg.pack_threads / (int)nworkers);
+    std::atomic<int> abort_flag{0};
+    std::vector<int> rcs(nworkers, 0);
+    std::vector<std::string> errs(nworkers);
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < nworkers; ++k)
+        th.emplace_back([&, k]() { rcs[k] = slot_worker(ctx, p, dp, tasks, n, out, k, nslots, threads, abort_flag, errs[k]); });
+    rcs[0] = slot_worker(ctx, p, dp, tasks, n, out, 0, nslots, threads, abort_flag, errs[0]);
+    for (auto &t : th) t.join();
+    for (size_t k = 0; k < nworkers; ++k)
+        if (rcs[k]) { ctx->err = errs[k]; return rcs[k]; }
     return BSW_OK;
 }
 

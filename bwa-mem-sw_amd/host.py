@@ -234,8 +234,10 @@ class BswContext:
         self.close()
 
     # streaming path: host buffers in, host buffers out
-    def submit(self, params, tasks):
-        out = np.zeros(len(tasks), dtype=RESULT)
+    def submit(self, params, tasks, out=None):
+        if out is None:
+            out = np.zeros(len(tasks), dtype=RESULT)
+        assert out.dtype == RESULT and len(out) >= len(tasks)
         self._keep = (params, tasks, out)
         self._chk(lib().bsw_submit(self.handle, params.ctypes.data, tasks.ctypes.data, len(tasks), out.ctypes.data), "bsw_submit")
         return out
@@ -244,10 +246,11 @@ class BswContext:
         self._chk(lib().bsw_wait(self.handle), "bsw_wait")
         self._keep = None
 
-    def extend_pairs(self, params, tasks):
-        out = self.submit(params, tasks)
+    def extend_pairs(self, params, tasks, out=None):
+        """Streaming path, synchronous.  Pass a reused `out` array to keep page faults of a fresh one out of timings."""
+        out = self.submit(params, tasks, out)
         self.wait()
-        return out
+        return out[:len(tasks)]
 
     def extend_batch(self, params, etasks):
         out = np.zeros(len(etasks), dtype=EXT)

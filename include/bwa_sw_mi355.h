@@ -114,8 +114,8 @@ typedef struct bsw_ext_task {
 typedef struct bsw_config {
     int32_t device;         /* HIP device ordinal                                */
     int32_t kernel;         /* BSW_KERNEL_*                                      */
-    int32_t streams;        /* copy/compute streams for bsw_submit (>=1, def 2)  */
-    int32_t pack_threads;   /* host packer threads (def 4)                       */
+    int32_t streams;        /* staging slots = streams = pipeline threads of bsw_submit (1..8, def 4) */
+    int32_t pack_threads;   /* host packer threads, shared by the slots (def 16)  */
     size_t  chunk_tasks;    /* tasks per H2D/launch chunk in bsw_submit (def 64Ki) */
 } bsw_config;
 

@@ -10,11 +10,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 p = host.default_params()
 tasks, arena = host.synth_tasks(n, seed=1000)
 out = []
-for streams, chunk, threads in ((2, 65536, 4), (3, 65536, 8), (4, 131072, 16), (4, 32768, 16)):
+for streams, chunk, threads in ((1, 65536, 8), (2, 65536, 8), (4, 65536, 8), (4, 65536, 16), (8, 32768, 16), (4, 131072, 16)):
     with host.BswContext(device=0, streams=streams, chunk_tasks=chunk, pack_threads=threads) as ctx:
-        ctx.extend_pairs(p, tasks[:chunk])          # warm up (allocations, code load)
+        buf = np.ones(n, dtype=host.RESULT)         # result buffer owned and already touched by the host, as in a C caller
+        ctx.extend_pairs(p, tasks, out=buf)         # warm up (staging allocations, code load)
         t0 = time.perf_counter()
-        res = ctx.extend_pairs(p, tasks)
+        res = ctx.extend_pairs(p, tasks, out=buf)
         dt = time.perf_counter() - t0
     cells = int(res["left"]["cells"].astype(np.int64).sum() + res["right"]["cells"].astype(np.int64).sum())
     out.append(dict(streams=streams, chunk_tasks=chunk, pack_threads=threads, seconds=round(dt, 4),
