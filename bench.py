@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="seeds timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(affinity, 16): the 1-GPU box's CPU share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 250 bp and mixed-bin side measurements (N=1 only, outside the timed region)")
     ap.add_argument("--check", type=int, default=2048, help="seeds spot-checked against the oracle after timing")
     ap.add_argument("--spec", action="append", default=[], help="override a generator field, e.g. --spec n_rate=0 (experiments)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -194,6 +195,26 @@ def main():
             nchk = min(args.check, ns)
             out["parity_spot_check"] = {"seeds": nchk, "bit_exact": bool(res[:nchk].tobytes() == ref[:nchk].tobytes())}
     batch.free()
+    if out is not None and world == 1 and not args.no_extra and not args.spec:
+        # BASELINE.json also asks for 250 bp batches; reported beside the headline, never part of `value`
+        extra = {}
+        for wl in ("250bp_w500", "150bp_w100_mixed_bins"):
+            if wl == args.workload:
+                continue
+            sp2 = dict(WORKLOADS[wl])
+            p2 = host.default_params(variant=args.variant, zdrop=args.zdrop, w=sp2["w"])
+            t2, a2 = host.synth_tasks(args.tasks, seed=2000, **sp2)
+            b2 = ctx.upload(p2, t2)
+            ctx.run(b2); ctx.sync(); ctx.run_history()
+            for _ in range(3):
+                ctx.run(b2)
+            ctx.sync()
+            ms = float(np.mean(ctx.run_history()))
+            r2 = ctx.download(b2)
+            c2 = int(r2["left"]["cells"].astype(np.int64).sum() + r2["right"]["cells"].astype(np.int64).sum())
+            extra[wl] = {"gcups": round(c2 / (ms * 1e-3) / 1e9, 1), "ms_per_step": round(ms, 3), "seeds": args.tasks}
+            b2.free()
+        out["other_workloads"] = extra
     ctx.close()
     if dist is not None:
         dist.barrier()
