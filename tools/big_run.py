@@ -1,5 +1,6 @@
 import sys, time, numpy as np
-sys.path.insert(0,'/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 host=g.load_package().host; orc=g.load_oracle()
 n=int(sys.argv[1])
