@@ -207,7 +207,7 @@ class DeviceBatch:
 class BswContext:
     """One GPU context = one of the reference's PE arrays behind its batch manager."""
 
-    def __init__(self, device=0, kernel=KERNEL_AUTO, streams=2, pack_threads=4, chunk_tasks=65536):
+    def __init__(self, device=0, kernel=KERNEL_AUTO, streams=4, pack_threads=16, chunk_tasks=65536):
         cfg = np.zeros(1, dtype=CONFIG)
         cfg["device"], cfg["kernel"], cfg["streams"] = device, kernel, streams
         cfg["pack_threads"], cfg["chunk_tasks"] = pack_threads, chunk_tasks
