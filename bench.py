@@ -64,11 +64,11 @@ def main():
     ap.add_argument("--workload", default="150bp_w100_single_bin", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--zdrop", type=int, default=100)
-    ap.add_argument("--cpu-sample", type=int, default=100_000, help="seeds timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="seeds timed on the CPU oracle (rank 0, N=1): ~35 s of CPU work on 16 threads")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(affinity, 16): the 1-GPU box's CPU share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 250 bp and mixed-bin side measurements (N=1 only, outside the timed region)")
-    ap.add_argument("--check", type=int, default=2048, help="seeds spot-checked against the oracle after timing")
+    ap.add_argument("--check", type=int, default=100_000, help="seeds checked bit-exact against the oracle after timing")
     ap.add_argument("--spec", action="append", default=[], help="override a generator field, e.g. --spec n_rate=0 (experiments)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / timing reduction (nccl = RCCL; gloo only to rehearse N>1 on a 1-GPU box)")
@@ -182,7 +182,7 @@ def main():
             ref = orc.pair_batch(params, tasks[:ns], nthreads=ncpu)
             dcpu = time.perf_counter() - t1
             ccells = int(ref["left"]["cells"].astype(np.int64).sum() + ref["right"]["cells"].astype(np.int64).sum())
-            n1 = min(ns, 10_000)
+            n1 = min(ns, 50_000)
             t1 = time.perf_counter()
             orc.pair_batch(params, tasks[:n1], nthreads=1)
             d1 = time.perf_counter() - t1
