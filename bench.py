@@ -4,11 +4,14 @@
 A "step" = one pass of the hot path (left+right ksw_extend2 with band retry and the
 mem_chain2aln decision) over one device-resident task batch.  At N=1 the workload is
 BASELINE.json configs[1]: 1M synthetic 150 bp reads, w=100, single (qlen,tlen)=(131,257)
-bin.  For N>1 every rank owns its own batch of the same shape (weak scaling, the
-per-read task pool is sharded, no data-path collective).
+bin.  --scaling weak (default): every rank owns its own batch of that shape.  --scaling strong:
+ONE pool of --pool seeds is cut into chunks, chunk c belongs to rank c mod N (the per-read task
+shard of SURVEY.md §8e); no data-path collective either way.
 
 Prints ONE JSON line on rank 0.  `value` = DP cells actually evaluated (exactly as the CPU
 algorithm iterates them) / wall time / 1e9, summed over ranks, inputs already in HBM.
+`e2e` = the same batch pushed through bsw_submit (host buffers in, host buffers out: DMA out of
+registered host memory, packing and binning on the GPU) — PCIe-inclusive, never `value`.
 """
 import argparse
 import json
@@ -35,24 +38,29 @@ WORKLOADS = {
 }
 
 VALU_OPS_PER_CELL = 15          # integer VALU ops of one DP cell
-# int32 VALU roof: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s.  (A wave64 integer
-# VALU op holds its SIMD for 4 cycles: measured, SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles in
-# profiles/r1/*_pmc_summary.json; the 157 TFLOP/s fp32 figure counts packed FMA.)
-PEAK_INT32_TOPS = 256 * 64 * 2.4e9 / 1e12
+# The binding roof is VALU issue (integer max/add DP: ~0.02 B per cell, nothing is a contraction).
+# Peak from MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector = 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
+# (a wave64 op at the full rate holds its SIMD for 2 cycles).  The opcodes a DP cell needs (v_max*, VOP3, SDWA, packed
+# VOP3P) issue at half that rate on gfx950 (measured: profiles/r1/ubench_*, profiles/r2/ubench3.txt), which is what
+# `peak_opcode_weighted` prices.
+PEAK_VALU_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # rocprofv3 --pmc summary of this same command
 
 
-def pmc_traffic(workload, tasks):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE in KiB;
-    gfx950 correction of MI355X_MICROARCH.md §HBM: FETCH_SIZE x 2), or None if no matching profile."""
+def pmc_summary(workload, tasks):
+    """Counters of the committed rocprofv3 PMC passes of this same command (profiles/pmc_latest.json), or {}."""
     try:
         j = json.load(open(PMC_FILE))
         if j.get("workload") != workload or j.get("seeds_per_gpu") != tasks:
-            return None
-        return int((2 * j["FETCH_SIZE_KiB"] + j["WRITE_SIZE_KiB"]) * 1024)
+            return {}
+        return j
     except Exception:
-        return None
+        return {}
+
+
+def cells_of(res):
+    return int(res["left"]["cells"].astype(np.int64).sum() + res["right"]["cells"].astype(np.int64).sum())
 
 
 def main():
@@ -60,14 +68,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tasks", type=int, default=1_000_000, help="seeds per GPU per step")
+    ap.add_argument("--tasks", type=int, default=1_000_000, help="seeds per GPU per step (weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--pool", type=int, default=8_000_000, help="--scaling strong: seeds in the one pool all ranks share")
     ap.add_argument("--workload", default="150bp_w100_single_bin", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--zdrop", type=int, default=100)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="seeds timed on the CPU oracle (rank 0, N=1): ~35 s of CPU work on 16 threads")
+    ap.add_argument("--cpu-sample", type=int, default=250_000, help="seeds timed on the CPU oracle (rank 0, N=1): 3 runs of ~9 s on 16 threads")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(affinity, 16): the 1-GPU box's CPU share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 250 bp and mixed-bin side measurements (N=1 only, outside the timed region)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the bsw_submit (PCIe-inclusive) measurement")
+    ap.add_argument("--e2e-reps", type=int, default=3)
     ap.add_argument("--check", type=int, default=100_000, help="seeds checked bit-exact against the oracle after timing")
     ap.add_argument("--spec", action="append", default=[], help="override a generator field, e.g. --spec n_rate=0 (experiments)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -102,7 +114,31 @@ def main():
         key, val = kv.split("=")
         spec[key] = type(spec[key])(float(val))
     params = host.default_params(variant=args.variant, zdrop=args.zdrop, w=spec["w"])
-    tasks, arena = host.synth_tasks(args.tasks, seed=1000 + rank, **spec)
+
+    # ---- this rank's seeds, generated straight into pinned (DMA-able) host memory ----
+    chunk = 65536
+    if args.scaling == "strong":
+        nchunks = (args.pool + chunk - 1) // chunk
+        mine = [c for c in range(nchunks) if c % world == rank]             # chunk c -> rank c mod N
+        sizes = [min(chunk, args.pool - c * chunk) for c in mine]
+        n_local = int(sum(sizes))
+    else:
+        mine, sizes, n_local = None, None, args.tasks
+    bound = (sum(host.synth_arena_bound(sz, **spec) for sz in sizes) if sizes else host.synth_arena_bound(max(n_local, 1), **spec)) + 4096
+    harena = host.HostArena(bound)
+    hout = host.HostArena(max(n_local, 1) * host.RESULT.itemsize)
+    if args.scaling == "strong":
+        tasks = np.zeros(n_local, dtype=host.TASK)
+        off = k = 0
+        for c, sz in zip(mine, sizes):                                      # every chunk has its own generator seed
+            t, _ = host.synth_tasks(sz, arena=harena.u8[off:], seed=5000 + c, **spec)
+            t["tag"] = np.arange(c * chunk, c * chunk + sz, dtype=np.uint32)
+            tasks[k:k + sz] = t
+            k += sz
+            off += host.synth_arena_bound(sz, **spec)
+    else:
+        tasks, _ = host.synth_tasks(n_local, arena=harena.u8, seed=1000 + rank, **spec)
+    out_buf = hout.view(host.RESULT, max(n_local, 1))[:n_local]
 
     ctx = host.BswContext(device=local_rank, kernel=args.kernel)
     batch = ctx.upload(params, tasks)            # inputs resident in HBM before the timed region
@@ -128,74 +164,112 @@ def main():
 
     res = ctx.download(batch)
     info = batch.info()
-    cells = int(res["left"]["cells"].astype(np.int64).sum() + res["right"]["cells"].astype(np.int64).sum())
+    batch.free()
+    cells = cells_of(res)
     ext_calls = int((tasks["lqlen"] > 0).sum() + (tasks["rqlen"] > 0).sum()
                     + (res["left"]["aw"] > spec["w"]).sum() + (res["right"]["aw"] > spec["w"]).sum())
     nominal = int((tasks["lqlen"].astype(np.int64) * tasks["ltlen"]).sum() + (tasks["rqlen"].astype(np.int64) * tasks["rtlen"]).sum())
 
+    # ---- the same seeds through bsw_submit: host buffers in (registered arena), host buffers out ----
+    e2e_dt = None
+    if not args.no_e2e:
+        sctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=4, pack_threads=4, chunk_tasks=chunk)
+        sctx.extend_pairs(params, tasks, out=out_buf)            # warm up: staging allocations, code load
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.e2e_reps):
+            got = sctx.extend_pairs(params, tasks, out=out_buf)
+        barrier()
+        e2e_dt = (time.perf_counter() - t1) / args.e2e_reps
+        e2e_same = bool(got.tobytes() == res.tobytes())
+        sctx.close()
+
     if dist is not None:
-        v = torch.tensor([dt, float(cells), float(ext_calls), float(len(tasks)), float(nominal)], dtype=torch.float64, device=red_dev)
-        tmax = v[:1].clone()
+        v = torch.tensor([dt, float(cells), float(ext_calls), float(len(tasks)), float(nominal), e2e_dt or 0.0],
+                         dtype=torch.float64, device=red_dev)
+        tmax = v[[0, 5]].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        dt_all = float(tmax.item())
-        cells_all, ext_all, tasks_all, nominal_all = (float(x) for x in v[1:].tolist())
+        dt_all, e2e_all = float(tmax[0].item()), float(tmax[1].item())
+        cells_all, ext_all, tasks_all, nominal_all = (float(x) for x in v[1:5].tolist())
     else:
-        dt_all, cells_all, ext_all, tasks_all, nominal_all = dt, float(cells), float(ext_calls), float(len(tasks)), float(nominal)
+        dt_all, e2e_all = dt, e2e_dt or 0.0
+        cells_all, ext_all, tasks_all, nominal_all = float(cells), float(ext_calls), float(len(tasks)), float(nominal)
 
     out = None
     if rank == 0:
         gcups = cells_all * args.steps / dt_all / 1e9
         kavg_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
-        alg_bytes = info["in_bytes"] + info["out_bytes"]          # per launch: packed seq + task records + results
+        alg_bytes = info["in_bytes"] + info["out_bytes"]          # per launch: packed seq + task records + order + results
+        pmc = pmc_summary(args.workload, n_local)
+        traffic = int((2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in pmc else None
+        tops = cells * VALU_OPS_PER_CELL / (kavg_ms * 1e-3) / 1e12
         out = {
             "metric": "GCUPS (seed-extension DP cells/s, 150 bp PE)", "value": round(gcups, 3), "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt_all / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": args.workload, "seeds_per_gpu": args.tasks, "read_len": spec["read_len"],
+            "ms_per_step": round(dt_all / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "int32 ALU on host-range-checked u8 rows (16-bit rows / int32 for wider scores)",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "seeds_per_gpu": n_local if args.scaling == "weak" else None,
+                       "pool_seeds": args.pool if args.scaling == "strong" else None, "read_len": spec["read_len"],
                        "band_w": spec["w"], "zdrop": args.zdrop, "variant": "H" if args.variant == 0 else "M",
-                       "sharding": "per-read task shard, no collective" if world > 1 else "single GPU",
+                       "sharding": "per-read task shard (chunk c -> rank c mod N), no collective" if world > 1 else "single GPU",
                        "kernel_launches_per_step": info["launches"]},
             "extensions_per_s": round(ext_all * args.steps / dt_all, 1),
             "seeds_per_s": round(tasks_all * args.steps / dt_all, 1),
             "cells_per_step": cells_all,
             "nominal_gcups_qlen_x_tlen": round(nominal_all * args.steps / dt_all / 1e9, 3),
             "roofline": {
+                "bound": "valu", "ops_per_cell": VALU_OPS_PER_CELL,
+                "achieved": round(tops, 4), "peak": round(PEAK_VALU_TOPS, 2), "unit": "T lane-ops/s",
+                "frac": round(tops / PEAK_VALU_TOPS, 5),
+                "peak_opcode_weighted": pmc.get("peak_opcode_weighted_tops"),
+                "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"),
+                "traffic": traffic, "traffic_kernels": pmc.get("traffic_kernels"),
+                "kernel_ms_avg": round(kavg_ms, 4),
+                "note": "integer max/add DP at ~0.02 B/cell: VALU issue binds, not HBM and not MFMA; see roofline_hbm",
+            },
+            "roofline_hbm": {
                 "bound": "hbm", "achieved": round(alg_bytes / (kavg_ms * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": round(alg_bytes / (kavg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
-                "traffic": pmc_traffic(args.workload, args.tasks),
-                "kernel_ms_avg": round(kavg_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "integer max/add DP at ~0.02 B/cell: neither HBM nor MFMA binds; see roofline_valu",
-            },
-            "roofline_valu": {
-                "bound": "valu-int32", "ops_per_cell": VALU_OPS_PER_CELL,
-                "achieved": round(cells * VALU_OPS_PER_CELL / (kavg_ms * 1e-3) / 1e12, 4), "peak": round(PEAK_INT32_TOPS, 2),
-                "unit": "Tops/s", "frac": round(cells * VALU_OPS_PER_CELL / (kavg_ms * 1e-3) / 1e12 / PEAK_INT32_TOPS, 5),
+                "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,
             },
         }
+        if e2e_dt is not None:
+            out["e2e"] = {
+                "seeds_per_s": round(tasks_all / e2e_all, 1), "gcups": round(cells_all / e2e_all / 1e9, 1),
+                "ratio_to_hbm_resident": round((cells_all / e2e_all / 1e9) / gcups, 3),
+                "pack_threads": 4, "host_threads": "4 slot threads (validate + count), no host packing",
+                "path": "bsw_submit: registered host arena DMA'd as is, pack + bin on the GPU, results DMA'd into registered host memory",
+                "bytes_per_seed_h2d": round((harena_used(tasks) + len(tasks) * 60) / max(len(tasks), 1), 1),
+                "bit_exact_vs_resident_run": e2e_same,
+            }
         if world == 1 and not args.no_cpu_baseline:
             orc = graft.load_oracle()
             ncpu = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)
             ns = min(args.cpu_sample, len(tasks))
-            t1 = time.perf_counter()
-            ref = orc.pair_batch(params, tasks[:ns], nthreads=ncpu)
-            dcpu = time.perf_counter() - t1
-            ccells = int(ref["left"]["cells"].astype(np.int64).sum() + ref["right"]["cells"].astype(np.int64).sum())
-            n1 = min(ns, 50_000)
+            runs = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ref = orc.pair_batch(params, tasks[:ns], nthreads=ncpu)
+                runs.append(time.perf_counter() - t1)
+            dcpu = float(np.median(runs))
+            ccells = cells_of(ref)
+            n1 = min(ns, 30_000)
             t1 = time.perf_counter()
             orc.pair_batch(params, tasks[:n1], nthreads=1)
             d1 = time.perf_counter() - t1
-            c1 = int(ref["left"]["cells"][:n1].astype(np.int64).sum() + ref["right"]["cells"][:n1].astype(np.int64).sum())
+            c1 = cells_of(ref[:n1])
             out["cpu_baseline"] = {
                 "value": round(ccells / dcpu / 1e9, 4), "unit": "GCUPS", "cores": ncpu, "kind": "port",
-                "sample": "first %d seeds of the same batch, scalar C oracle (-O3 -march=x86-64-v3), %d pthreads" % (ns, ncpu),
+                "sample": "first %d seeds of the same batch, scalar C oracle (-O3 -march=x86-64-v3), %d pthreads, median of 3 runs (%s s)"
+                          % (ns, ncpu, "/".join("%.2f" % r for r in runs)),
                 "single_thread_gcups": round(c1 / d1 / 1e9, 4),
             }
             nchk = min(args.check, ns)
-            out["parity_spot_check"] = {"seeds": nchk, "bit_exact": bool(res[:nchk].tobytes() == ref[:nchk].tobytes())}
-    batch.free()
-    if out is not None and world == 1 and not args.no_extra and not args.spec:
+            out["parity_spot_check"] = {"seeds": nchk, "bit_exact": bool(res[:nchk].tobytes() == ref[:nchk].tobytes()),
+                                        "cells_gpu_eq_cpu_on_sample": bool(cells_of(res[:ns]) == ccells), "sample_seeds": ns}
+    if out is not None and world == 1 and not args.no_extra and not args.spec and args.scaling == "weak":
         # BASELINE.json also asks for 250 bp batches; reported beside the headline, never part of `value`
         extra = {}
         for wl in ("250bp_w500", "150bp_w100_mixed_bins"):
@@ -211,16 +285,34 @@ def main():
             ctx.sync()
             ms = float(np.mean(ctx.run_history()))
             r2 = ctx.download(b2)
-            c2 = int(r2["left"]["cells"].astype(np.int64).sum() + r2["right"]["cells"].astype(np.int64).sum())
-            extra[wl] = {"gcups": round(c2 / (ms * 1e-3) / 1e9, 1), "ms_per_step": round(ms, 3), "seeds": args.tasks}
+            extra[wl] = {"gcups": round(cells_of(r2) / (ms * 1e-3) / 1e9, 1), "ms_per_step": round(ms, 3), "seeds": args.tasks}
             b2.free()
         out["other_workloads"] = extra
+        if not args.no_e2e:
+            # the same submit path when the caller's memory is NOT registered: host threads gather into pinned staging
+            t3, a3 = host.synth_tasks(args.tasks, seed=1000, **spec)
+            with host.BswContext(device=local_rank, kernel=args.kernel, streams=4, pack_threads=4, chunk_tasks=chunk) as c3:
+                o3 = np.ones(len(t3), dtype=host.RESULT)
+                c3.extend_pairs(params, t3, out=o3)
+                t1 = time.perf_counter()
+                r3 = c3.extend_pairs(params, t3, out=o3)
+                d3 = time.perf_counter() - t1
+            out["e2e_unregistered_memory"] = {"seeds_per_s": round(len(t3) / d3, 1), "gcups": round(cells_of(r3) / d3 / 1e9, 1),
+                                              "pack_threads": 4, "path": "bsw_submit: pageable host memory, 4 threads gather into pinned staging"}
     ctx.close()
+    harena.free()
+    hout.free()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def harena_used(tasks):
+    """bytes of byte-per-base sequence the tasks reference (what one submit moves over PCIe besides the records)"""
+    return int(tasks["lqlen"].astype(np.int64).sum() + tasks["ltlen"].astype(np.int64)[tasks["lqlen"] > 0].sum()
+               + tasks["rqlen"].astype(np.int64).sum() + tasks["rtlen"].astype(np.int64)[tasks["rqlen"] > 0].sum())
 
 
 if __name__ == "__main__":

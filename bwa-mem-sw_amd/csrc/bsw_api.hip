@@ -3,9 +3,10 @@
  *
  * Plays the role of the reference's batch_manager.v + tbb.v + rbb.v (CSR/DSM handshake,
  * 256 KiB task batches in, 16 KiB result batches out, round-robin over 4 PE arrays:
- * batch_manager.v:358-739) on top of the HIP runtime: tasks are binned by the number of
- * eh[] columns a lane must hold, packed 16 bases per uint64 into pinned staging, streamed
- * with hipMemcpyAsync on several streams, and the kernels write results in task order.
+ * batch_manager.v:358-739) on top of the HIP runtime.  The host only validates lengths, counts
+ * seeds per kernel class and starts DMAs; packing (byte-per-base -> 16 bases per uint64) and
+ * binning (the (qlen, tlen, band) bins of BASELINE.json) run on the GPU (bsw_stage_kernel.hip),
+ * chunk k of a submit goes to device k mod n_devices, and the kernels write results in task order.
  * There is no CPU compute path here: every DP cell is evaluated by the HIP kernels.
  */
 #include <hip/hip_runtime.h>
@@ -13,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -23,96 +25,256 @@
 #include <vector>
 
 #include "bsw_device.h"
-
-namespace bsw {
-int wave_class_count();
-int wave_class_cols(int cls);
-hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
-                       const uint32_t *order, uint32_t n, const uint32_t *n_dev, bsw_result *out, hipStream_t s);
-int lane_class_count();
-int lane_class_cols(int cls);
-int lane_class_bits(int cls);
-hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
-                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
-hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
-                           bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, hipStream_t s);
-hipError_t launch_fetch(const uint8_t *pac, int64_t l_pac, const bsw_fetch_desc *desc, uint32_t nd, uint64_t *seq, hipStream_t s);
-}  // namespace bsw
+#include "bsw_stage.h"
 
 struct bsw_ref {
     uint8_t *d_pac = nullptr;
     int64_t l_pac = 0;
+    int device = 0;
 };
 
-#define MAX_CLASSES 8
-#define MAX_LANE_CLASSES 8
 /* BSW_KERNEL_AUTO: a lane launch costs one wave's full duration (~1.3 ms for 150 bp seeds) however few seeds it
  * holds, the wave-per-task kernel scales with the seed count; measured crossover ~22k seeds (tools/crossover.py) */
 #define LANE_AUTO_MIN 20000
+#define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
 
 /* How one batch is cut into kernel launches (all offsets index the device `order` array).
  *   [wave classes][lane seeds, any order][lane left sides by qlen][lane right sides by qlen][redo list] + counter */
 struct batch_plan {
-    uint32_t wave_start[MAX_CLASSES + 1] = {0};
+    uint32_t wave_start[BSW_MAX_WAVE_CLASSES + 1] = {0};
     uint32_t lane_all_off = 0, lane_all_cnt = 0;
-    uint32_t laneL_off[MAX_LANE_CLASSES + 1] = {0}, laneR_off[MAX_LANE_CLASSES + 1] = {0};
+    uint32_t laneL_off[BSW_MAX_LANE_CLASSES + 1] = {0}, laneR_off[BSW_MAX_LANE_CLASSES + 1] = {0};
     uint32_t redo_off = 0;
     uint32_t order_len = 0;          /* entries before the redo counter */
     int redo_cls = 0;
 };
 
-struct slot_t;
-static void slots_release(std::vector<slot_t> *v);
-
-struct bsw_ctx {
-    int device = 0;
-    bsw_config cfg{};
-    std::vector<hipStream_t> streams;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool timed = false;
-    /* per-run event pairs since the last bsw_run_history() call (kernel time of every bsw_run) */
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> hist;
-    size_t hist_used = 0;
-    hipEvent_t ev_last0 = nullptr, ev_last1 = nullptr;
-    std::string err;
-    /* async submit */
-    std::thread worker;
-    bool worker_active = false;
-    int worker_rc = 0;
-    std::vector<struct slot_t> *slots = nullptr;    /* pinned + device staging, kept across submits */
+/* error text travels with the thread that produced it; the context keeps the last one */
+struct errs {
+    std::string msg;
 };
 
-struct bsw_dev_batch {
-    uint64_t n = 0;
-    bsw_dparams P{};
-    int variant = 0;
-    uint64_t *d_seq = nullptr;
-    bsw_dtask *d_tasks = nullptr;
-    uint32_t *d_order = nullptr;
-    bsw_result *d_out = nullptr;
-    uint64_t seq_words = 0;
-    batch_plan plan;
-    uint64_t launches = 0;
-    uint64_t h2d_bytes = 0;      /* bytes the upload moved over PCIe */
-};
-
-static int fail(bsw_ctx *ctx, int code, const char *fmt, ...)
+static int fail(errs &e, int code, const char *fmt, ...)
 {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    e.msg = buf;
     return code;
 }
 
-#define HIPCHK(ctx, call)                                                                         \
+#define HIPCHK(e, call)                                                                           \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess)                                                                     \
-            return fail(ctx, BSW_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return fail(e, BSW_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+/* ---- growable buffers ------------------------------------------------------- */
+template <class T>
+struct dbuf {                         /* device */
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t need)
+    {
+        if (cap >= need) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = need + need / 4 + 16;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+template <class T>
+struct hbuf {                         /* pinned host (or plain malloc for one-shot uploads) */
+    T *p = nullptr;
+    size_t cap = 0;
+    bool pinned = true;
+    hipError_t reserve(size_t need)
+    {
+        if (cap >= need) return hipSuccess;
+        release();
+        const size_t want = need + need / 4 + 16;
+        if (pinned) {
+            hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocPortable);
+            if (e != hipSuccess) { p = nullptr; return e; }
+        } else {
+            p = (T *)malloc(want * sizeof(T));
+            if (!p) return hipErrorOutOfMemory;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) { if (pinned) (void)hipHostFree(p); else free(p); }
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+/* staging of one chunk (streaming slot) or of one resident batch */
+struct stage_t {
+    hbuf<uint8_t> h_raw;              /* gather target; unused when the caller's memory is registered */
+    hbuf<bsw_dtask> h_tasks;
+    hbuf<bsw_rawoff> h_roff;
+    hbuf<bsw_result> h_out;
+    hbuf<bsw_fetch_desc> h_desc;
+    hbuf<bsw_wireoff> h_woff;
+    dbuf<uint8_t> d_raw;
+    dbuf<uint64_t> d_seq;
+    dbuf<bsw_dtask> d_tasks;
+    dbuf<bsw_rawoff> d_roff;
+    dbuf<uint32_t> d_order, d_bins;
+    dbuf<bsw_result> d_out;
+    dbuf<bsw_fetch_desc> d_desc;
+    dbuf<bsw_wireoff> d_woff;
+    void set_pinned(bool on) { h_raw.pinned = h_tasks.pinned = h_roff.pinned = h_out.pinned = h_desc.pinned = h_woff.pinned = on; }
+    void release_host() { h_raw.release(); h_tasks.release(); h_roff.release(); h_out.release(); h_desc.release(); h_woff.release(); }
+    void release_transient_dev() { d_raw.release(); d_roff.release(); d_bins.release(); d_desc.release(); d_woff.release(); }
+    void release()
+    {
+        release_host();
+        release_transient_dev();
+        d_seq.release(); d_tasks.release(); d_order.release(); d_out.release();
+    }
+};
+
+struct dev_state {
+    int device = 0;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> events;   /* one per stream, for the watchdog */
+    std::vector<stage_t> slots;
+};
+
+struct refbatch_req {
+    const uint32_t *in;
+    uint32_t *out;
+};
+
+struct bsw_ctx {
+    bsw_config cfg{};
+    std::vector<dev_state> devs;
+    std::atomic<bool> dead{false};    /* a wait for the GPU timed out: every later call fails fast */
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    /* per-run event pairs since the last bsw_run_history() call (kernel time of every bsw_run) */
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> hist;
+    size_t hist_used = 0;
+    hipEvent_t ev_last0 = nullptr, ev_last1 = nullptr;
+    errs err;
+    /* async submit */
+    std::thread worker;
+    bool worker_active = false;
+    int worker_rc = 0;
+    /* small synchronous batches (bsw_extend_batch, scalar ABI, wire format) */
+    stage_t small;
+    std::vector<refbatch_req> ref_queue;
+    int device0() const { return devs[0].device; }
+    hipStream_t stream0() const { return devs[0].streams[0]; }
+};
+
+struct bsw_dev_batch {
+    uint64_t n = 0;
+    bsw_dparams P{};
+    int variant = 0;
+    stage_t st;                       /* device buffers of the batch (host side released after upload) */
+    uint64_t seq_words = 0;
+    batch_plan plan;
+    uint64_t launches = 0;
+    uint64_t h2d_bytes = 0;           /* bytes the upload moved over PCIe */
+};
+
+/* ---- watchdog: never block in the runtime without a deadline (the RTL documents an
+ * inactivity timeout, bwa_mem_sw.v:84-101, but a wedged PE array leaves its busy bit set forever) ---- */
+static int sync_stream(bsw_ctx *ctx, errs &e, hipStream_t st, hipEvent_t ev)
+{
+    if (ctx->dead) return fail(e, BSW_E_HIP, "context is dead (an earlier wait for the GPU timed out)");
+    HIPCHK(e, hipEventRecord(ev, st));
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = ctx->cfg.timeout_ms > 0 ? (double)ctx->cfg.timeout_ms : 120000.0;
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return BSW_OK;
+        if (q != hipErrorNotReady) return fail(e, BSW_E_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+        if ((spins & 63u) == 63u) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > limit) {
+                ctx->dead = true;
+                return fail(e, BSW_E_HIP, "timeout: the GPU did not finish within %d ms; context marked dead", (int)limit);
+            }
+            if (ms > 2.0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        if (spins < 4096u) std::this_thread::yield();
+    }
+}
+
+/* ---- registered (DMA-able) host memory ---------------------------------------- */
+struct reg_range {
+    const uint8_t *lo;
+    size_t len;
+    bool owned;                       /* from bsw_host_alloc */
+};
+static std::mutex g_reg_mu;
+static std::vector<reg_range> g_regs;
+
+static bool is_registered(const void *p, size_t len)
+{
+    if (!p) return false;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    const uint8_t *b = (const uint8_t *)p;
+    for (const reg_range &r : g_regs)
+        if (b >= r.lo && b + len <= r.lo + r.len) return true;
+    return false;
+}
+
+extern "C" void *bsw_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_regs.push_back(reg_range{(const uint8_t *)p, bytes, true});
+    return p;
+}
+
+static int reg_remove(void *p, bool owned)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (size_t i = 0; i < g_regs.size(); ++i)
+        if (g_regs[i].lo == (const uint8_t *)p && g_regs[i].owned == owned) {
+            g_regs.erase(g_regs.begin() + (long)i);
+            return BSW_OK;
+        }
+    return BSW_E_INVAL;
+}
+
+extern "C" void bsw_host_free(void *p)
+{
+    if (!p) return;
+    if (reg_remove(p, true) == BSW_OK) (void)hipHostFree(p);
+}
+
+extern "C" int bsw_host_register(void *p, size_t bytes)
+{
+    if (!p || bytes == 0) return BSW_E_INVAL;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) return e == hipErrorNoDevice ? BSW_E_NODEVICE : BSW_E_HIP;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_regs.push_back(reg_range{(const uint8_t *)p, bytes, false});
+    return BSW_OK;
+}
+
+extern "C" int bsw_host_unregister(void *p)
+{
+    if (!p) return BSW_E_INVAL;
+    if (reg_remove(p, false) != BSW_OK) return BSW_E_INVAL;
+    return hipHostUnregister(p) == hipSuccess ? BSW_OK : BSW_E_HIP;
+}
 
 /* ------------------------------------------------------------------------- */
 extern "C" void bsw_default_params(bsw_params *p)
@@ -135,8 +297,10 @@ extern "C" void bsw_default_config(bsw_config *c)
     c->device = 0;
     c->kernel = BSW_KERNEL_AUTO;
     c->streams = 4;
-    c->pack_threads = 16;
+    c->pack_threads = 4;
     c->chunk_tasks = 65536;
+    c->n_devices = 0;
+    c->timeout_ms = 120000;
 }
 
 extern "C" int bsw_device_count(void)
@@ -151,7 +315,28 @@ extern "C" int bsw_device_count(void)
     return ok;
 }
 
-extern "C" const char *bsw_last_error(const bsw_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+extern "C" const char *bsw_last_error(const bsw_ctx *ctx) { return ctx ? ctx->err.msg.c_str() : "null ctx"; }
+
+static void ctx_release(bsw_ctx *ctx)
+{
+    const bool dead = ctx->dead;
+    for (auto &d : ctx->devs) {
+        (void)hipSetDevice(d.device);
+        if (!dead) {
+            for (auto s : d.streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+            for (auto ev : d.events) (void)hipEventDestroy(ev);
+            for (auto &sl : d.slots) sl.release();
+        }
+    }
+    if (!ctx->devs.empty()) (void)hipSetDevice(ctx->device0());
+    if (!dead) {
+        if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+        if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+        for (auto &pr : ctx->hist) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        ctx->small.release();
+    }
+    delete ctx;
+}
 
 extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
 {
@@ -163,26 +348,45 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
     if (c.streams > 8) c.streams = 8;
     if (c.pack_threads < 1) c.pack_threads = 1;
     if (c.chunk_tasks == 0) c.chunk_tasks = 65536;
+    if (c.timeout_ms <= 0) c.timeout_ms = 120000;
+    if (const char *t = getenv("BSW_TIMEOUT_MS")) { if (atoi(t) > 0) c.timeout_ms = atoi(t); }
+    if (c.n_devices < 0 || c.n_devices > BSW_MAX_DEVICES) return BSW_E_INVAL;
+    if (c.n_devices == 0) { c.n_devices = 1; c.devices[0] = c.device; }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         fprintf(stderr, "libbwasw_mi355: no HIP device visible — this library has no CPU path\n");
         return BSW_E_NODEVICE;
     }
-    if (c.device < 0 || c.device >= n) return BSW_E_INVAL;
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, c.device) != hipSuccess) return BSW_E_HIP;
-    if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) {
-        fprintf(stderr, "libbwasw_mi355: device %d is %s, kernels are built for gfx950 only\n", c.device, pr.gcnArchName);
-        return BSW_E_NODEVICE;
+    for (int k = 0; k < c.n_devices; ++k) {
+        const int dv = c.devices[k];
+        if (dv < 0 || dv >= n) return BSW_E_INVAL;
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dv) != hipSuccess) return BSW_E_HIP;
+        if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) {
+            fprintf(stderr, "libbwasw_mi355: device %d is %s, kernels are built for gfx950 only\n", dv, pr.gcnArchName);
+            return BSW_E_NODEVICE;
+        }
     }
+    c.device = c.devices[0];
     bsw_ctx *ctx = new bsw_ctx();
-    ctx->device = c.device;
     ctx->cfg = c;
-    if (hipSetDevice(c.device) != hipSuccess) { delete ctx; return BSW_E_HIP; }
-    ctx->streams.resize((size_t)c.streams);
-    for (auto &s : ctx->streams)
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BSW_E_HIP; }
-    if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) { delete ctx; return BSW_E_HIP; }
+    ctx->devs.resize((size_t)c.n_devices);
+    for (int k = 0; k < c.n_devices; ++k) {
+        dev_state &d = ctx->devs[(size_t)k];
+        d.device = c.devices[k];
+        if (hipSetDevice(d.device) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
+        d.slots.resize((size_t)c.streams);
+        for (int s = 0; s < c.streams; ++s) {
+            hipStream_t st = nullptr;
+            hipEvent_t ev = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
+            d.streams.push_back(st);
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
+            d.events.push_back(ev);
+        }
+    }
+    if (hipSetDevice(ctx->device0()) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
     *out = ctx;
     return BSW_OK;
 }
@@ -191,24 +395,18 @@ extern "C" void bsw_destroy(bsw_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->worker_active && ctx->worker.joinable()) ctx->worker.join();
-    (void)hipSetDevice(ctx->device);
-    for (auto s : ctx->streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
-    for (auto &pr : ctx->hist) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    slots_release(ctx->slots);
-    delete ctx;
+    ctx_release(ctx);
 }
 
-/* ---- validation + packing -------------------------------------------------- */
-static int check_params(bsw_ctx *ctx, const bsw_params *p, bsw_dparams *dp)
+/* ---- validation ---------------------------------------------------------------- */
+static int check_params(errs &e, const bsw_params *p, bsw_dparams *dp)
 {
-    if (!p) return fail(ctx, BSW_E_INVAL, "params is NULL");
+    if (!p) return fail(e, BSW_E_INVAL, "params is NULL");
     if (p->e_del < 1 || p->e_ins < 1 || p->o_del < 0 || p->o_ins < 0)
-        return fail(ctx, BSW_E_INVAL, "need e_del,e_ins >= 1 and o_del,o_ins >= 0");
-    if (p->w < 0 || p->w > (1 << 20) || p->max_band_try > 8) return fail(ctx, BSW_E_INVAL, "band out of range");
-    if (p->variant != BSW_VARIANT_H && p->variant != BSW_VARIANT_M) return fail(ctx, BSW_E_INVAL, "bad variant");
-    if (p->o_del + p->e_del > 4096 || p->o_ins + p->e_ins > 4096) return fail(ctx, BSW_E_LIMIT, "gap penalties too large");
+        return fail(e, BSW_E_INVAL, "need e_del,e_ins >= 1 and o_del,o_ins >= 0");
+    if (p->w < 0 || p->w > (1 << 20) || p->max_band_try > 8) return fail(e, BSW_E_INVAL, "band out of range");
+    if (p->variant != BSW_VARIANT_H && p->variant != BSW_VARIANT_M) return fail(e, BSW_E_INVAL, "bad variant");
+    if (p->o_del + p->e_del > 4096 || p->o_ins + p->e_ins > 4096) return fail(e, BSW_E_LIMIT, "gap penalties too large");
     memset(dp, 0, sizeof(*dp));
     memcpy(dp->mat, p->mat, 25);
     dp->o_del = p->o_del; dp->e_del = p->e_del; dp->o_ins = p->o_ins; dp->e_ins = p->e_ins;
@@ -238,7 +436,7 @@ static inline int gap_limit(const bsw_params *p, int mx, int qlen, int end_bonus
 
 static inline size_t nwords(int len) { return (size_t)((len + 15) >> 4); }
 
-/* 8 base bytes (codes 0..4) -> 8 nibbles in the low 32 bits */
+/* ---- bsw_pack_bases: the device sequence format, on the host (tools and tests; the batch path packs on the GPU) ---- */
 static inline uint64_t squeeze8(uint64_t x)
 {
     x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
@@ -247,9 +445,9 @@ static inline uint64_t squeeze8(uint64_t x)
     return x;
 }
 
-/* byte-per-base -> 16 bases per uint64; returns non-zero when the sequence holds an N (code >= 4) */
-static unsigned pack_seq(const uint8_t *s, int len, uint64_t *dst)
+extern "C" int bsw_pack_bases(const uint8_t *s, int len, uint64_t *dst)
 {
+    if (len < 0 || (len > 0 && (!s || !dst))) return BSW_E_INVAL;
     const int full = len >> 4;
     uint64_t any = 0;
     for (int w = 0; w < full; ++w) {
@@ -285,12 +483,6 @@ static unsigned pack_seq(const uint8_t *s, int len, uint64_t *dst)
     return any != 0;
 }
 
-extern "C" int bsw_pack_bases(const uint8_t *bases, int len, uint64_t *words)
-{
-    if (len < 0 || (len > 0 && (!bases || !words))) return BSW_E_INVAL;
-    return (int)pack_seq(bases, len, words);
-}
-
 /* lane kernel needs a bwa-style matrix (bwa_fill_scmat): a on the diagonal, one mismatch score off it,
  * one score for every pair that involves an N */
 static bool lane_matrix_ok(const bsw_params *p)
@@ -303,305 +495,397 @@ static bool lane_matrix_ok(const bsw_params *p)
     return true;
 }
 
-struct packed_host {
-    std::vector<uint64_t> seq;
-    std::vector<bsw_dtask> tasks;
-    std::vector<uint32_t> order;
-    batch_plan plan;
-};
-
 static size_t order_capacity(size_t n) { return 4 * n + 16; }   /* upper bound of plan.order_len + 1 */
 
-static int task_class(int qmax)
+/* ---- host pass over a chunk: validate, lay out, count per class ------------------------------ */
+struct chunk_info {
+    size_t words = 0;                 /* seq words the chunk needs */
+    const uint8_t *lo = nullptr, *hi = nullptr;   /* span of every sequence the chunk references */
+    size_t sum_len = 0;               /* bytes referenced (= gather size) */
+    bool direct = false;              /* raw bytes are DMA'd straight out of registered memory */
+    batch_plan plan;
+    bsw_binparams bp;
+};
+
+static int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams &bp)
 {
-    const int nc = bsw::wave_class_count();
-    for (int c = 0; c < nc; ++c)
-        if (qmax + 1 <= bsw::wave_class_cols(c)) return c;
-    return -1;
+    memset(&bp, 0, sizeof(bp));
+    bp.a = p->mat[0];
+    bp.n_wave = bsw::wave_class_count();
+    bp.n_lane = bsw::lane_class_count();
+    if (bp.n_wave > BSW_MAX_WAVE_CLASSES || bp.n_lane > BSW_MAX_LANE_CLASSES) return fail(e, BSW_E_LIMIT, "class table too large");
+    for (int c = 0; c < bp.n_wave; ++c) bp.wave_cols[c] = bsw::wave_class_cols(c);
+    for (int c = 0; c < bp.n_lane; ++c) {
+        bp.lane_cols[c] = bsw::lane_class_cols(c);
+        bp.lane_bits[c] = bsw::lane_class_bits(c);
+        if (bp.lane_cols[c] > BSW_LANE_QBINS) return fail(e, BSW_E_LIMIT, "lane class %d has %d columns (> %d)", c, bp.lane_cols[c], BSW_LANE_QBINS);
+        if (bp.lane_bits[c] == 8) bp.cols8 = std::max(bp.cols8, bp.lane_cols[c]);
+        else bp.cols16 = std::max(bp.cols16, bp.lane_cols[c]);
+    }
+    bp.lane_on = kern != BSW_KERNEL_WAVE && lane_matrix_ok(p);
+    return BSW_OK;
 }
 
-/* validate, lay out and pack tasks[0..n) — `threads` host threads do the nibble packing —
- * then bin them: the batch manager's (qlen, tlen, w) bins of BASELINE.json.
- *   - lane bins: seeds the lane-per-task kernel can take (bwa-style matrix, no N, short query,
- *     16-bit score range), each side sorted by query length so a wave holds equal-length queries;
- *   - wave classes: everything else, by the number of eh[] columns a lane must hold. */
-static int pack_tasks(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, int threads,
-                      uint64_t *seq_dst /* may be NULL: use ph.seq */, size_t seq_cap, packed_host &ph,
-                      bsw_dtask *task_dst, uint32_t *order_dst, size_t *seq_words_out,
-                      bool dev_targets = false /* targets are fetched on the device: leave their words alone */)
+/* tasks[0..n) -> dt[0..n) (device task records), ro[0..n) (gather layout of the raw bytes), class counts -> plan */
+static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task *tasks, size_t n, bool dev_targets,
+                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci)
 {
     const int mx = mat_max(p->mat);
-    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
-    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_a = dbg ? tnow() : 0;
-    std::vector<uint64_t> off(n + 1);
-    uint64_t acc = 0;
+    int rc = fill_binparams(e, p, kern, ci.bp);
+    if (rc) return rc;
+    bsw_binparams &bp = ci.bp;
+    uint64_t acc = 0, accb = 0;
+    const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
+    uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0};
+    uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0;
+    auto span = [&](const uint8_t *s, int len) {
+        if (len > 0) { if (s < lo) lo = s; if (s + len > hi) hi = s + len; }
+    };
     for (size_t i = 0; i < n; ++i) {
         const bsw_task &t = tasks[i];
         if (t.lqlen < 0 || t.rqlen < 0 || t.ltlen < 0 || t.rtlen < 0)
-            return fail(ctx, BSW_E_INVAL, "task %zu: negative length", i);
+            return fail(e, BSW_E_INVAL, "task %zu: negative length", i);
         if (t.lqlen > BSW_MAX_QLEN || t.rqlen > BSW_MAX_QLEN || t.ltlen > BSW_MAX_TLEN || t.rtlen > BSW_MAX_TLEN)
-            return fail(ctx, BSW_E_LIMIT, "task %zu: length beyond BSW_MAX_QLEN/BSW_MAX_TLEN", i);
-        if (t.h0 <= 0) return fail(ctx, BSW_E_INVAL, "task %zu: h0 must be > 0", i);
+            return fail(e, BSW_E_LIMIT, "task %zu: length beyond BSW_MAX_QLEN/BSW_MAX_TLEN", i);
+        if (t.h0 <= 0) return fail(e, BSW_E_INVAL, "task %zu: h0 must be > 0", i);
         if ((int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * mx >= BSW_MAX_SCORE)
-            return fail(ctx, BSW_E_LIMIT, "task %zu: score range beyond BSW_MAX_SCORE", i);
+            return fail(e, BSW_E_LIMIT, "task %zu: score range beyond BSW_MAX_SCORE", i);
         if ((t.lqlen && (!t.lquery || (t.ltlen && !t.ltarget && !dev_targets))) ||
             (t.rqlen && (!t.rquery || (t.rtlen && !t.rtarget && !dev_targets))))
-            return fail(ctx, BSW_E_INVAL, "task %zu: NULL sequence pointer", i);
-        off[i] = acc;
-        acc += (t.lqlen ? nwords(t.lqlen) + nwords(t.ltlen) : 0) + (t.rqlen ? nwords(t.rqlen) + nwords(t.rtlen) : 0);
+            return fail(e, BSW_E_INVAL, "task %zu: NULL sequence pointer", i);
+        if (t.wlim_l < 0 || t.wlim_r < 0) return fail(e, BSW_E_INVAL, "task %zu: negative wlim", i);
+        bsw_dtask &d = dt[i];
+        bsw_rawoff &r = ro[i];
+        memset(&d, 0, sizeof(d));
+        memset(&r, 0, sizeof(r));
+        if (t.lqlen) {
+            d.lq_off = (uint32_t)acc; acc += nwords(t.lqlen);
+            d.lt_off = (uint32_t)acc; acc += nwords(t.ltlen);
+            r.lq = (uint32_t)accb; accb += (uint64_t)t.lqlen;
+            span(t.lquery, t.lqlen);
+            if (!dev_targets) { r.lt = (uint32_t)accb; accb += (uint64_t)t.ltlen; span(t.ltarget, t.ltlen); }
+        }
+        if (t.rqlen) {
+            d.rq_off = (uint32_t)acc; acc += nwords(t.rqlen);
+            d.rt_off = (uint32_t)acc; acc += nwords(t.rtlen);
+            r.rq = (uint32_t)accb; accb += (uint64_t)t.rqlen;
+            span(t.rquery, t.rqlen);
+            if (!dev_targets) { r.rt = (uint32_t)accb; accb += (uint64_t)t.rtlen; span(t.rtarget, t.rtlen); }
+        }
+        d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
+        d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
+        /* H5/H6: host-supplied band limits win over the library's formula (proc_element.v:925,933) */
+        d.wlim_l = (uint16_t)(t.wlim_l > 0 ? std::min(t.wlim_l, 65535) : gap_limit(p, mx, t.lqlen, p->pen_clip5));
+        d.wlim_r = (uint16_t)(t.wlim_r > 0 ? std::min(t.wlim_r, 65535) : gap_limit(p, mx, t.rqlen, p->pen_clip3));
+        d.h0 = t.h0; d.init_score = t.init_score; d.qbeg = t.qbeg; d.tag = t.tag;
+        /* class counts (the device sorts with the same functions) */
+        const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
+        const int wc = bsw_wave_class_of(&bp, qm);
+        if (wc < 0) return fail(e, BSW_E_LIMIT, "task %zu: no kernel class", i);
+        ++cw_all[wc];
+        const int bits = bsw_seed_lane_bits(&bp, t.lqlen, t.rqlen, t.h0);
+        if (!bits) ++cw[wc];
+        else {
+            ++n_lane;
+            if (t.lqlen) {
+                const int c = bsw_side_lane_class(&bp, bits, t.lqlen);
+                if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i);
+                ++cl[c];
+            }
+            if (t.rqlen) {
+                const int c = bsw_side_lane_class(&bp, bits, t.rqlen);
+                if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i);
+                ++cr[c];
+            }
+        }
     }
-    off[n] = acc;
-    if (acc >= (1ull << 32)) return fail(ctx, BSW_E_LIMIT, "batch sequence arena beyond 2^32 words; split the batch");
-    uint64_t *seq = seq_dst;
-    if (!seq) { ph.seq.assign((size_t)acc + 1, 0); seq = ph.seq.data(); }
-    else if (acc > seq_cap) return fail(ctx, BSW_E_NOMEM, "staging too small");
-    bsw_dtask *dt = task_dst;
-    if (!dt) { ph.tasks.resize(n); dt = ph.tasks.data(); }
-    uint32_t *ord = order_dst;
-    if (!ord) { ph.order.assign(order_capacity(n), 0); ord = ph.order.data(); }
+    if (acc >= (1ull << 32)) return fail(e, BSW_E_LIMIT, "batch sequence arena beyond 2^32 words; split the batch");
+    if (accb >= (1ull << 32) - RAW_SLACK) return fail(e, BSW_E_LIMIT, "batch holds more than 4 GiB of bases; split the batch");
+    if (kern == BSW_KERNEL_AUTO && n_lane < LANE_AUTO_MIN) bp.lane_on = 0;
+    if (!bp.lane_on) {
+        memcpy(cw, cw_all, sizeof(cw));
+        memset(cl, 0, sizeof(cl));
+        memset(cr, 0, sizeof(cr));
+        n_lane = 0;
+    }
+    batch_plan &pl = ci.plan;
+    pl = batch_plan();
+    for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) pl.wave_start[c + 1] = pl.wave_start[c] + cw[c];
+    uint32_t cur = pl.wave_start[BSW_MAX_WAVE_CLASSES];
+    pl.lane_all_off = cur;
+    pl.lane_all_cnt = n_lane;
+    cur += n_lane;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { pl.laneL_off[c] = cur; cur += cl[c]; }
+    pl.laneL_off[BSW_MAX_LANE_CLASSES] = cur;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { pl.laneR_off[c] = cur; cur += cr[c]; }
+    pl.laneR_off[BSW_MAX_LANE_CLASSES] = cur;
+    pl.redo_off = cur;
+    pl.order_len = cur + n_lane;
+    pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
+    memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
+    bp.lane_all_off = pl.lane_all_off;
+    memcpy(bp.laneL_off, pl.laneL_off, sizeof(bp.laneL_off));
+    memcpy(bp.laneR_off, pl.laneR_off, sizeof(bp.laneR_off));
+    ci.words = (size_t)acc;
+    ci.sum_len = (size_t)accb;
+    ci.lo = hi ? lo : nullptr;
+    ci.hi = hi;
+    /* DMA the caller's arena as it is when it is registered memory and not much larger than what it holds */
+    const size_t spanb = hi ? (size_t)(hi - lo) : 0;
+    ci.direct = spanb > 0 && spanb < (1ull << 32) - RAW_SLACK && spanb <= 2 * ci.sum_len + (1u << 20) && is_registered(lo, spanb);
+    if (ci.direct) {
+        for (size_t i = 0; i < n; ++i) {
+            const bsw_task &t = tasks[i];
+            bsw_rawoff &r = ro[i];
+            if (t.lqlen) { r.lq = (uint32_t)(t.lquery - lo); if (!dev_targets && t.ltlen) r.lt = (uint32_t)(t.ltarget - lo); }
+            if (t.rqlen) { r.rq = (uint32_t)(t.rquery - lo); if (!dev_targets && t.rtlen) r.rt = (uint32_t)(t.rtarget - lo); }
+        }
+    }
+    return BSW_OK;
+}
 
-    double t_b = dbg ? tnow() : 0;
+/* copy the sequences of tasks[0..n) into the pinned staging arena laid out by prepare_chunk */
+static void gather_raw(const bsw_task *tasks, const bsw_rawoff *ro, size_t n, bool dev_targets, uint8_t *dst, int threads)
+{
     auto work = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const bsw_task &t = tasks[i];
-            bsw_dtask &d = dt[i];
-            uint64_t o = off[i];
-            unsigned nn = 0;
-            memset(&d, 0, sizeof(d));
+            const bsw_rawoff &r = ro[i];
             if (t.lqlen) {
-                d.lq_off = (uint32_t)o; nn |= pack_seq(t.lquery, t.lqlen, seq + o); o += nwords(t.lqlen);
-                d.lt_off = (uint32_t)o; if (!dev_targets) nn |= pack_seq(t.ltarget, t.ltlen, seq + o); o += nwords(t.ltlen);
+                memcpy(dst + r.lq, t.lquery, (size_t)t.lqlen);
+                if (!dev_targets && t.ltlen) memcpy(dst + r.lt, t.ltarget, (size_t)t.ltlen);
             }
             if (t.rqlen) {
-                d.rq_off = (uint32_t)o; nn |= pack_seq(t.rquery, t.rqlen, seq + o); o += nwords(t.rqlen);
-                d.rt_off = (uint32_t)o; if (!dev_targets) nn |= pack_seq(t.rtarget, t.rtlen, seq + o); o += nwords(t.rtlen);
+                memcpy(dst + r.rq, t.rquery, (size_t)t.rqlen);
+                if (!dev_targets && t.rtlen) memcpy(dst + r.rt, t.rtarget, (size_t)t.rtlen);
             }
-            (void)nn;                               /* N-bearing seeds are fine for both kernels */
-            d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
-            d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
-            d.wlim_l = (uint16_t)gap_limit(p, mx, t.lqlen, p->pen_clip5);
-            d.wlim_r = (uint16_t)gap_limit(p, mx, t.rqlen, p->pen_clip3);
-            d.h0 = t.h0; d.init_score = t.init_score; d.qbeg = t.qbeg; d.tag = t.tag;
         }
     };
-    if (threads <= 1 || n < 4096) work(0, n);
-    else {
-        std::vector<std::thread> th;
-        const size_t per = (n + (size_t)threads - 1) / (size_t)threads;
-        for (int k = 0; k < threads; ++k) {
-            const size_t lo = per * (size_t)k, hi = std::min(n, lo + per);
-            if (lo < hi) th.emplace_back(work, lo, hi);
-        }
-        for (auto &t : th) t.join();
+    if (threads <= 1 || n < 4096) { work(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+    for (int k = 1; k < threads; ++k) {
+        const size_t lo = per * (size_t)k, hi = std::min(n, lo + per);
+        if (lo < hi) th.emplace_back(work, lo, hi);
     }
+    work(0, std::min(n, per));
+    for (auto &t : th) t.join();
+}
 
-    double t_c = dbg ? tnow() : 0;
-    /* ---- binning ---- */
-    batch_plan &pl = ph.plan;
-    pl = batch_plan();
-    const int nlc = bsw::lane_class_count();
-    int cols8 = 0, cols16 = 0;                       /* widest lane class per value width */
-    for (int c = 0; c < nlc; ++c) {
-        if (bsw::lane_class_bits(c) == 8) cols8 = std::max(cols8, bsw::lane_class_cols(c));
-        else cols16 = std::max(cols16, bsw::lane_class_cols(c));
+/* ---- device side of a chunk: DMA, pack, (fetch), bin, and optionally the DP kernels ---------- */
+static int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
+                         uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches)
+{
+    const int nc = bsw::wave_class_count();
+    for (int c = 0; c < nc; ++c) {
+        const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
+        if (!cnt) continue;
+        HIPCHK(e, bsw::launch_wave(c, variant, P, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, d_out, s));
+        if (launches) ++*launches;
     }
-    const int kern = ctx ? ctx->cfg.kernel : BSW_KERNEL_AUTO;
-    const bool lane_params = kern != BSW_KERNEL_WAVE && lane_matrix_ok(p);
-    const int a = p->mat[0];
-    std::vector<uint8_t> lane_bits(n ? n : 1, 0);    /* 0 = wave kernel, 8 / 16 = lane kernel value width */
-    uint32_t n_lane = 0;
-    if (lane_params) {
-        for (size_t i = 0; i < n; ++i) {
-            const bsw_task &t = tasks[i];
-            const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
-            const int64_t top = (int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * a;     /* no H can exceed this */
-            if (top <= 255 && qm + 1 <= cols8) lane_bits[i] = 8;
-            else if (top < 65000 && qm + 1 <= cols16) lane_bits[i] = 16;
-            if (lane_bits[i]) ++n_lane;
-        }
-        if (kern == BSW_KERNEL_AUTO && n_lane < LANE_AUTO_MIN) {
-            std::fill(lane_bits.begin(), lane_bits.end(), 0);
-            n_lane = 0;
-        }
-    }
-    auto side_class = [&](int bits, int q) {
-        for (int c = 0; c < nlc; ++c)
-            if (bsw::lane_class_bits(c) == bits && q + 1 <= bsw::lane_class_cols(c)) return c;
-        return nlc - 1;
-    };
-    /* wave classes: counting sort by columns-per-lane class */
-    uint32_t count[MAX_CLASSES] = {0};
-    std::vector<uint8_t> cls(n ? n : 1, 0);
-    for (size_t i = 0; i < n; ++i) {
-        if (lane_bits[i]) continue;
-        const bsw_task &t = tasks[i];
-        const int c = task_class(t.lqlen > t.rqlen ? t.lqlen : t.rqlen);
-        if (c < 0) return fail(ctx, BSW_E_LIMIT, "task %zu: no kernel class", i);
-        cls[i] = (uint8_t)c;
-        ++count[c];
-    }
-    uint32_t pos[MAX_CLASSES];
-    pl.wave_start[0] = 0;
-    for (int c = 0; c < MAX_CLASSES; ++c) pl.wave_start[c + 1] = pl.wave_start[c] + count[c];
-    for (int c = 0; c < MAX_CLASSES; ++c) pos[c] = pl.wave_start[c];
-    for (size_t i = 0; i < n; ++i)
-        if (!lane_bits[i]) ord[pos[cls[i]]++] = (uint32_t)i;
-    uint32_t cur = pl.wave_start[MAX_CLASSES];
-    /* lane seeds (finalize pass) */
-    pl.lane_all_off = cur;
-    pl.lane_all_cnt = n_lane;
-    for (size_t i = 0; i < n; ++i)
-        if (lane_bits[i]) ord[cur++] = (uint32_t)i;
-    /* per side: counting sort by (lane class, query length descending) so a wave holds equal-length queries */
-    for (int side = 0; side < 2; ++side) {
-        std::vector<uint32_t> hist((size_t)nlc * 256 + 1, 0);
-        auto key = [&](uint32_t ti) -> int {
-            const bsw_task &t = tasks[ti];
-            const int q = side ? t.rqlen : t.lqlen;
-            return q > 0 ? side_class(lane_bits[ti], q) * 256 + q : -1;
-        };
-        for (uint32_t k = 0; k < n_lane; ++k) {
-            const int kk = key(ord[pl.lane_all_off + k]);
-            if (kk >= 0) ++hist[(size_t)kk];
-        }
-        uint32_t *offs = side ? pl.laneR_off : pl.laneL_off;
-        std::vector<uint32_t> start((size_t)nlc * 256 + 1, 0);
-        uint32_t run = cur;
-        for (int c = 0; c < nlc; ++c) {                 /* inside a class: longest queries (most work) first */
-            offs[c] = run;
-            for (int q = 255; q >= 0; --q) {
-                start[(size_t)c * 256 + q] = run;
-                run += hist[(size_t)c * 256 + q];
+    if (pl.lane_all_cnt) {
+        uint32_t *redo_cnt = d_order + pl.order_len;
+        HIPCHK(e, hipMemsetAsync(redo_cnt, 0, sizeof(uint32_t), s));
+        const int nlc = bsw::lane_class_count();
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t *offs = side ? pl.laneR_off : pl.laneL_off;
+            for (int c = 0; c < nlc; ++c) {
+                const uint32_t cnt = offs[c + 1] - offs[c];
+                if (!cnt) continue;
+                HIPCHK(e, bsw::launch_lane(c, variant, P, side, d_seq, d_tasks, d_order + offs[c], cnt, d_out, s));
+                if (launches) ++*launches;
             }
         }
-        for (int c = nlc; c <= MAX_LANE_CLASSES; ++c) offs[c] = run;
-        for (uint32_t k = 0; k < n_lane; ++k) {
-            const uint32_t ti = ord[pl.lane_all_off + k];
-            const int kk = key(ti);
-            if (kk >= 0) ord[start[(size_t)kk]++] = ti;
-        }
-        cur = run;
+        HIPCHK(e, bsw::launch_finalize(P, d_tasks, d_order + pl.lane_all_off, pl.lane_all_cnt, d_out,
+                                       d_order + pl.redo_off, redo_cnt, s));
+        /* seeds whose first band try was not final: recompute from scratch, one wavefront each */
+        HIPCHK(e, bsw::launch_wave(pl.redo_cls, variant, P, d_seq, d_tasks, d_order + pl.redo_off, pl.lane_all_cnt,
+                                   redo_cnt, d_out, s));
+        if (launches) *launches += 2;
     }
-    pl.redo_off = cur;
-    pl.order_len = cur + n_lane;
-    pl.redo_cls = task_class(std::max(cols8, cols16) - 1);
-    if (dbg) fprintf(stderr, "[bsw] pack_tasks n=%zu: validate+alloc %.2f ms, pack %.2f ms, bin %.2f ms\n", n, t_b - t_a, t_c - t_b, tnow() - t_c);
-    if (seq_words_out) *seq_words_out = (size_t)acc;
     return BSW_OK;
+}
+
+/* the raw bytes and the task records are in st.h_* (or the caller's registered arena): move them, pack, bin */
+static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &ci, size_t n, bool dev_targets,
+                        const bsw_ref *ref, size_t n_desc, uint64_t *h2d_bytes)
+{
+    const size_t rawb = ci.direct ? (size_t)(ci.hi - ci.lo) : ci.sum_len;
+    hipError_t he;
+    if ((he = st.d_raw.reserve(rawb + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve(ci.words + 4)) != hipSuccess ||
+        (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_roff.reserve(n + 1)) != hipSuccess ||
+        (he = st.d_order.reserve(order_capacity(n))) != hipSuccess || (he = st.d_bins.reserve(BSW_BIN_WORDS)) != hipSuccess ||
+        (he = st.d_out.reserve(n + 1)) != hipSuccess || (n_desc && (he = st.d_desc.reserve(n_desc)) != hipSuccess))
+        return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    if (rawb) HIPCHK(e, hipMemcpyAsync(st.d_raw.p, ci.direct ? ci.lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s));
+    HIPCHK(e, bsw::launch_pack(st.d_raw.p, st.d_tasks.p, st.d_roff.p, (uint32_t)n, dev_targets ? 1 : 0, st.d_seq.p, s));
+    if (n_desc) {
+        HIPCHK(e, hipMemcpyAsync(st.d_desc.p, st.h_desc.p, n_desc * sizeof(bsw_fetch_desc), hipMemcpyHostToDevice, s));
+        HIPCHK(e, bsw::launch_fetch(ref->d_pac, ref->l_pac, st.d_desc.p, (uint32_t)n_desc, st.d_seq.p, s));
+    }
+    HIPCHK(e, bsw::launch_bin(ci.bp, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
+    if (h2d_bytes) *h2d_bytes = rawb + n * (sizeof(bsw_dtask) + sizeof(bsw_rawoff)) + n_desc * sizeof(bsw_fetch_desc);
+    return BSW_OK;
+}
+
+/* ---- batch plan export (host only) ---------------------------------------------------------- */
+static void plan_segments(const batch_plan &pl, uint32_t *seg)
+{
+    int k = 0;
+    for (int c = 0; c < 8; ++c) seg[k++] = pl.wave_start[c];
+    seg[k++] = pl.lane_all_off;                    /* 8 */
+    for (int c = 0; c < 8; ++c) seg[k++] = pl.laneL_off[std::min(c, BSW_MAX_LANE_CLASSES)];    /* 9..16 */
+    for (int c = 0; c < 8; ++c) seg[k++] = pl.laneR_off[std::min(c, BSW_MAX_LANE_CLASSES)];    /* 17..24 */
+    seg[k++] = pl.redo_off;                        /* 25 */
+    seg[k++] = pl.order_len;                       /* 26 */
 }
 
 extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, size_t n, int kernel, int pack_threads,
                                   uint32_t *order, uint32_t *seg)
 {
-    if (!p || (!tasks && n) || !order || !seg) return BSW_E_INVAL;
-    bsw_ctx tmp;                                   /* carries only the kernel choice; no device is touched */
-    tmp.cfg.kernel = kernel;
+    (void)pack_threads;
+    if (!p || (!tasks && n) || !seg) return BSW_E_INVAL;
+    errs e;
     bsw_dparams dp;
-    int rc = check_params(&tmp, p, &dp);
+    int rc = check_params(e, p, &dp);
     if (rc) return rc;
-    packed_host ph;
-    size_t words = 0;
-    rc = pack_tasks(&tmp, p, tasks, n, pack_threads > 0 ? pack_threads : 1, nullptr, 0, ph, nullptr, order, &words);
+    std::vector<bsw_dtask> dt(n ? n : 1);
+    std::vector<bsw_rawoff> ro(n ? n : 1);
+    chunk_info ci;
+    rc = prepare_chunk(e, p, kernel, tasks, n, false, dt.data(), ro.data(), ci);
     if (rc) return rc;
-    const batch_plan &pl = ph.plan;
-    int k = 0;
-    for (int c = 0; c < MAX_CLASSES; ++c) seg[k++] = pl.wave_start[c];
-    seg[k++] = pl.lane_all_off;                    /* 8 */
-    for (int c = 0; c < MAX_LANE_CLASSES; ++c) seg[k++] = pl.laneL_off[c];    /* 9..16 */
-    for (int c = 0; c < MAX_LANE_CLASSES; ++c) seg[k++] = pl.laneR_off[c];    /* 17..24 */
-    seg[k++] = pl.redo_off;                        /* 25 */
-    seg[k++] = pl.order_len;                       /* 26 */
-    return (int64_t)words;
+    plan_segments(ci.plan, seg);
+    if (order) {
+        /* the device's rules (bsw_bin_count/scan/scatter) replayed on the host: lists by class, lane sides by
+         * (class, query length descending); the order inside one query length is task order here, arbitrary there */
+        const bsw_binparams &bp = ci.bp;
+        std::vector<uint32_t> cur(BSW_BIN_WORDS, 0), hist(BSW_BIN_WAVE0, 0);
+        auto keys = [&](const bsw_dtask &T, int &k0, int &k1, int &k2) {
+            k1 = k2 = -1;
+            const int bits = bsw_seed_lane_bits(&bp, T.lqlen, T.rqlen, T.h0);
+            if (!bits) { k0 = BSW_BIN_WAVE0 + bsw_wave_class_of(&bp, std::max(T.lqlen, T.rqlen)); return; }
+            k0 = BSW_BIN_LANEALL;
+            if (T.lqlen) k1 = (0 * BSW_MAX_LANE_CLASSES + bsw_side_lane_class(&bp, bits, T.lqlen)) * BSW_LANE_QBINS + T.lqlen;
+            if (T.rqlen) k2 = (1 * BSW_MAX_LANE_CLASSES + bsw_side_lane_class(&bp, bits, T.rqlen)) * BSW_LANE_QBINS + T.rqlen;
+        };
+        for (size_t i = 0; i < n; ++i) {
+            int k0, k1, k2;
+            keys(dt[i], k0, k1, k2);
+            if (k1 >= 0) ++hist[(size_t)k1];
+            if (k2 >= 0) ++hist[(size_t)k2];
+        }
+        for (int side = 0; side < 2; ++side)
+            for (int c = 0; c < bp.n_lane; ++c) {
+                uint32_t run = side ? bp.laneR_off[c] : bp.laneL_off[c];
+                for (int q = BSW_LANE_QBINS - 1; q >= 0; --q) {
+                    const size_t idx = (size_t)((side * BSW_MAX_LANE_CLASSES + c) * BSW_LANE_QBINS + q);
+                    cur[idx] = run;
+                    run += hist[idx];
+                }
+            }
+        for (int c = 0; c < bp.n_wave; ++c) cur[(size_t)(BSW_BIN_WAVE0 + c)] = bp.wave_start[c];
+        cur[BSW_BIN_LANEALL] = bp.lane_all_off;
+        for (size_t i = 0; i < n; ++i) {
+            int k0, k1, k2;
+            keys(dt[i], k0, k1, k2);
+            order[cur[(size_t)k0]++] = (uint32_t)i;
+            if (k1 >= 0) order[cur[(size_t)k1]++] = (uint32_t)i;
+            if (k2 >= 0) order[cur[(size_t)k2]++] = (uint32_t)i;
+        }
+    }
+    return (int64_t)ci.words;
 }
 
 /* ---- device-resident batches ------------------------------------------------ */
 extern "C" void bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b)
 {
     if (!b) return;
-    if (ctx) (void)hipSetDevice(ctx->device);
-    if (b->d_seq) (void)hipFree(b->d_seq);
-    if (b->d_tasks) (void)hipFree(b->d_tasks);
-    if (b->d_order) (void)hipFree(b->d_order);
-    if (b->d_out) (void)hipFree(b->d_out);
+    if (ctx) (void)hipSetDevice(ctx->device0());
+    b->st.release();
     delete b;
+}
+
+static int busy_check(bsw_ctx *ctx, const char *what)
+{
+    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "%s: context is dead (an earlier wait for the GPU timed out)", what);
+    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "%s: a bsw_submit is in flight (call bsw_wait first)", what);
+    return BSW_OK;
 }
 
 static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out,
                          const bsw_ref *ref /* NULL: targets come from the host */, const bsw_ref_task *rtasks)
 {
     *out = nullptr;
-    if (n >= (1ull << 32)) return fail(ctx, BSW_E_LIMIT, "more than 2^32-1 tasks in one batch");
+    errs &e = ctx->err;
+    if (n >= (1ull << 32)) return fail(e, BSW_E_LIMIT, "more than 2^32-1 tasks in one batch");
     bsw_dparams dp;
-    int rc = check_params(ctx, p, &dp);
+    int rc = check_params(e, p, &dp);
     if (rc) return rc;
-    packed_host ph;
-    size_t words = 0;
-    rc = pack_tasks(ctx, p, tasks, n, ctx->cfg.pack_threads, nullptr, 0, ph, nullptr, nullptr, &words, ref != nullptr);
-    if (rc) return rc;
-    std::vector<bsw_fetch_desc> descs;
+    HIPCHK(e, hipSetDevice(ctx->device0()));
+    bsw_dev_batch *b = new bsw_dev_batch();
+    stage_t &st = b->st;
+    st.set_pinned(false);               /* one-shot upload: plain host staging, synchronous copies */
+    chunk_info ci;
+    if (st.h_tasks.reserve(n + 1) != hipSuccess || st.h_roff.reserve(n + 1) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
+    rc = prepare_chunk(e, p, ctx->cfg.kernel, tasks, n, ref != nullptr, st.h_tasks.p, st.h_roff.p, ci);
+    if (rc) { bsw_free_batch(ctx, b); return rc; }
+    if (!ci.direct) {
+        if (st.h_raw.reserve(ci.sum_len + RAW_SLACK) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
+        gather_raw(tasks, st.h_roff.p, n, ref != nullptr, st.h_raw.p, ctx->cfg.pack_threads);
+    }
+    size_t n_desc = 0;
     if (ref) {
-        descs.reserve(2 * n);
+        if (st.h_desc.reserve(2 * n + 1) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
         for (size_t i = 0; i < n; ++i) {
-            const bsw_dtask &d = ph.tasks[i];
+            const bsw_dtask &d = st.h_tasks.p[i];
             const bsw_seed &sd = rtasks[i].seed;
-            if (d.lqlen && d.ltlen) descs.push_back(bsw_fetch_desc{sd.rbeg - 1, d.lt_off, d.ltlen, -1, 0});
-            if (d.rqlen && d.rtlen) descs.push_back(bsw_fetch_desc{sd.rbeg + sd.len, d.rt_off, d.rtlen, 1, 0});
+            if (d.lqlen && d.ltlen) st.h_desc.p[n_desc++] = bsw_fetch_desc{sd.rbeg - 1, d.lt_off, d.ltlen, -1, 0};
+            if (d.rqlen && d.rtlen) st.h_desc.p[n_desc++] = bsw_fetch_desc{sd.rbeg + sd.len, d.rt_off, d.rtlen, 1, 0};
         }
     }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    bsw_dev_batch *b = new bsw_dev_batch();
-    b->n = n; b->P = dp; b->variant = p->variant; b->seq_words = words;
-    b->plan = ph.plan;
-    const size_t olen = (size_t)ph.plan.order_len + 1;          /* + redo counter */
-    hipError_t e = hipSuccess;
-    bsw_fetch_desc *d_desc = nullptr;
-    if ((e = hipMalloc((void **)&b->d_seq, (words + 1) * sizeof(uint64_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&b->d_tasks, (n + 1) * sizeof(bsw_dtask))) != hipSuccess ||
-        (e = hipMalloc((void **)&b->d_order, (olen + 1) * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&b->d_out, (n + 1) * sizeof(bsw_result))) != hipSuccess ||
-        (!descs.empty() && (e = hipMalloc((void **)&d_desc, descs.size() * sizeof(bsw_fetch_desc))) != hipSuccess)) {
-        bsw_free_batch(ctx, b);
-        return fail(ctx, BSW_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    b->n = n; b->P = dp; b->variant = p->variant; b->seq_words = ci.words; b->plan = ci.plan;
+    hipStream_t s = ctx->stream0();
+    rc = stage_device(e, st, s, ci, n, ref != nullptr, ref, n_desc, &b->h2d_bytes);
+    if (!rc && n) {
+        hipError_t he = hipMemsetAsync(st.d_out.p, 0xff, n * sizeof(bsw_result), s);
+        if (he != hipSuccess) rc = fail(e, BSW_E_HIP, "memset: %s", hipGetErrorString(he));
     }
-    hipStream_t s = ctx->streams[0];
-    if ((e = hipMemcpyAsync(b->d_seq, ph.seq.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, s)) != hipSuccess ||
-        (e = hipMemcpyAsync(b->d_tasks, ph.tasks.data(), n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s)) != hipSuccess ||
-        (e = hipMemcpyAsync(b->d_order, ph.order.data(), olen * sizeof(uint32_t), hipMemcpyHostToDevice, s)) != hipSuccess ||
-        (e = hipMemsetAsync(b->d_out, 0xff, n * sizeof(bsw_result), s)) != hipSuccess ||
-        (!descs.empty() && ((e = hipMemcpyAsync(d_desc, descs.data(), descs.size() * sizeof(bsw_fetch_desc), hipMemcpyHostToDevice, s)) != hipSuccess ||
-                            (e = bsw::launch_fetch(ref->d_pac, ref->l_pac, d_desc, (uint32_t)descs.size(), b->d_seq, s)) != hipSuccess)) ||
-        (e = hipStreamSynchronize(s)) != hipSuccess) {
-        if (d_desc) (void)hipFree(d_desc);
-        bsw_free_batch(ctx, b);
-        return fail(ctx, BSW_E_HIP, "upload: %s", hipGetErrorString(e));
-    }
-    if (d_desc) (void)hipFree(d_desc);
-    b->h2d_bytes = words * 8 + n * sizeof(bsw_dtask) + olen * 4 + descs.size() * sizeof(bsw_fetch_desc);
+    if (!rc) rc = sync_stream(ctx, e, s, ctx->devs[0].events[0]);
+    if (rc) { bsw_free_batch(ctx, b); return rc; }
+    st.release_host();
+    st.release_transient_dev();
     *out = b;
     return BSW_OK;
 }
 
 extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out)
 {
-    if (!ctx || !out || (!tasks && n)) return fail(ctx, BSW_E_INVAL, "bsw_upload: NULL argument");
+    if (!ctx) return BSW_E_INVAL;
+    if (!out || (!tasks && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_upload: NULL argument");
+    int rc = busy_check(ctx, "bsw_upload");
+    if (rc) return rc;
     return upload_common(ctx, p, tasks, n, out, nullptr, nullptr);
 }
 
 /* ---- device-resident reference (F3) ------------------------------------------------ */
 extern "C" int bsw_ref_upload(bsw_ctx *ctx, const uint8_t *pac, int64_t l_pac, bsw_ref **out)
 {
-    if (!ctx || !pac || !out || l_pac <= 0) return fail(ctx, BSW_E_INVAL, "bsw_ref_upload: bad argument");
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!pac || !out || l_pac <= 0) return fail(e, BSW_E_INVAL, "bsw_ref_upload: bad argument");
     *out = nullptr;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(e, hipSetDevice(ctx->device0()));
     bsw_ref *r = new bsw_ref();
     r->l_pac = l_pac;
+    r->device = ctx->device0();
     const size_t bytes = (size_t)((l_pac + 3) >> 2);
-    hipError_t e;
-    if ((e = hipMalloc((void **)&r->d_pac, bytes + 8)) != hipSuccess) { delete r; return fail(ctx, BSW_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
-    if ((e = hipMemcpy(r->d_pac, pac, bytes, hipMemcpyHostToDevice)) != hipSuccess) {
+    hipError_t he;
+    if ((he = hipMalloc((void **)&r->d_pac, bytes + 8)) != hipSuccess) { delete r; return fail(e, BSW_E_NOMEM, "hipMalloc: %s", hipGetErrorString(he)); }
+    if ((he = hipMemcpy(r->d_pac, pac, bytes, hipMemcpyHostToDevice)) != hipSuccess) {
         (void)hipFree(r->d_pac); delete r;
-        return fail(ctx, BSW_E_HIP, "pac upload: %s", hipGetErrorString(e));
+        return fail(e, BSW_E_HIP, "pac upload: %s", hipGetErrorString(he));
     }
     *out = r;
     return BSW_OK;
@@ -610,14 +894,18 @@ extern "C" int bsw_ref_upload(bsw_ctx *ctx, const uint8_t *pac, int64_t l_pac, b
 extern "C" void bsw_ref_free(bsw_ctx *ctx, bsw_ref *ref)
 {
     if (!ref) return;
-    if (ctx) (void)hipSetDevice(ctx->device);
+    if (ctx) (void)hipSetDevice(ctx->device0());
     if (ref->d_pac) (void)hipFree(ref->d_pac);
     delete ref;
 }
 
 extern "C" int bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rt, size_t n, bsw_dev_batch **out)
 {
-    if (!ctx || !p || !ref || !out || (!rt && n)) return fail(ctx, BSW_E_INVAL, "bsw_upload_ref: NULL argument");
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!p || !ref || !out || (!rt && n)) return fail(e, BSW_E_INVAL, "bsw_upload_ref: NULL argument");
+    int rc = busy_check(ctx, "bsw_upload_ref");
+    if (rc) return rc;
     /* mem_chain2aln's task extraction minus the target bases, which stay on the device */
     std::vector<bsw_task> tasks(n ? n : 1);
     size_t scratch_len = 0;
@@ -629,12 +917,12 @@ extern "C" int bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *
         const bsw_ref_task &r = rt[i];
         const bsw_seed &sd = r.seed;
         if (!r.query || r.l_query < 1 || sd.qbeg < 0 || sd.len < 1 || sd.qbeg + sd.len > r.l_query)
-            return fail(ctx, BSW_E_INVAL, "ref task %zu: bad seed / read", i);
+            return fail(e, BSW_E_INVAL, "ref task %zu: bad seed / read", i);
         if (r.rmax0 < 0 || r.rmax1 > two || r.rmax0 > sd.rbeg || r.rmax1 < sd.rbeg + sd.len ||
             (r.rmax0 < ref->l_pac && ref->l_pac < r.rmax1))
-            return fail(ctx, BSW_E_INVAL, "ref task %zu: window outside the reference or bridging the strands", i);
+            return fail(e, BSW_E_INVAL, "ref task %zu: window outside the reference or bridging the strands", i);
         const int64_t lt = sd.rbeg - r.rmax0, rtl = r.rmax1 - (sd.rbeg + sd.len);
-        if (lt > BSW_MAX_TLEN || rtl > BSW_MAX_TLEN) return fail(ctx, BSW_E_LIMIT, "ref task %zu: window beyond BSW_MAX_TLEN", i);
+        if (lt > BSW_MAX_TLEN || rtl > BSW_MAX_TLEN) return fail(e, BSW_E_LIMIT, "ref task %zu: window beyond BSW_MAX_TLEN", i);
         bsw_task &t = tasks[i];
         memset(&t, 0, sizeof(t));
         if (sd.qbeg > 0) {
@@ -652,7 +940,8 @@ extern "C" int bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *
 
 extern "C" int bsw_extend_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rt, size_t n, bsw_result *out)
 {
-    if (!ctx || (!out && n)) return fail(ctx, BSW_E_INVAL, "bsw_extend_ref: NULL argument");
+    if (!ctx) return BSW_E_INVAL;
+    if (!out && n) return fail(ctx->err, BSW_E_INVAL, "bsw_extend_ref: NULL argument");
     bsw_dev_batch *b = nullptr;
     int rc = bsw_upload_ref(ctx, p, ref, rt, n, &b);
     if (rc) return rc;
@@ -662,61 +951,32 @@ extern "C" int bsw_extend_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *
     return rc;
 }
 
-static int enqueue_batch(bsw_ctx *ctx, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
-                         uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches)
-{
-    const int nc = bsw::wave_class_count();
-    for (int c = 0; c < nc; ++c) {
-        const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
-        if (!cnt) continue;
-        HIPCHK(ctx, bsw::launch_wave(c, variant, P, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, d_out, s));
-        if (launches) ++*launches;
-    }
-    if (pl.lane_all_cnt) {
-        uint32_t *redo_cnt = d_order + pl.order_len;
-        HIPCHK(ctx, hipMemsetAsync(redo_cnt, 0, sizeof(uint32_t), s));
-        const int nlc = bsw::lane_class_count();
-        for (int side = 0; side < 2; ++side) {
-            const uint32_t *offs = side ? pl.laneR_off : pl.laneL_off;
-            for (int c = 0; c < nlc; ++c) {
-                const uint32_t cnt = offs[c + 1] - offs[c];
-                if (!cnt) continue;
-                HIPCHK(ctx, bsw::launch_lane(c, variant, P, side, d_seq, d_tasks, d_order + offs[c], cnt, d_out, s));
-                if (launches) ++*launches;
-            }
-        }
-        HIPCHK(ctx, bsw::launch_finalize(P, d_tasks, d_order + pl.lane_all_off, pl.lane_all_cnt, d_out,
-                                         d_order + pl.redo_off, redo_cnt, s));
-        /* seeds whose first band try was not final: recompute from scratch, one wavefront each */
-        HIPCHK(ctx, bsw::launch_wave(pl.redo_cls, variant, P, d_seq, d_tasks, d_order + pl.redo_off, pl.lane_all_cnt,
-                                     redo_cnt, d_out, s));
-        if (launches) *launches += 2;
-    }
-    return BSW_OK;
-}
-
 extern "C" int bsw_run(bsw_ctx *ctx, bsw_dev_batch *b)
 {
-    if (!ctx || !b) return fail(ctx, BSW_E_INVAL, "bsw_run: NULL argument");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->streams[0];
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!b) return fail(e, BSW_E_INVAL, "bsw_run: NULL argument");
+    int rc = busy_check(ctx, "bsw_run");
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(ctx->device0()));
+    hipStream_t s = ctx->stream0();
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if (ctx->hist_used < 4096) {
         if (ctx->hist_used == ctx->hist.size()) {
             hipEvent_t a, c;
-            HIPCHK(ctx, hipEventCreate(&a));
-            HIPCHK(ctx, hipEventCreate(&c));
+            HIPCHK(e, hipEventCreate(&a));
+            HIPCHK(e, hipEventCreate(&c));
             ctx->hist.emplace_back(a, c);
         }
         e0 = ctx->hist[ctx->hist_used].first;
         e1 = ctx->hist[ctx->hist_used].second;
         ++ctx->hist_used;
     }
-    HIPCHK(ctx, hipEventRecord(e0, s));
+    HIPCHK(e, hipEventRecord(e0, s));
     b->launches = 0;
-    int rc = enqueue_batch(ctx, b->P, b->variant, b->d_seq, b->d_tasks, b->d_order, b->plan, b->d_out, s, &b->launches);
+    rc = enqueue_batch(e, b->P, b->variant, b->st.d_seq.p, b->st.d_tasks.p, b->st.d_order.p, b->plan, b->st.d_out.p, s, &b->launches);
     if (rc) return rc;
-    HIPCHK(ctx, hipEventRecord(e1, s));
+    HIPCHK(e, hipEventRecord(e1, s));
     ctx->ev_last0 = e0; ctx->ev_last1 = e1;
     ctx->timed = true;
     return BSW_OK;
@@ -725,38 +985,43 @@ extern "C" int bsw_run(bsw_ctx *ctx, bsw_dev_batch *b)
 extern "C" int bsw_sync(bsw_ctx *ctx)
 {
     if (!ctx) return BSW_E_INVAL;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (auto s : ctx->streams) HIPCHK(ctx, hipStreamSynchronize(s));
-    return BSW_OK;
+    errs &e = ctx->err;
+    if (ctx->worker_active) return fail(e, BSW_E_BUSY, "bsw_sync: a bsw_submit is in flight (call bsw_wait)");
+    HIPCHK(e, hipSetDevice(ctx->device0()));
+    return sync_stream(ctx, e, ctx->stream0(), ctx->devs[0].events[0]);
 }
 
 extern "C" int bsw_last_run_ms(bsw_ctx *ctx, float *ms)
 {
     if (!ctx || !ms || !ctx->timed) return BSW_E_INVAL;
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev_last1));
-    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev_last0, ctx->ev_last1));
+    errs &e = ctx->err;
+    int rc = bsw_sync(ctx);
+    if (rc) return rc;
+    HIPCHK(e, hipEventElapsedTime(ms, ctx->ev_last0, ctx->ev_last1));
     return BSW_OK;
 }
 
 extern "C" int bsw_run_history(bsw_ctx *ctx, float *ms, int cap)
 {
     if (!ctx || (!ms && cap > 0)) return BSW_E_INVAL;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    errs &e = ctx->err;
+    int rc = bsw_sync(ctx);
+    if (rc) return rc;
     int n = 0;
-    for (size_t i = 0; i < ctx->hist_used && n < cap; ++i, ++n) {
-        HIPCHK(ctx, hipEventSynchronize(ctx->hist[i].second));
-        HIPCHK(ctx, hipEventElapsedTime(&ms[n], ctx->hist[i].first, ctx->hist[i].second));
-    }
+    for (size_t i = 0; i < ctx->hist_used && n < cap; ++i, ++n)
+        HIPCHK(e, hipEventElapsedTime(&ms[n], ctx->hist[i].first, ctx->hist[i].second));
     ctx->hist_used = 0;
     return n;
 }
 
 extern "C" int bsw_download(bsw_ctx *ctx, bsw_dev_batch *b, bsw_result *out)
 {
-    if (!ctx || !b || (!out && b->n)) return fail(ctx, BSW_E_INVAL, "bsw_download: NULL argument");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->streams[0]));
-    HIPCHK(ctx, hipMemcpy(out, b->d_out, b->n * sizeof(bsw_result), hipMemcpyDeviceToHost));
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!b || (!out && b->n)) return fail(e, BSW_E_INVAL, "bsw_download: NULL argument");
+    int rc = bsw_sync(ctx);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpy(out, b->st.d_out.p, b->n * sizeof(bsw_result), hipMemcpyDeviceToHost));
     return BSW_OK;
 }
 
@@ -770,90 +1035,60 @@ extern "C" int bsw_batch_info(const bsw_dev_batch *b, uint64_t *n_tasks, uint64_
     return BSW_OK;
 }
 
-/* ---- streaming submit: pinned double buffering over several streams ----------- */
-struct slot_t {
-    uint64_t *h_seq = nullptr, *d_seq = nullptr; size_t seq_cap = 0;
-    bsw_dtask *h_tasks = nullptr, *d_tasks = nullptr;
-    uint32_t *h_order = nullptr, *d_order = nullptr;
-    bsw_result *h_out = nullptr, *d_out = nullptr;
-    size_t task_cap = 0;
-    size_t base = 0, cnt = 0;       /* chunk in flight */
-    bool busy = false;
-};
-
-static void slot_free(slot_t &s)
+extern "C" int bsw_batch_order(bsw_ctx *ctx, const bsw_dev_batch *b, uint32_t *order, uint32_t *seg)
 {
-    if (s.h_seq) (void)hipHostFree(s.h_seq);
-    if (s.d_seq) (void)hipFree(s.d_seq);
-    if (s.h_tasks) (void)hipHostFree(s.h_tasks);
-    if (s.d_tasks) (void)hipFree(s.d_tasks);
-    if (s.h_order) (void)hipHostFree(s.h_order);
-    if (s.d_order) (void)hipFree(s.d_order);
-    if (s.h_out) (void)hipHostFree(s.h_out);
-    if (s.d_out) (void)hipFree(s.d_out);
-    s = slot_t();
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!b || !seg) return fail(e, BSW_E_INVAL, "bsw_batch_order: NULL argument");
+    int rc = bsw_sync(ctx);
+    if (rc) return rc;
+    plan_segments(b->plan, seg);
+    if (order && b->plan.redo_off)
+        HIPCHK(e, hipMemcpy(order, b->st.d_order.p, (size_t)b->plan.redo_off * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return BSW_OK;
 }
 
-static void slots_release(std::vector<slot_t> *v)
+/* ---- one synchronous chunk through a staging slot (small batches; the streaming workers use the same steps) ---- */
+static int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params &p, const bsw_dparams &dp,
+                     const bsw_task *tasks, size_t n, bsw_result *out, int gather_threads)
 {
-    if (!v) return;
-    for (auto &s : *v) slot_free(s);
-    delete v;
+    if (n == 0) return BSW_OK;
+    hipError_t he;
+    if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess)
+        return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    chunk_info ci;
+    int rc = prepare_chunk(e, &p, ctx->cfg.kernel, tasks, n, false, st.h_tasks.p, st.h_roff.p, ci);
+    if (rc) return rc;
+    if (!ci.direct) {
+        if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+        gather_raw(tasks, st.h_roff.p, n, false, st.h_raw.p, gather_threads);
+    }
+    rc = stage_device(e, st, s, ci, n, false, nullptr, 0, nullptr);
+    if (rc) return rc;
+    rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, s, nullptr);
+    if (rc) return rc;
+    const bool out_direct = is_registered(out, n * sizeof(bsw_result));
+    if (!out_direct && (he = st.h_out.reserve(n)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    HIPCHK(e, hipMemcpyAsync(out_direct ? out : st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
+    rc = sync_stream(ctx, e, s, ev);
+    if (rc) return rc;
+    if (!out_direct) memcpy(out, st.h_out.p, n * sizeof(bsw_result));
+    return BSW_OK;
 }
 
-/* One staging slot = one stream = one host thread: chunk ci is handled by slot ci % nslots (validate, pack into
- * pinned staging, H2D, kernels, D2H, copy-out), so host packing of several chunks and the GPU work of several
- * chunks overlap — the round-robin of the reference's four TBB/RBB pairs (batch_manager.v:418,745-773). */
+/* ---- streaming submit: one host thread per (device, slot); chunk k -> device k mod G, slot (k / G) mod S —
+ * the round-robin of the reference's four TBB/RBB pairs over its PE arrays (batch_manager.v:343-348,418,745-773) ---- */
 static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp, const bsw_task *tasks, size_t n,
-                       bsw_result *out, size_t k, size_t nslots, int threads, std::atomic<int> &abort_flag, std::string &err)
+                       bsw_result *out, size_t d, size_t s, int gather_threads, std::atomic<int> &abort_flag, errs &e)
 {
-    bsw_ctx local;                       /* error text + kernel choice for this thread (ctx->err is not thread-safe) */
-    local.cfg = ctx->cfg;
-    auto failed = [&](int rc) { err = local.err; abort_flag = 1; return rc; };
-    hipError_t e = hipSetDevice(ctx->device);
-    if (e != hipSuccess) { local.err = hipGetErrorString(e); return failed(BSW_E_HIP); }
-    const size_t chunk = ctx->cfg.chunk_tasks;
-    slot_t &s = (*ctx->slots)[k];
-    hipStream_t st = ctx->streams[k];
-    for (size_t base = k * chunk; base < n && !abort_flag; base += nslots * chunk) {
-        const size_t cnt = std::min(chunk, n - base);
-        size_t words = 0;
-        for (size_t i = base; i < base + cnt; ++i) {
-            const bsw_task &t = tasks[i];
-            if (t.lqlen < 0 || t.rqlen < 0 || t.ltlen < 0 || t.rtlen < 0) { fail(&local, BSW_E_INVAL, "task %zu: negative length", i); return failed(BSW_E_INVAL); }
-            words += (t.lqlen ? nwords(t.lqlen) + nwords(t.ltlen) : 0) + (t.rqlen ? nwords(t.rqlen) + nwords(t.rtlen) : 0);
-        }
-        if (s.seq_cap < words + 1) {
-            if (s.h_seq) (void)hipHostFree(s.h_seq);
-            if (s.d_seq) (void)hipFree(s.d_seq);
-            s.h_seq = nullptr; s.d_seq = nullptr;
-            s.seq_cap = (words + 1) * 5 / 4;
-            if ((e = hipHostMalloc((void **)&s.h_seq, s.seq_cap * 8, hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&s.d_seq, s.seq_cap * 8)) != hipSuccess) { s.seq_cap = 0; fail(&local, BSW_E_NOMEM, "staging: %s", hipGetErrorString(e)); return failed(BSW_E_NOMEM); }
-        }
-        if (s.task_cap < cnt) {
-            if (s.h_tasks) { (void)hipHostFree(s.h_tasks); (void)hipFree(s.d_tasks); (void)hipHostFree(s.h_order); (void)hipFree(s.d_order); (void)hipHostFree(s.h_out); (void)hipFree(s.d_out); }
-            s.h_tasks = nullptr; s.d_tasks = nullptr; s.h_order = nullptr; s.d_order = nullptr; s.h_out = nullptr; s.d_out = nullptr;
-            s.task_cap = std::max(cnt, chunk);
-            if ((e = hipHostMalloc((void **)&s.h_tasks, s.task_cap * sizeof(bsw_dtask), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&s.d_tasks, s.task_cap * sizeof(bsw_dtask))) != hipSuccess ||
-                (e = hipHostMalloc((void **)&s.h_order, order_capacity(s.task_cap) * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&s.d_order, order_capacity(s.task_cap) * sizeof(uint32_t))) != hipSuccess ||
-                (e = hipHostMalloc((void **)&s.h_out, s.task_cap * sizeof(bsw_result), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&s.d_out, s.task_cap * sizeof(bsw_result))) != hipSuccess) { s.task_cap = 0; fail(&local, BSW_E_NOMEM, "staging: %s", hipGetErrorString(e)); return failed(BSW_E_NOMEM); }
-        }
-        packed_host ph;
-        size_t w2 = 0;
-        int rc = pack_tasks(&local, &p, tasks + base, cnt, threads, s.h_seq, s.seq_cap, ph, s.h_tasks, s.h_order, &w2);
-        if (rc) return failed(rc);
-        if ((e = hipMemcpyAsync(s.d_seq, s.h_seq, w2 * 8, hipMemcpyHostToDevice, st)) != hipSuccess ||
-            (e = hipMemcpyAsync(s.d_tasks, s.h_tasks, cnt * sizeof(bsw_dtask), hipMemcpyHostToDevice, st)) != hipSuccess ||
-            (e = hipMemcpyAsync(s.d_order, s.h_order, ((size_t)ph.plan.order_len + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st)) != hipSuccess) { fail(&local, BSW_E_HIP, "H2D: %s", hipGetErrorString(e)); return failed(BSW_E_HIP); }
-        rc = enqueue_batch(&local, dp, p.variant, s.d_seq, s.d_tasks, s.d_order, ph.plan, s.d_out, st, nullptr);
-        if (rc) return failed(rc);
-        if ((e = hipMemcpyAsync(s.h_out, s.d_out, cnt * sizeof(bsw_result), hipMemcpyDeviceToHost, st)) != hipSuccess ||
-            (e = hipStreamSynchronize(st)) != hipSuccess) { fail(&local, BSW_E_HIP, "D2H: %s", hipGetErrorString(e)); return failed(BSW_E_HIP); }
-        memcpy(out + base, s.h_out, cnt * sizeof(bsw_result));
+    dev_state &dev = ctx->devs[d];
+    const size_t G = ctx->devs.size(), S = dev.slots.size(), chunk = ctx->cfg.chunk_tasks;
+    hipError_t he = hipSetDevice(dev.device);
+    if (he != hipSuccess) { abort_flag = 1; return fail(e, BSW_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)); }
+    for (size_t ci = d + G * s; ci * chunk < n && !abort_flag; ci += G * S) {
+        const size_t base = ci * chunk, cnt = std::min(chunk, n - base);
+        const int rc = run_chunk(ctx, e, dev.slots[s], dev.streams[s], dev.events[s], p, dp, tasks + base, cnt, out + base, gather_threads);
+        if (rc) { abort_flag = 1; return rc; }
     }
     return BSW_OK;
 }
@@ -861,34 +1096,36 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
 static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, size_t n, bsw_result *out)
 {
     bsw_dparams dp;
-    int rc = check_params(ctx, &p, &dp);
+    int rc = check_params(ctx->err, &p, &dp);
     if (rc) return rc;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    const size_t chunk = ctx->cfg.chunk_tasks;
-    const size_t nslots = ctx->streams.size();
-    if (!ctx->slots) ctx->slots = new std::vector<slot_t>(nslots);
+    const size_t G = ctx->devs.size(), S = (size_t)ctx->cfg.streams, chunk = ctx->cfg.chunk_tasks;
     const size_t nchunks = (n + chunk - 1) / chunk;
-    const size_t nworkers = std::min(nslots, nchunks ? nchunks : 1);
-    const int threads = std::max(1, ctx->cfg.pack_threads / (int)nworkers);
+    struct wk { size_t d, s; int rc = 0; errs e; };
+    std::vector<wk> ws;
+    for (size_t s = 0; s < S; ++s)
+        for (size_t d = 0; d < G; ++d)
+            if (d + G * s < nchunks) { wk w; w.d = d; w.s = s; ws.push_back(w); }
+    if (ws.empty()) return BSW_OK;
+    const int gather_threads = std::max(1, ctx->cfg.pack_threads / (int)ws.size());
     std::atomic<int> abort_flag{0};
-    std::vector<int> rcs(nworkers, 0);
-    std::vector<std::string> errs(nworkers);
     std::vector<std::thread> th;
-    for (size_t k = 1; k < nworkers; ++k)
-        th.emplace_back([&, k]() { rcs[k] = slot_worker(ctx, p, dp, tasks, n, out, k, nslots, threads, abort_flag, errs[k]); });
-    rcs[0] = slot_worker(ctx, p, dp, tasks, n, out, 0, nslots, threads, abort_flag, errs[0]);
+    for (size_t k = 1; k < ws.size(); ++k)
+        th.emplace_back([&, k]() { ws[k].rc = slot_worker(ctx, p, dp, tasks, n, out, ws[k].d, ws[k].s, gather_threads, abort_flag, ws[k].e); });
+    ws[0].rc = slot_worker(ctx, p, dp, tasks, n, out, ws[0].d, ws[0].s, gather_threads, abort_flag, ws[0].e);
     for (auto &t : th) t.join();
-    for (size_t k = 0; k < nworkers; ++k)
-        if (rcs[k]) { ctx->err = errs[k]; return rcs[k]; }
+    for (auto &w : ws)
+        if (w.rc) { ctx->err = w.e; return w.rc; }
     return BSW_OK;
 }
 
 extern "C" int bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out)
 {
-    if (!ctx || !p || (!tasks && n) || (!out && n)) return fail(ctx, BSW_E_INVAL, "bsw_submit: NULL argument");
-    if (ctx->worker_active) return fail(ctx, BSW_E_BUSY, "previous bsw_submit not waited for");
+    if (!ctx) return BSW_E_INVAL;
+    if (!p || (!tasks && n) || (!out && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_submit: NULL argument");
+    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "bsw_submit: context is dead (an earlier wait for the GPU timed out)");
+    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "previous bsw_submit not waited for");
     bsw_dparams dp;
-    int rc = check_params(ctx, p, &dp);
+    int rc = check_params(ctx->err, p, &dp);
     if (rc) return rc;
     ctx->worker_active = true;
     ctx->worker_rc = 0;
@@ -907,98 +1144,200 @@ extern "C" int bsw_wait(bsw_ctx *ctx)
 }
 
 /* ---- batched plain ksw_extend2 ------------------------------------------------ */
-extern "C" int bsw_extend_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_ext_task *tasks, size_t n, bsw_ext *out)
+/* One pass each, per-task w / end_bonus / h0.  A task's band is min(w, max_ins, max_del) (sw_pe_array_sw_extend.v:
+ * 1881,1890), which is exactly a per-task band limit, so tasks with different w and end_bonus share one launch:
+ * P.w = the largest w of the group, wlim_r = min(w_i, gap limit of end_bonus_i). */
+static int ext_group(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params *p,
+                     const bsw_ext_task *tasks, const uint32_t *idx, size_t n, int w_group, bsw_ext *out)
 {
-    if (!ctx || !p || (!tasks && n) || (!out && n)) return fail(ctx, BSW_E_INVAL, "bsw_extend_batch: NULL argument");
-    /* group by (w, end_bonus): each group is one pair-batch with only the right side populated,
-     * one band try, clip penalties = end_bonus (they only feed max_ins/max_del here). */
-    std::vector<uint32_t> idx(n);
-    for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
-        if (tasks[a].w != tasks[b].w) return tasks[a].w < tasks[b].w;
-        return tasks[a].end_bonus < tasks[b].end_bonus;
-    });
-    size_t g0 = 0;
-    while (g0 < n) {
-        size_t g1 = g0;
-        while (g1 < n && tasks[idx[g1]].w == tasks[idx[g0]].w && tasks[idx[g1]].end_bonus == tasks[idx[g0]].end_bonus) ++g1;
-        bsw_params pp = *p;
-        pp.w = tasks[idx[g0]].w;
-        pp.pen_clip3 = pp.pen_clip5 = tasks[idx[g0]].end_bonus;
-        pp.max_band_try = 1;
-        std::vector<bsw_task> pt(g1 - g0);
-        for (size_t k = g0; k < g1; ++k) {
-            const bsw_ext_task &e = tasks[idx[k]];
-            bsw_task &t = pt[k - g0];
-            memset(&t, 0, sizeof(t));
-            if (e.qlen < 1) return fail(ctx, BSW_E_INVAL, "ext task %u: qlen must be >= 1", idx[k]);
-            t.rquery = e.query; t.rtarget = e.target; t.rqlen = e.qlen; t.rtlen = e.tlen;
-            t.h0 = e.h0; t.init_score = -1; t.tag = idx[k];
-        }
-        std::vector<bsw_result> res(g1 - g0);
-        bsw_dev_batch *b = nullptr;
-        int rc = bsw_upload(ctx, &pp, pt.data(), pt.size(), &b);
-        if (rc) return rc;
-        rc = bsw_run(ctx, b);
-        if (!rc) rc = bsw_download(ctx, b, res.data());
-        bsw_free_batch(ctx, b);
-        if (rc) return rc;
-        for (size_t k = g0; k < g1; ++k) {
-            out[idx[k]] = res[k - g0].right;
-            out[idx[k]].aw = tasks[idx[k]].w;
-        }
-        g0 = g1;
+    bsw_params pp = *p;
+    pp.w = w_group;
+    pp.max_band_try = 1;
+    const int mx = mat_max(p->mat);
+    std::vector<bsw_task> pt(n);
+    for (size_t k = 0; k < n; ++k) {
+        const bsw_ext_task &x = tasks[idx[k]];
+        bsw_task &t = pt[k];
+        memset(&t, 0, sizeof(t));
+        if (x.qlen < 1) return fail(e, BSW_E_INVAL, "ext task %u: qlen must be >= 1", idx[k]);
+        t.rquery = x.query; t.rtarget = x.target; t.rqlen = x.qlen; t.rtlen = x.tlen;
+        t.h0 = x.h0; t.init_score = -1; t.tag = idx[k];
+        const int gl = gap_limit(p, mx, x.qlen, x.end_bonus);
+        t.wlim_r = x.w >= 1 ? std::min(x.w, gl) : 0;        /* w < 1 groups: P.w itself is the band */
+    }
+    bsw_dparams dp;
+    int rc = check_params(e, &pp, &dp);
+    if (rc) return rc;
+    std::vector<bsw_result> res(n);
+    rc = run_chunk(ctx, e, st, s, ev, pp, dp, pt.data(), n, res.data(), 1);
+    if (rc) return rc;
+    for (size_t k = 0; k < n; ++k) {
+        out[idx[k]] = res[k].right;
+        out[idx[k]].aw = tasks[idx[k]].w;
     }
     return BSW_OK;
 }
 
-/* ---- drop-in scalar ABI -------------------------------------------------------- */
+static int ext_batch_on(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params *p,
+                        const bsw_ext_task *tasks, size_t n, bsw_ext *out)
+{
+    std::vector<uint32_t> pos, odd;
+    int wmax = 1;
+    for (size_t i = 0; i < n; ++i) {
+        if (tasks[i].w >= 1) { pos.push_back((uint32_t)i); wmax = std::max(wmax, tasks[i].w); }
+        else odd.push_back((uint32_t)i);
+    }
+    if (wmax > (1 << 20)) return fail(e, BSW_E_INVAL, "band out of range");
+    int rc = BSW_OK;
+    const size_t chunk = std::max<size_t>(ctx->cfg.chunk_tasks, 1);
+    for (size_t b0 = 0; b0 < pos.size() && !rc; b0 += chunk)
+        rc = ext_group(ctx, e, st, s, ev, p, tasks, pos.data() + b0, std::min(chunk, pos.size() - b0), wmax, out);
+    /* w <= 0 (never passed by bwa): one launch per distinct value */
+    std::stable_sort(odd.begin(), odd.end(), [&](uint32_t a, uint32_t b) { return tasks[a].w < tasks[b].w; });
+    for (size_t g0 = 0; g0 < odd.size() && !rc;) {
+        size_t g1 = g0;
+        while (g1 < odd.size() && tasks[odd[g1]].w == tasks[odd[g0]].w) ++g1;
+        const int w = tasks[odd[g0]].w;
+        if (w < 0) return fail(e, BSW_E_INVAL, "ext task %u: negative band", odd[g0]);
+        rc = ext_group(ctx, e, st, s, ev, p, tasks, odd.data() + g0, g1 - g0, w, out);
+        g0 = g1;
+    }
+    return rc;
+}
+
+extern "C" int bsw_extend_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_ext_task *tasks, size_t n, bsw_ext *out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!p || (!tasks && n) || (!out && n)) return fail(e, BSW_E_INVAL, "bsw_extend_batch: NULL argument");
+    int rc = busy_check(ctx, "bsw_extend_batch");
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(ctx->device0()));
+    return ext_batch_on(ctx, e, ctx->small, ctx->stream0(), ctx->devs[0].events[0], p, tasks, n, out);
+}
+
+/* ---- drop-in scalar ABI ----------------------------------------------------------
+ * bwa calls ksw_extend2 from its -t worker threads.  Calls that arrive while a device round trip is in
+ * flight are queued; the thread that finds no round trip in flight becomes the leader, takes everything
+ * queued (its own call included), runs it as ONE device batch on the process-wide context's staging
+ * (persistent pinned + device buffers: no allocation per call) and wakes the others. */
+struct scalar_req {
+    bsw_params p;
+    bsw_ext_task t;
+    bsw_ext x;
+    int rc = 0;
+    bool done = false;
+};
 static std::mutex g_mu;
+static std::condition_variable g_cv;
+static std::vector<scalar_req *> g_queue;
+static bool g_leader = false;
 static bsw_ctx *g_ctx = nullptr;
+static int g_ctx_rc = 0;
 static std::atomic<int> g_variant{BSW_VARIANT_H};
+static std::atomic<uint64_t> g_scalar_calls{0}, g_scalar_trips{0};
 
 extern "C" void bsw_set_default_variant(int variant) { g_variant = variant == BSW_VARIANT_M ? BSW_VARIANT_M : BSW_VARIANT_H; }
+
+/* calls served and device round trips made by the scalar ABI so far (calls / trips = mean coalescing factor) */
+extern "C" void bsw_scalar_stats(uint64_t *calls, uint64_t *trips)
+{
+    if (calls) *calls = g_scalar_calls;
+    if (trips) *trips = g_scalar_trips;
+}
+
+static bool same_scoring(const bsw_params &a, const bsw_params &b)
+{
+    return memcmp(a.mat, b.mat, 25) == 0 && a.o_del == b.o_del && a.e_del == b.e_del && a.o_ins == b.o_ins &&
+           a.e_ins == b.e_ins && a.zdrop == b.zdrop && a.variant == b.variant;
+}
+
+static void scalar_round_trip(std::vector<scalar_req *> &batch)
+{
+    if (!g_ctx && !g_ctx_rc) {
+        bsw_config c;
+        bsw_default_config(&c);
+        const char *dv = getenv("BSW_DEVICE");
+        if (dv) c.device = atoi(dv);
+        c.kernel = BSW_KERNEL_WAVE;              /* a handful of seeds per trip: one wavefront per extension */
+        g_ctx_rc = bsw_create(&c, &g_ctx);
+        if (g_ctx_rc) fprintf(stderr, "ksw_extend2(libbwasw_mi355): cannot create GPU context (%d); no CPU fallback exists\n", g_ctx_rc);
+    }
+    if (!g_ctx) {
+        for (scalar_req *r : batch) r->rc = g_ctx_rc;
+        return;
+    }
+    ++g_scalar_trips;
+    g_scalar_calls += batch.size();
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); ++i) {
+        if (taken[i]) continue;
+        std::vector<size_t> grp;
+        for (size_t j = i; j < batch.size(); ++j)
+            if (!taken[j] && same_scoring(batch[i]->p, batch[j]->p)) { grp.push_back(j); taken[j] = 1; }
+        std::vector<bsw_ext_task> t(grp.size());
+        std::vector<bsw_ext> x(grp.size());
+        for (size_t k = 0; k < grp.size(); ++k) t[k] = batch[grp[k]]->t;
+        int rc = BSW_OK;
+        if (hipSetDevice(g_ctx->device0()) != hipSuccess) rc = BSW_E_HIP;
+        if (!rc) rc = ext_batch_on(g_ctx, g_ctx->err, g_ctx->small, g_ctx->stream0(), g_ctx->devs[0].events[0], &batch[i]->p, t.data(), t.size(), x.data());
+        if (rc) fprintf(stderr, "ksw_extend2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
+        for (size_t k = 0; k < grp.size(); ++k) { batch[grp[k]]->rc = rc; if (!rc) batch[grp[k]]->x = x[k]; }
+    }
+}
 
 extern "C" int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
                            int o_del, int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0,
                            int *qle, int *tle, int *gtle, int *gscore, int *max_off)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_ctx) {
-        bsw_config c;
-        bsw_default_config(&c);
-        const char *dv = getenv("BSW_DEVICE");
-        if (dv) c.device = atoi(dv);
-        int rc = bsw_create(&c, &g_ctx);
-        if (rc) {
-            fprintf(stderr, "ksw_extend2(libbwasw_mi355): cannot create GPU context (%d); no CPU fallback exists\n", rc);
-            return -1;
+    auto neutral = [&](int score) {
+        if (qle) *qle = 0;
+        if (tle) *tle = 0;
+        if (gtle) *gtle = 0;
+        if (gscore) *gscore = -1;
+        if (max_off) *max_off = 0;
+        return score;
+    };
+    if (m != 5 || !mat || (qlen > 0 && !query) || (tlen > 0 && !target)) {
+        fprintf(stderr, "ksw_extend2(libbwasw_mi355): unsupported arguments (m must be 5)\n");
+        return neutral(-1);
+    }
+    if (h0 <= 0 || qlen <= 0) return neutral(h0 > 0 ? h0 : 0);      /* outside bwa's assert(h0 > 0) domain */
+    if (tlen < 0) tlen = 0;
+    scalar_req req;
+    bsw_default_params(&req.p);
+    memcpy(req.p.mat, mat, 25);
+    req.p.o_del = o_del; req.p.e_del = e_del; req.p.o_ins = o_ins; req.p.e_ins = e_ins;
+    req.p.zdrop = zdrop; req.p.variant = g_variant;
+    memset(&req.t, 0, sizeof(req.t));
+    req.t.query = query; req.t.target = target; req.t.qlen = qlen; req.t.tlen = tlen;
+    req.t.w = w; req.t.end_bonus = end_bonus; req.t.h0 = h0;
+    {
+        std::unique_lock<std::mutex> lk(g_mu);
+        g_queue.push_back(&req);
+        while (!req.done) {
+            if (!g_leader) {
+                g_leader = true;
+                std::vector<scalar_req *> batch;
+                batch.swap(g_queue);
+                lk.unlock();
+                scalar_round_trip(batch);
+                lk.lock();
+                for (scalar_req *r : batch) r->done = true;
+                g_leader = false;
+                g_cv.notify_all();
+            } else {
+                g_cv.wait(lk);
+            }
         }
     }
-    if (m != 5 || !mat || !query || (tlen > 0 && !target)) {
-        fprintf(stderr, "ksw_extend2(libbwasw_mi355): unsupported arguments (m must be 5)\n");
-        return -1;
-    }
-    bsw_params p;
-    bsw_default_params(&p);
-    memcpy(p.mat, mat, 25);
-    p.o_del = o_del; p.e_del = e_del; p.o_ins = o_ins; p.e_ins = e_ins;
-    p.zdrop = zdrop; p.variant = g_variant;
-    bsw_ext_task t;
-    memset(&t, 0, sizeof(t));
-    t.query = query; t.target = target; t.qlen = qlen; t.tlen = tlen; t.w = w; t.end_bonus = end_bonus; t.h0 = h0;
-    bsw_ext x;
-    int rc = bsw_extend_batch(g_ctx, &p, &t, 1, &x);
-    if (rc) {
-        fprintf(stderr, "ksw_extend2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
-        return -1;
-    }
-    if (qle) *qle = x.qle;
-    if (tle) *tle = x.tle;
-    if (gtle) *gtle = x.gtle;
-    if (gscore) *gscore = x.gscore;
-    if (max_off) *max_off = x.max_off;
-    return x.score;
+    if (req.rc) return neutral(-1);
+    if (qle) *qle = req.x.qle;
+    if (tle) *tle = req.x.tle;
+    if (gtle) *gtle = req.x.gtle;
+    if (gscore) *gscore = req.x.gscore;
+    if (max_off) *max_off = req.x.max_off;
+    return req.x.score;
 }
 
 extern "C" int ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
@@ -1009,28 +1348,167 @@ extern "C" int ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_
                        qle, tle, gtle, gscore, max_off);
 }
 
-/* ---- reference wire format end to end ----------------------------------------- */
+/* ---- reference wire format end to end (F1) -----------------------------------------
+ * bsw_refbatch_submit queues 256 KiB task batches; bsw_refbatch_wait parses the 8-word headers on the host
+ * (task_parse.v:1931-1940), DMAs the batches as they are, unpacks the nibble streams on the GPU
+ * (bsw_wire_pack_kernel) and runs everything queued as one device batch. */
+extern "C" int bsw_refbatch_submit(bsw_ctx *ctx, const uint32_t *in_words, uint32_t *out_words)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!in_words || !out_words) return fail(ctx->err, BSW_E_INVAL, "bsw_refbatch_submit: NULL argument");
+    int rc = busy_check(ctx, "bsw_refbatch_submit");
+    if (rc) return rc;
+    if (ctx->ref_queue.size() >= BSW_REFBATCH_MAX_INFLIGHT) return fail(ctx->err, BSW_E_BUSY, "%d task batches already in flight", BSW_REFBATCH_MAX_INFLIGHT);
+    if (in_words[2] > BSW_REFBATCH_MAX_TASKS) return fail(ctx->err, BSW_E_LIMIT, "task batch announces %u tasks (> %d)", in_words[2], BSW_REFBATCH_MAX_TASKS);
+    ctx->ref_queue.push_back(refbatch_req{in_words, out_words});
+    return BSW_OK;
+}
+
+/* one run of queued batches [q0, q1) that share G0/G1 */
+static int refbatch_group(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int zdrop)
+{
+    errs &e = ctx->err;
+    stage_t &st = ctx->small;
+    hipStream_t s = ctx->stream0();
+    const uint32_t *W0 = ctx->ref_queue[q0].in;
+    bsw_params p;
+    bsw_default_params(&p);                       /* matrix a=1,b=4,N=-1 is hard-wired (sw_extend.v:1915-1940) */
+    p.o_del = (int)(W0[0] & 0xff); p.e_del = (int)((W0[0] >> 8) & 0xff);
+    p.o_ins = (int)((W0[0] >> 16) & 0xff); p.e_ins = (int)((W0[0] >> 24) & 0xff);
+    p.pen_clip5 = (int)(W0[1] & 0xff); p.pen_clip3 = (int)((W0[1] >> 8) & 0xff);
+    p.w = (int)((W0[1] >> 16) & 0xff);
+    p.zdrop = zdrop; p.variant = variant; p.max_band_try = 2;
+    bsw_dparams dp;
+    int rc = check_params(e, &p, &dp);
+    if (rc) return rc;
+    size_t n = 0;
+    for (size_t q = q0; q < q1; ++q) n += ctx->ref_queue[q].in[2];
+    if (n == 0) {
+        for (size_t q = q0; q < q1; ++q) memset(ctx->ref_queue[q].out, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
+        return BSW_OK;
+    }
+    const size_t nb = q1 - q0, wire_words = nb * (size_t)BSW_REFBATCH_IN_WORDS;
+    hipError_t he;
+    if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_woff.reserve(n + 1)) != hipSuccess ||
+        (he = st.h_out.reserve(n + 1)) != hipSuccess || (he = st.h_raw.reserve(wire_words * 4 + RAW_SLACK)) != hipSuccess)
+        return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    /* headers -> task records (host: 8 words per task) */
+    chunk_info ci;
+    rc = fill_binparams(e, &p, ctx->cfg.kernel, ci.bp);
+    if (rc) return rc;
+    bsw_binparams &bp = ci.bp;
+    uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0};
+    uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0;
+    uint64_t acc = 0;
+    size_t ti = 0;
+    for (size_t q = q0; q < q1; ++q) {
+        const uint32_t *W = ctx->ref_queue[q].in;
+        const uint32_t nt = W[2];
+        if (nt == 0) continue;
+        const int64_t base = (int64_t)(8 + 8 * nt) - (int64_t)W[8 + 2];
+        for (uint32_t i = 0; i < nt; ++i, ++ti) {
+            const uint32_t *H = &W[8 + 8 * i];
+            bsw_dtask &d = st.h_tasks.p[ti];
+            bsw_wireoff &wo = st.h_woff.p[ti];
+            memset(&d, 0, sizeof(d));
+            const int lq = (int)(H[0] & 0xff), lt = (int)((H[0] >> 16) & 0x7ff), rq = (int)(H[1] & 0xff), rt = (int)((H[1] >> 16) & 0x7ff);
+            const int64_t pos = base + (int64_t)H[2];
+            if (pos < 8 + 8 * (int64_t)nt || pos + (lq + rq + lt + rt + 7) / 8 > BSW_REFBATCH_IN_WORDS)
+                return fail(e, BSW_E_INVAL, "malformed task batch (task %u: data position)", i);
+            const int h0 = (int)(H[4] & 0xff);
+            if (h0 <= 0) return fail(e, BSW_E_INVAL, "task batch: task %u has h0 <= 0", i);
+            wo.nib = ((uint64_t)(q - q0) * BSW_REFBATCH_IN_WORDS + (uint64_t)pos) * 8u;
+            wo.lqlen = (uint16_t)lq; wo.rqlen = (uint16_t)rq; wo.ltlen = (uint16_t)lt; wo.rtlen = (uint16_t)rt;
+            if (lq) { d.lq_off = (uint32_t)acc; acc += nwords(lq); d.lt_off = (uint32_t)acc; acc += nwords(lt); }
+            if (rq) { d.rq_off = (uint32_t)acc; acc += nwords(rq); d.rt_off = (uint32_t)acc; acc += nwords(rt); }
+            d.lqlen = (uint16_t)lq; d.rqlen = (uint16_t)rq; d.ltlen = (uint16_t)lt; d.rtlen = (uint16_t)rt;
+            /* H5/H6 = {max_del[31:16], max_ins[15:0]}: the band limit the RTL applies (proc_element.v:925,933) */
+            auto lim = [](uint32_t h) {
+                const int mi = (int)(int16_t)(h & 0xffff), md = (int)(int16_t)(h >> 16);
+                const int l = mi < md ? mi : md;
+                return (uint16_t)(l < 0 ? 0 : l);
+            };
+            d.wlim_l = lim(H[5]); d.wlim_r = lim(H[6]);
+            d.h0 = h0; d.init_score = (int)(int16_t)(H[3] & 0xffff); d.qbeg = (int)(H[3] >> 16); d.tag = H[7];
+            const int wc = bsw_wave_class_of(&bp, std::max(lq, rq));
+            ++cw_all[wc];
+            const int bits = bsw_seed_lane_bits(&bp, lq, rq, h0);
+            if (!bits) ++cw[wc];
+            else { ++n_lane; if (lq) ++cl[bsw_side_lane_class(&bp, bits, lq)]; if (rq) ++cr[bsw_side_lane_class(&bp, bits, rq)]; }
+        }
+        memcpy((uint32_t *)st.h_raw.p + (q - q0) * (size_t)BSW_REFBATCH_IN_WORDS, W, BSW_REFBATCH_IN_WORDS * sizeof(uint32_t));
+    }
+    if (ctx->cfg.kernel == BSW_KERNEL_AUTO && n_lane < LANE_AUTO_MIN) bp.lane_on = 0;
+    if (!bp.lane_on) { memcpy(cw, cw_all, sizeof(cw)); memset(cl, 0, sizeof(cl)); memset(cr, 0, sizeof(cr)); n_lane = 0; }
+    batch_plan &pl = ci.plan;
+    pl = batch_plan();
+    for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) pl.wave_start[c + 1] = pl.wave_start[c] + cw[c];
+    uint32_t cur = pl.wave_start[BSW_MAX_WAVE_CLASSES];
+    pl.lane_all_off = cur; pl.lane_all_cnt = n_lane; cur += n_lane;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { pl.laneL_off[c] = cur; cur += cl[c]; }
+    pl.laneL_off[BSW_MAX_LANE_CLASSES] = cur;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { pl.laneR_off[c] = cur; cur += cr[c]; }
+    pl.laneR_off[BSW_MAX_LANE_CLASSES] = cur;
+    pl.redo_off = cur; pl.order_len = cur + n_lane;
+    pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
+    memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
+    bp.lane_all_off = pl.lane_all_off;
+    memcpy(bp.laneL_off, pl.laneL_off, sizeof(bp.laneL_off));
+    memcpy(bp.laneR_off, pl.laneR_off, sizeof(bp.laneR_off));
+    /* device: wire batches -> seq, bins, DP kernels, results */
+    if ((he = st.d_raw.reserve(wire_words * 4 + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve((size_t)acc + 4)) != hipSuccess ||
+        (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_woff.reserve(n + 1)) != hipSuccess ||
+        (he = st.d_order.reserve(order_capacity(n))) != hipSuccess || (he = st.d_bins.reserve(BSW_BIN_WORDS)) != hipSuccess ||
+        (he = st.d_out.reserve(n + 1)) != hipSuccess)
+        return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    HIPCHK(e, hipMemcpyAsync(st.d_raw.p, st.h_raw.p, wire_words * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_woff.p, st.h_woff.p, n * sizeof(bsw_wireoff), hipMemcpyHostToDevice, s));
+    HIPCHK(e, bsw::launch_wire_pack((const uint32_t *)st.d_raw.p, st.d_tasks.p, st.d_woff.p, (uint32_t)n, st.d_seq.p, s));
+    HIPCHK(e, bsw::launch_bin(bp, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
+    rc = enqueue_batch(e, dp, variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, pl, st.d_out.p, s, nullptr);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
+    rc = sync_stream(ctx, e, s, ctx->devs[0].events[0]);
+    if (rc) return rc;
+    ti = 0;
+    for (size_t q = q0; q < q1; ++q) {
+        const uint32_t nt = ctx->ref_queue[q].in[2];
+        memset(ctx->ref_queue[q].out, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
+        rc = bsw_refbatch_encode_results(st.h_out.p + ti, nt, ctx->ref_queue[q].out);
+        if (rc < 0) return fail(e, rc, "result batch encode");
+        ti += nt;
+    }
+    return BSW_OK;
+}
+
+extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
+{
+    if (!ctx) return BSW_E_INVAL;
+    int rc = busy_check(ctx, "bsw_refbatch_wait");
+    if (rc) { ctx->ref_queue.clear(); return rc; }
+    errs &e = ctx->err;
+    if (variant != BSW_VARIANT_H && variant != BSW_VARIANT_M) { ctx->ref_queue.clear(); return fail(e, BSW_E_INVAL, "bad variant"); }
+    if (hipSetDevice(ctx->device0()) != hipSuccess) { ctx->ref_queue.clear(); return fail(e, BSW_E_HIP, "hipSetDevice"); }
+    const size_t nq = ctx->ref_queue.size();
+    for (size_t q0 = 0; q0 < nq;) {
+        size_t q1 = q0 + 1;
+        while (q1 < nq && ctx->ref_queue[q1].in[0] == ctx->ref_queue[q0].in[0] && ctx->ref_queue[q1].in[1] == ctx->ref_queue[q0].in[1]) ++q1;
+        rc = refbatch_group(ctx, q0, q1, variant, zdrop);
+        if (rc) { ctx->ref_queue.clear(); return rc; }
+        q0 = q1;
+    }
+    ctx->ref_queue.clear();
+    return (int)nq;
+}
+
 extern "C" int bsw_refbatch_run(bsw_ctx *ctx, const uint32_t *in_words, uint32_t *out_words, int variant, int zdrop)
 {
-    if (!ctx || !in_words || !out_words) return fail(ctx, BSW_E_INVAL, "bsw_refbatch_run: NULL argument");
+    if (!ctx) return BSW_E_INVAL;
+    if (!ctx->ref_queue.empty()) return fail(ctx->err, BSW_E_BUSY, "bsw_refbatch_run: task batches are queued (call bsw_refbatch_wait)");
+    int rc = bsw_refbatch_submit(ctx, in_words, out_words);
+    if (rc) return rc;
     const uint32_t n = in_words[2];
-    if (n > BSW_REFBATCH_MAX_TASKS) return fail(ctx, BSW_E_LIMIT, "task batch announces %u tasks (> %d)", n, BSW_REFBATCH_MAX_TASKS);
-    bsw_params p;
-    std::vector<bsw_task> tasks(n ? n : 1);
-    std::vector<uint8_t> seqbuf((size_t)BSW_REFBATCH_IN_WORDS * 8 + 64);
-    int got = bsw_refbatch_decode(in_words, &p, tasks.data(), n, seqbuf.data(), seqbuf.size());
-    if (got < 0) return fail(ctx, got, "malformed task batch");
-    p.variant = variant; p.zdrop = zdrop;
-    std::vector<bsw_result> res((size_t)got ? (size_t)got : 1);
-    if (got) {
-        bsw_dev_batch *b = nullptr;
-        int rc = bsw_upload(ctx, &p, tasks.data(), (size_t)got, &b);
-        if (rc) return rc;
-        rc = bsw_run(ctx, b);
-        if (!rc) rc = bsw_download(ctx, b, res.data());
-        bsw_free_batch(ctx, b);
-        if (rc) return rc;
-    }
-    memset(out_words, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
-    return bsw_refbatch_encode_results(res.data(), (size_t)got, out_words);
+    rc = bsw_refbatch_wait(ctx, variant, zdrop);
+    return rc < 0 ? rc : (int)n;
 }

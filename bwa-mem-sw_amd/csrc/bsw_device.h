@@ -3,12 +3,15 @@
  * HIP kernels (internal; the public C ABI is include/bwa_sw_mi355.h).
  *
  * HBM layout of one device batch
+ *   raw   : uint8[]    the caller's byte-per-base sequences exactly as they arrived over PCIe
+ *                      (one DMA of a registered arena, or a gather into pinned staging);
+ *                      consumed once by bsw_pack_kernel, never read by the DP kernels
  *   seq   : uint64[]   all sequences, 4 bits per base, 16 bases per uint64, base k of
  *                      a word in bits [4k,4k+3]; every sequence starts on a word
  *                      boundary; codes 0..3 = ACGT, 4 = N (anything >4 is stored as 4)
  *   tasks : bsw_dtask[] one record per seed (the RTL's 8-word header H0..H7,
  *                      sw_pe_array_proc_element.v:807-933, widened past its 8-bit limits)
- *   order : uint32[]   launch order -> task index (bins sorted by the batch manager)
+ *   order : uint32[]   launch order -> task index (bins built on the device by bsw_bin_*)
  *   out   : bsw_result[] indexed by task index (task order, not completion order —
  *                      the RTL's fill_resulBuf emits completion order and needs the tag)
  */
@@ -18,6 +21,12 @@
 #include <stdint.h>
 #include "../../include/bwa_sw_mi355.h"
 
+#if defined(__HIPCC__) || defined(__HIP__)
+#define BSW_HD __host__ __device__ inline
+#else
+#define BSW_HD static inline
+#endif
+
 typedef struct bsw_dtask {
     uint32_t lq_off, lt_off, rq_off, rt_off;   /* word offsets into seq              */
     uint16_t lqlen, rqlen, ltlen, rtlen;
@@ -25,6 +34,11 @@ typedef struct bsw_dtask {
     int32_t  h0, init_score, qbeg;
     uint32_t tag;
 } bsw_dtask;                                   /* 44 bytes */
+
+/* where the four byte-per-base sequences of a seed start inside `raw` (bytes) */
+typedef struct bsw_rawoff {
+    uint32_t lq, lt, rq, rt;
+} bsw_rawoff;
 
 typedef struct bsw_dparams {
     int8_t  mat[25];
@@ -43,5 +57,50 @@ typedef struct bsw_fetch_desc {
 } bsw_fetch_desc;
 
 #define BSW_KEY_BITS 10                        /* column index bits in the arg-max key */
+
+/* ---- binning: which kernel class a seed goes to.  The host counts seeds per class with these
+ * functions (launch sizes), the device sorts with the same functions (bsw_stage_kernel.hip), so the
+ * two can never disagree. ---- */
+#define BSW_MAX_WAVE_CLASSES 8
+#define BSW_MAX_LANE_CLASSES 4
+#define BSW_LANE_QBINS       256               /* a lane class holds at most 256 eh[] columns */
+
+typedef struct bsw_binparams {
+    int32_t a;                                 /* match score (score range test)            */
+    int32_t lane_on;                           /* 0: every seed goes to the wave-per-task classes */
+    int32_t n_wave, n_lane;
+    int32_t wave_cols[BSW_MAX_WAVE_CLASSES];
+    int32_t lane_cols[BSW_MAX_LANE_CLASSES];
+    int32_t lane_bits[BSW_MAX_LANE_CLASSES];   /* 8 / 16: width of h and e in the lane class */
+    int32_t cols8, cols16;                     /* widest lane class per value width          */
+    /* offsets into `order` of every list the device fills */
+    uint32_t wave_start[BSW_MAX_WAVE_CLASSES + 1];
+    uint32_t lane_all_off;
+    uint32_t laneL_off[BSW_MAX_LANE_CLASSES + 1], laneR_off[BSW_MAX_LANE_CLASSES + 1];
+} bsw_binparams;
+
+/* value width of the lane kernel a seed may use: 0 = wave-per-task kernel */
+BSW_HD int bsw_seed_lane_bits(const bsw_binparams *bp, int lqlen, int rqlen, int h0)
+{
+    if (!bp->lane_on) return 0;
+    const int qm = lqlen > rqlen ? lqlen : rqlen;
+    const int64_t top = (int64_t)h0 + (int64_t)(lqlen + rqlen) * bp->a;   /* no H can exceed this */
+    if (top <= 255 && qm + 1 <= bp->cols8) return 8;
+    if (top < 65000 && qm + 1 <= bp->cols16) return 16;
+    return 0;
+}
+/* lane class of one side (query length q) of a seed with value width `bits`; -1: none */
+BSW_HD int bsw_side_lane_class(const bsw_binparams *bp, int bits, int q)
+{
+    for (int c = 0; c < bp->n_lane; ++c)
+        if (bp->lane_bits[c] == bits && q + 1 <= bp->lane_cols[c]) return c;
+    return -1;
+}
+BSW_HD int bsw_wave_class_of(const bsw_binparams *bp, int qmax)
+{
+    for (int c = 0; c < bp->n_wave; ++c)
+        if (qmax + 1 <= bp->wave_cols[c]) return c;
+    return -1;
+}
 
 #endif

@@ -70,10 +70,13 @@ int bsw_refbatch_encode(const bsw_params *p, const bsw_task *tasks, size_t n, ui
             H[2] = pos;
             H[3] = ((uint32_t)t->qbeg << 16) | ((uint32_t)t->init_score & 0xffffu);
             H[4] = (uint32_t)t->h0;
-            H[5] = ((uint32_t)gap_lim(t->lqlen, mx, p->pen_clip5, p->o_del, p->e_del) << 16) |
-                   (uint32_t)gap_lim(t->lqlen, mx, p->pen_clip5, p->o_ins, p->e_ins);
-            H[6] = ((uint32_t)gap_lim(t->rqlen, mx, p->pen_clip3, p->o_del, p->e_del) << 16) |
-                   (uint32_t)gap_lim(t->rqlen, mx, p->pen_clip3, p->o_ins, p->e_ins);
+            /* H5/H6: a task that carries its own band limits (wlim > 0) ships them as max_ins = max_del */
+            if (t->wlim_l > 0) { uint32_t l = (uint32_t)(t->wlim_l > 32767 ? 32767 : t->wlim_l); H[5] = (l << 16) | l; }
+            else H[5] = ((uint32_t)gap_lim(t->lqlen, mx, p->pen_clip5, p->o_del, p->e_del) << 16) |
+                        (uint32_t)gap_lim(t->lqlen, mx, p->pen_clip5, p->o_ins, p->e_ins);
+            if (t->wlim_r > 0) { uint32_t l = (uint32_t)(t->wlim_r > 32767 ? 32767 : t->wlim_r); H[6] = (l << 16) | l; }
+            else H[6] = ((uint32_t)gap_lim(t->rqlen, mx, p->pen_clip3, p->o_del, p->e_del) << 16) |
+                        (uint32_t)gap_lim(t->rqlen, mx, p->pen_clip3, p->o_ins, p->e_ins);
             H[7] = t->tag;
             src[0] = t->lquery; len[0] = t->lqlen; src[1] = t->rquery; len[1] = t->rqlen;
             src[2] = t->ltarget; len[2] = t->ltlen; src[3] = t->rtarget; len[3] = t->rtlen;
@@ -122,6 +125,16 @@ int bsw_refbatch_decode(const uint32_t *W, bsw_params *p, bsw_task *tasks, size_
         t->init_score = (int)(int16_t)(H[3] & 0xffff);
         t->h0 = (int)(H[4] & 0xff);
         t->tag = H[7];
+        /* H5/H6 {max_del[31:16], max_ins[15:0]}: the band limits the RTL applies (proc_element.v:925,933;
+         * sw_extend.v:1881,1890).  A non-positive limit (never written by bwa: both are >= 1) decodes as 1. */
+        {
+            int mi = (int)(int16_t)(H[5] & 0xffff), md = (int)(int16_t)(H[5] >> 16);
+            t->wlim_l = mi < md ? mi : md;
+            if (t->wlim_l < 1) t->wlim_l = 1;
+            mi = (int)(int16_t)(H[6] & 0xffff); md = (int)(int16_t)(H[6] >> 16);
+            t->wlim_r = mi < md ? mi : md;
+            if (t->wlim_r < 1) t->wlim_r = 1;
+        }
         len[0] = t->lqlen; len[1] = t->rqlen; len[2] = t->ltlen; len[3] = t->rtlen;
         if (pos < 8 + 8 * (int64_t)n ||
             pos + (len[0] + len[1] + len[2] + len[3] + 7) / 8 > BSW_REFBATCH_IN_WORDS) return BSW_E_INVAL;

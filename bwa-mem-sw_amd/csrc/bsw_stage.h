@@ -1,0 +1,39 @@
+/* bsw_stage.h — internal: launchers of the kernels in bsw_stage_kernel.hip / bsw_*_kernel.hip */
+#ifndef BSW_STAGE_H
+#define BSW_STAGE_H
+
+#include <hip/hip_runtime.h>
+#include "bsw_device.h"
+
+/* layout of the `bins` scratch array (uint32): per (side, lane class, query length) histogram -> cursor,
+ * then one cursor per wave class list, then the cursor of the list of all lane seeds */
+#define BSW_BIN_WAVE0   (2 * BSW_MAX_LANE_CLASSES * BSW_LANE_QBINS)
+#define BSW_BIN_LANEALL (BSW_BIN_WAVE0 + BSW_MAX_WAVE_CLASSES)
+#define BSW_BIN_WORDS   (BSW_BIN_LANEALL + 8)
+
+/* where a task's nibble stream starts inside the uploaded wire batches, and the four lengths in stream order */
+typedef struct bsw_wireoff {
+    uint64_t nib;
+    uint16_t lqlen, rqlen, ltlen, rtlen;
+} bsw_wireoff;
+
+namespace bsw {
+int wave_class_count();
+int wave_class_cols(int cls);
+hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
+                       const uint32_t *order, uint32_t n, const uint32_t *n_dev, bsw_result *out, hipStream_t s);
+int lane_class_count();
+int lane_class_cols(int cls);
+int lane_class_bits(int cls);
+hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
+                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
+hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
+                           bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, hipStream_t s);
+hipError_t launch_fetch(const uint8_t *pac, int64_t l_pac, const bsw_fetch_desc *desc, uint32_t nd, uint64_t *seq, hipStream_t s);
+hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, int skip_targets,
+                       uint64_t *seq, hipStream_t s);
+hipError_t launch_wire_pack(const uint32_t *wire, const bsw_dtask *tasks, const bsw_wireoff *woffs, uint32_t n, uint64_t *seq, hipStream_t s);
+hipError_t launch_bin(const bsw_binparams &bp, const bsw_dtask *tasks, uint32_t n, uint32_t *bins, uint32_t *order, hipStream_t s);
+}  // namespace bsw
+
+#endif

@@ -1,0 +1,259 @@
+/*
+ * bsw_stage_kernel.hip — device side of the batch manager: everything between "the caller's bytes
+ * have landed in HBM" and "the DP kernels can start".
+ *
+ * The reference's batch manager moves 256 KiB task batches into the PE arrays without a CPU in the
+ * loop (batch_manager.v:358-739, tbb.v:12-212) and its task parser hands tasks to PEs as they come
+ * (sw_pe_array_task_parse.v:1600-1648).  Here the host only validates lengths and DMAs the raw
+ * bytes; these kernels do the rest:
+ *   bsw_pack_kernel      byte-per-base -> 16 bases per uint64 (codes > 4 become 4 = N)
+ *   bsw_bin_count/scan/scatter   counting sort of the seeds into kernel bins: wave-per-task classes
+ *                        by eh[] columns per lane, lane bins per side by (class, query length
+ *                        descending) — BASELINE.json's "(qlen, tlen, band-width) bins"
+ *   bsw_wire_pack_kernel the reference's 256 KiB wire format (8 bases per 32-bit word, first base in
+ *                        bits [31:28], one nibble stream per task: proc_element.v:1638,1677) -> seq
+ * All three are HBM-bound byte/index work (no MFMA, nothing to tile): coalesced dword loads,
+ * v_alignbyte for the unaligned starts, LDS-privatised histograms.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bsw_device.h"
+#include "bsw_stage.h"
+
+namespace bsw {
+
+/* 8 base bytes (codes 0..4) -> 8 nibbles in the low 32 bits */
+__device__ __forceinline__ uint64_t squeeze8(uint64_t x)
+{
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return x;
+}
+
+/* codes 5..7 -> 4; bytes >= 8 are clamped bytewise (never produced by bwa) */
+__device__ __forceinline__ uint64_t clamp_codes(uint64_t x)
+{
+    if (x & 0xF8F8F8F8F8F8F8F8ull) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint64_t b = (x >> (8 * k)) & 0xff;
+            v |= (b > 4 ? 4ull : b) << (8 * k);
+        }
+        return v;
+    }
+    const uint64_t n = x & 0x0404040404040404ull;
+    return x & ~((n >> 1) | (n >> 2));
+}
+
+/* 16 lanes per sequence, 4 sequences per seed (leftQ, leftT, rightQ, rightT); lane k packs words k, k+16, ... */
+__global__ __launch_bounds__(256) void bsw_pack_kernel(const uint8_t *__restrict__ raw, const bsw_dtask *__restrict__ tasks,
+                                                       const bsw_rawoff *__restrict__ roff, const uint32_t n,
+                                                       const int skip_targets, uint64_t *__restrict__ seq)
+{
+    const uint32_t g = blockIdx.x * 16u + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    const uint32_t ti = g >> 2;
+    const int which = (int)(g & 3u);
+    if (ti >= n) return;
+    if (skip_targets && (which & 1)) return;
+    const bsw_dtask T = tasks[ti];
+    const bsw_rawoff R = roff[ti];
+    int len;
+    uint32_t woff, boff;
+    switch (which) {
+    case 0: len = T.lqlen; woff = T.lq_off; boff = R.lq; break;
+    case 1: len = T.lqlen ? T.ltlen : 0; woff = T.lt_off; boff = R.lt; break;
+    case 2: len = T.rqlen; woff = T.rq_off; boff = R.rq; break;
+    default: len = T.rqlen ? T.rtlen : 0; woff = T.rt_off; boff = R.rt; break;
+    }
+    const int nw = (len + 15) >> 4;
+    for (int k = l16; k < nw; k += 16) {
+        const uintptr_t a = (uintptr_t)(raw + boff) + 16u * (uint32_t)k;
+        const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
+        const uint32_t sh = (uint32_t)(a & 3u);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];   /* the raw buffer has >= 32 bytes of slack */
+        const uint32_t x0 = __builtin_amdgcn_alignbyte(d1, d0, sh), x1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        const uint32_t x2 = __builtin_amdgcn_alignbyte(d3, d2, sh), x3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+        uint64_t lo = (uint64_t)x0 | ((uint64_t)x1 << 32), hi = (uint64_t)x2 | ((uint64_t)x3 << 32);
+        const int valid = len - 16 * k;                     /* bases of this word */
+        if (valid < 16) {
+            if (valid <= 8) { hi = 0; lo = valid == 8 ? lo : lo & ((1ull << (8 * valid)) - 1ull); }
+            else hi &= (1ull << (8 * (valid - 8))) - 1ull;
+        }
+        lo = clamp_codes(lo);
+        hi = clamp_codes(hi);
+        seq[woff + (uint32_t)k] = squeeze8(lo) | (squeeze8(hi) << 32);
+    }
+}
+
+/* ---- binning ---- */
+__device__ __forceinline__ int bin_side(int side, int cls, int q) { return (side * BSW_MAX_LANE_CLASSES + cls) * BSW_LANE_QBINS + q; }
+
+struct seed_bins { int k0, k1, k2; };      /* class list, left-side bin, right-side bin (-1: none) */
+
+__device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const bsw_dtask &T)
+{
+    seed_bins s;
+    s.k1 = s.k2 = -1;
+    const int bits = bsw_seed_lane_bits(&bp, T.lqlen, T.rqlen, T.h0);
+    if (!bits) {
+        const int c = bsw_wave_class_of(&bp, T.lqlen > T.rqlen ? T.lqlen : T.rqlen);
+        s.k0 = BSW_BIN_WAVE0 + (c < 0 ? 0 : c);     /* c < 0 cannot happen: the host rejects such seeds */
+    } else {
+        s.k0 = BSW_BIN_LANEALL;
+        if (T.lqlen) s.k1 = bin_side(0, bsw_side_lane_class(&bp, bits, T.lqlen), T.lqlen);
+        if (T.rqlen) s.k2 = bin_side(1, bsw_side_lane_class(&bp, bits, T.rqlen), T.rqlen);
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void bsw_bin_count(const bsw_binparams bp, const bsw_dtask *__restrict__ tasks, const uint32_t n,
+                                                     uint32_t *__restrict__ bins)
+{
+    __shared__ uint32_t h[BSW_BIN_WAVE0];
+    for (int b = threadIdx.x; b < BSW_BIN_WAVE0; b += 256) h[b] = 0;
+    __syncthreads();
+    for (uint32_t ti = blockIdx.x * 256u + threadIdx.x; ti < n; ti += gridDim.x * 256u) {
+        const seed_bins s = seed_keys(bp, tasks[ti]);
+        if (s.k1 >= 0) atomicAdd(&h[s.k1], 1u);
+        if (s.k2 >= 0) atomicAdd(&h[s.k2], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < BSW_BIN_WAVE0; b += 256)
+        if (h[b]) atomicAdd(&bins[b], h[b]);
+}
+
+/* one block: per (side, lane class) turn the query-length histogram into start offsets, longest queries first
+ * (a wave then holds equal-length queries and the most work starts first) */
+__global__ __launch_bounds__(256) void bsw_bin_scan(const bsw_binparams bp, uint32_t *__restrict__ bins)
+{
+    __shared__ uint32_t sc[256];
+    const int t = threadIdx.x, q = 255 - t;
+    for (int side = 0; side < 2; ++side)
+        for (int c = 0; c < bp.n_lane; ++c) {
+            const int idx = bin_side(side, c, q);
+            const uint32_t v = bins[idx];
+            sc[t] = v;
+            __syncthreads();
+            for (int d = 1; d < 256; d <<= 1) {
+                const uint32_t add = t >= d ? sc[t - d] : 0u;
+                __syncthreads();
+                sc[t] += add;
+                __syncthreads();
+            }
+            const uint32_t base = side ? bp.laneR_off[c] : bp.laneL_off[c];
+            bins[idx] = base + sc[t] - v;
+            __syncthreads();
+        }
+    if (t < bp.n_wave) bins[BSW_BIN_WAVE0 + t] = bp.wave_start[t];
+    if (t == 0) bins[BSW_BIN_LANEALL] = bp.lane_all_off;
+}
+
+__global__ __launch_bounds__(256) void bsw_bin_scatter(const bsw_binparams bp, const bsw_dtask *__restrict__ tasks, const uint32_t n,
+                                                       uint32_t *__restrict__ bins, uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t cnt[BSW_BIN_WORDS], base[BSW_BIN_WORDS];
+    for (int b = threadIdx.x; b < BSW_BIN_WORDS; b += 256) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t ti = blockIdx.x * 256u + threadIdx.x;
+    seed_bins s;
+    s.k0 = s.k1 = s.k2 = -1;
+    uint32_t r0 = 0, r1 = 0, r2 = 0;
+    if (ti < n) {
+        s = seed_keys(bp, tasks[ti]);
+        r0 = atomicAdd(&cnt[s.k0], 1u);
+        if (s.k1 >= 0) r1 = atomicAdd(&cnt[s.k1], 1u);
+        if (s.k2 >= 0) r2 = atomicAdd(&cnt[s.k2], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < BSW_BIN_WORDS; b += 256)
+        if (cnt[b]) base[b] = atomicAdd(&bins[b], cnt[b]);
+    __syncthreads();
+    if (ti < n) {
+        order[base[s.k0] + r0] = ti;
+        if (s.k1 >= 0) order[base[s.k1] + r1] = ti;
+        if (s.k2 >= 0) order[base[s.k2] + r2] = ti;
+    }
+}
+
+/* ---- reference wire format -> seq (F1).  One 16-lane group per sequence, as in bsw_pack_kernel.
+ * `wire` holds whole 256 KiB task batches back to back; nib = nibble offset of the sequence's first base
+ * counted from the start of `wire` (8 nibbles per 32-bit word, first base of a word in bits [31:28]). ---- */
+__device__ __forceinline__ uint32_t rev_nibbles(uint32_t w)
+{
+    w = __builtin_bswap32(w);
+    return ((w >> 4) & 0x0F0F0F0Fu) | ((w & 0x0F0F0F0Fu) << 4);
+}
+
+__global__ __launch_bounds__(256) void bsw_wire_pack_kernel(const uint32_t *__restrict__ wire, const bsw_dtask *__restrict__ tasks,
+                                                            const bsw_wireoff *__restrict__ woffs, const uint32_t n,
+                                                            uint64_t *__restrict__ seq)
+{
+    const uint32_t g = blockIdx.x * 16u + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    const uint32_t ti = g >> 2;
+    const int which = (int)(g & 3u);
+    if (ti >= n) return;
+    const bsw_dtask T = tasks[ti];
+    const bsw_wireoff W = woffs[ti];
+    int len;
+    uint32_t woff;
+    uint64_t nib;                                           /* stream order: leftQ, rightQ, leftT, rightT */
+    switch (which) {
+    case 0: len = T.lqlen; woff = T.lq_off; nib = W.nib; break;
+    case 1: len = T.lqlen ? T.ltlen : 0; woff = T.lt_off; nib = W.nib + W.lqlen + W.rqlen; break;
+    case 2: len = T.rqlen; woff = T.rq_off; nib = W.nib + W.lqlen; break;
+    default: len = T.rqlen ? T.rtlen : 0; woff = T.rt_off; nib = W.nib + W.lqlen + W.rqlen + W.ltlen; break;
+    }
+    const int nw = (len + 15) >> 4;
+    for (int k = l16; k < nw; k += 16) {
+        const uint64_t nb = nib + 16u * (uint64_t)k;
+        const uint32_t *q = wire + (nb >> 3);
+        const uint32_t sh = (uint32_t)(nb & 7u) * 4u;
+        /* after rev_nibbles, base j of a wire word sits in bits [4j,4j+3] — the seq layout */
+        const uint64_t a0 = rev_nibbles(q[0]), a1 = rev_nibbles(q[1]), a2 = rev_nibbles(q[2]);
+        const uint64_t lo64 = a0 | (a1 << 32);
+        uint64_t v = sh ? (lo64 >> sh) | (a2 << (64 - sh)) : lo64;
+        const int valid = len - 16 * k;
+        if (valid < 16) v &= (1ull << (4 * valid)) - 1ull;
+        /* nibble codes > 4 -> 4 */
+        const uint64_t big = ((v >> 3) | ((v >> 2) & ((v >> 1) | v))) & 0x1111111111111111ull;   /* 1 where nibble > 4 */
+        v = (v & ~(big * 0xFull)) | (big << 2);
+        seq[woff + (uint32_t)k] = v;
+    }
+}
+
+/* ---- launchers ---- */
+hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, int skip_targets,
+                       uint64_t *seq, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t groups = n * 4u;
+    hipLaunchKernelGGL(bsw_pack_kernel, dim3((groups + 15u) / 16u), dim3(256), 0, s, raw, tasks, roff, n, skip_targets, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_wire_pack(const uint32_t *wire, const bsw_dtask *tasks, const bsw_wireoff *woffs, uint32_t n, uint64_t *seq, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t groups = n * 4u;
+    hipLaunchKernelGGL(bsw_wire_pack_kernel, dim3((groups + 15u) / 16u), dim3(256), 0, s, wire, tasks, woffs, n, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_bin(const bsw_binparams &bp, const bsw_dtask *tasks, uint32_t n, uint32_t *bins, uint32_t *order, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(bins, 0, BSW_BIN_WORDS * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    uint32_t blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(bsw_bin_count, dim3(blocks > 1024u ? 1024u : blocks), dim3(256), 0, s, bp, tasks, n, bins);
+    hipLaunchKernelGGL(bsw_bin_scan, dim3(1), dim3(256), 0, s, bp, bins);
+    hipLaunchKernelGGL(bsw_bin_scatter, dim3(blocks), dim3(256), 0, s, bp, tasks, n, bins, order);
+    return hipGetLastError();
+}
+
+}  // namespace bsw

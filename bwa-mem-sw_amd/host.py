@@ -19,7 +19,8 @@ PARAMS = np.dtype([("mat", "i1", (25,)), ("_pad", "i1", (3,)), ("o_del", "<i4"),
                    ("pen_clip3", "<i4"), ("zdrop", "<i4"), ("max_band_try", "<i4"), ("variant", "<i4")])
 TASK = np.dtype([("lquery", "<u8"), ("ltarget", "<u8"), ("rquery", "<u8"), ("rtarget", "<u8"),
                  ("lqlen", "<i4"), ("ltlen", "<i4"), ("rqlen", "<i4"), ("rtlen", "<i4"),
-                 ("h0", "<i4"), ("init_score", "<i4"), ("qbeg", "<i4"), ("tag", "<u4")])
+                 ("h0", "<i4"), ("init_score", "<i4"), ("qbeg", "<i4"), ("tag", "<u4"),
+                 ("wlim_l", "<i4"), ("wlim_r", "<i4")])
 EXT = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "<i4"), ("gscore", "<i4"),
                 ("max_off", "<i4"), ("aw", "<i4"), ("cells", "<u4")])
 RESULT = np.dtype([("tag", "<u4"), ("qb", "<i4"), ("qe", "<i4"), ("rb", "<i4"), ("re", "<i4"),
@@ -34,10 +35,12 @@ ALNREG = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), (
                    ("w", "<i4"), ("_pad", "<i4")])
 REF_TASK = np.dtype([("query", "<u8"), ("l_query", "<i4"), ("init_score", "<i4"), ("seed", SEED),
                      ("rmax0", "<i8"), ("rmax1", "<i8"), ("tag", "<u4"), ("_pad", "<u4")])
+MAX_DEVICES = 16
 CONFIG = np.dtype([("device", "<i4"), ("kernel", "<i4"), ("streams", "<i4"), ("pack_threads", "<i4"),
-                   ("chunk_tasks", "<u8")])
-assert PARAMS.itemsize == 68 and TASK.itemsize == 64 and EXT.itemsize == 32 and RESULT.itemsize == 96
-assert EXT_TASK.itemsize == 40 and SYNTH.itemsize == 72 and CONFIG.itemsize == 24 and REF_TASK.itemsize == 56
+                   ("chunk_tasks", "<u8"), ("n_devices", "<i4"), ("devices", "<i4", (MAX_DEVICES,)),
+                   ("timeout_ms", "<i4")])
+assert PARAMS.itemsize == 68 and TASK.itemsize == 72 and EXT.itemsize == 32 and RESULT.itemsize == 96
+assert EXT_TASK.itemsize == 40 and SYNTH.itemsize == 72 and CONFIG.itemsize == 96 and REF_TASK.itemsize == 56
 
 REFBATCH_IN_WORDS, REFBATCH_OUT_WORDS, REFBATCH_MAX_TASKS = 65536, 4096, 819
 KERNEL_AUTO, KERNEL_WAVE, KERNEL_LANE = 0, 1, 2
@@ -96,6 +99,12 @@ def lib():
             "bsw_refbatch_encode_results": (C.c_int, [vp, sz, vp]),
             "bsw_refbatch_decode_results": (C.c_int, [vp, sz, vp]),
             "bsw_refbatch_run": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+            "bsw_refbatch_submit": (C.c_int, [vp, vp, vp]),
+            "bsw_refbatch_wait": (C.c_int, [vp, C.c_int, C.c_int]),
+            "bsw_host_alloc": (vp, [sz]), "bsw_host_free": (None, [vp]),
+            "bsw_host_register": (C.c_int, [vp, sz]), "bsw_host_unregister": (C.c_int, [vp]),
+            "bsw_batch_order": (C.c_int, [vp, vp, vp, vp]),
+            "bsw_scalar_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
             "bsw_ref_upload": (C.c_int, [vp, vp, C.c_int64, C.POINTER(vp)]),
             "bsw_ref_free": (None, [vp, vp]),
             "bsw_upload_ref": (C.c_int, [vp, vp, vp, vp, sz, C.POINTER(vp)]),
@@ -121,7 +130,8 @@ def lib():
     return _lib
 
 
-EXPORTS = ["ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_default_params", "bsw_default_config",
+EXPORTS = ["ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_scalar_stats", "bsw_host_alloc", "bsw_host_free",
+           "bsw_host_register", "bsw_host_unregister", "bsw_batch_order", "bsw_refbatch_submit", "bsw_refbatch_wait", "bsw_default_params", "bsw_default_config",
            "bsw_device_count", "bsw_create", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
@@ -148,8 +158,19 @@ def bwa_matrix(a=1, b=4, n=-1):
     return m.reshape(25)
 
 
-def synth_tasks(n, **spec):
-    """Generate n synthetic seeds.  Returns (tasks, arena); keep arena alive."""
+def synth_arena_bound(n, **spec):
+    s = np.zeros(1, dtype=SYNTH)
+    d = dict(seed=1, read_len=150, seed_len_min=19, seed_len_max=19, seed_at_start=1, sub_rate=0.01,
+             indel_rate=0.001, n_rate=0.0, junk_frac=0.0, a=1, w=100, o=6, e=1)
+    d.update(spec)
+    for k, v in d.items():
+        s[k] = v
+    return int(lib().bsw_synth_arena_bound(s.ctypes.data, n))
+
+
+def synth_tasks(n, arena=None, **spec):
+    """Generate n synthetic seeds.  Returns (tasks, arena); keep arena alive.
+    arena: optional uint8 buffer to generate into (e.g. HostArena(...).u8 for DMA-direct submits)."""
     s = np.zeros(1, dtype=SYNTH)
     d = dict(seed=1, read_len=150, seed_len_min=19, seed_len_max=19, seed_at_start=1, sub_rate=0.01,
              indel_rate=0.001, n_rate=0.0, junk_frac=0.0, a=1, w=100, o=6, e=1)
@@ -158,7 +179,10 @@ def synth_tasks(n, **spec):
         s[k] = v
     L = lib()
     bound = L.bsw_synth_arena_bound(s.ctypes.data, n)
-    arena = np.zeros(bound, dtype=np.uint8)
+    if arena is None:
+        arena = np.zeros(bound, dtype=np.uint8)
+    elif arena.size < bound:
+        raise ValueError("arena too small: need %d bytes" % bound)
     tasks = np.zeros(n, dtype=TASK)
     used = L.bsw_synth_generate(s.ctypes.data, n, tasks.ctypes.data, arena.ctypes.data, arena.size)
     if used < 0:
@@ -207,10 +231,17 @@ class DeviceBatch:
 class BswContext:
     """One GPU context = one of the reference's PE arrays behind its batch manager."""
 
-    def __init__(self, device=0, kernel=KERNEL_AUTO, streams=4, pack_threads=16, chunk_tasks=65536):
+    def __init__(self, device=0, kernel=KERNEL_AUTO, streams=4, pack_threads=4, chunk_tasks=65536, devices=None,
+                 timeout_ms=0):
         cfg = np.zeros(1, dtype=CONFIG)
+        lib().bsw_default_config(cfg.ctypes.data)
         cfg["device"], cfg["kernel"], cfg["streams"] = device, kernel, streams
         cfg["pack_threads"], cfg["chunk_tasks"] = pack_threads, chunk_tasks
+        if devices is not None:                 # one context over several GPUs: chunk k -> devices[k % len(devices)]
+            cfg["n_devices"] = len(devices)
+            cfg["devices"][0, :len(devices)] = devices
+        if timeout_ms:
+            cfg["timeout_ms"] = timeout_ms
         h = C.c_void_p()
         rc = lib().bsw_create(cfg.ctypes.data, C.byref(h))
         if rc:
@@ -286,6 +317,25 @@ class BswContext:
         self._chk(lib().bsw_download(self.handle, batch.handle, out.ctypes.data), "bsw_download")
         return out
 
+    def batch_order(self, batch):
+        """Launch order the device-side binning produced (order, seg) — same layout as plan_batch."""
+        order = np.zeros(4 * batch.n + 16, dtype=np.uint32)
+        seg = np.zeros(PLAN_SEGS + 1, dtype=np.uint32)
+        self._chk(lib().bsw_batch_order(self.handle, batch.handle, order.ctypes.data, seg.ctypes.data), "bsw_batch_order")
+        return order, seg
+
+    def refbatch_submit(self, in_words, out_words):
+        """Queue one 256 KiB task batch; both arrays must stay alive until refbatch_wait()."""
+        assert in_words.dtype == np.uint32 and in_words.size == REFBATCH_IN_WORDS and in_words.flags.c_contiguous
+        assert out_words.dtype == np.uint32 and out_words.size == REFBATCH_OUT_WORDS and out_words.flags.c_contiguous
+        self._chk(lib().bsw_refbatch_submit(self.handle, in_words.ctypes.data, out_words.ctypes.data), "bsw_refbatch_submit")
+
+    def refbatch_wait(self, variant=VARIANT_H, zdrop=0):
+        rc = lib().bsw_refbatch_wait(self.handle, variant, zdrop)
+        if rc < 0:
+            self._chk(rc, "bsw_refbatch_wait")
+        return rc
+
     # seeds against a device-resident 2-bit reference (F3)
     def ref_upload(self, pac, l_pac):
         pac = np.ascontiguousarray(pac, dtype=np.uint8)
@@ -309,6 +359,42 @@ class BswContext:
         if rc < 0:
             self._chk(rc, "bsw_refbatch_run")
         return out, rc
+
+
+class HostArena:
+    """Pinned (DMA-able) host memory from bsw_host_alloc, viewed as a numpy array.  Sequences and result
+    arrays kept in such memory cross PCIe without a host copy (bsw_submit's direct path)."""
+
+    def __init__(self, nbytes):
+        self.ptr = lib().bsw_host_alloc(nbytes)
+        if not self.ptr:
+            raise BswError(-5, "bsw_host_alloc(%d)" % nbytes)
+        self.nbytes = nbytes
+        self.u8 = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def view(self, dtype, count, offset=0):
+        return self.u8[offset:offset + count * np.dtype(dtype).itemsize].view(dtype)
+
+    def free(self):
+        if self.ptr:
+            self.u8 = None
+            lib().bsw_host_free(self.ptr)
+            self.ptr = None
+
+
+def host_register(arr):
+    """Pin an existing numpy array for DMA (bsw_host_register); returns the rc."""
+    return lib().bsw_host_register(arr.ctypes.data, arr.nbytes)
+
+
+def host_unregister(arr):
+    return lib().bsw_host_unregister(arr.ctypes.data)
+
+
+def scalar_stats():
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    lib().bsw_scalar_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def refbatch_encode(params, tasks):
@@ -351,7 +437,8 @@ PLAN_SEGS = 26
 
 
 def plan_batch(params, tasks, kernel=KERNEL_AUTO, pack_threads=1):
-    """Batch manager's launch plan for a task batch (host only).  Returns (order, seg, seq_words)."""
+    """Batch manager's launch plan for a task batch (host only; the order is the host replay of the device's
+    binning rules).  Returns (order, seg, seq_words)."""
     order = np.zeros(4 * len(tasks) + 16, dtype=np.uint32)
     seg = np.zeros(PLAN_SEGS + 1, dtype=np.uint32)
     w = lib().bsw_plan_batch(params.ctypes.data, tasks.ctypes.data, len(tasks), kernel, pack_threads, order.ctypes.data, seg.ctypes.data)

@@ -84,6 +84,10 @@ typedef struct bsw_task {
     int32_t  init_score;    /* a->score before the left ext; bwa: -1 (H3 low)    */
     int32_t  qbeg;          /* s->qbeg                          (H3 high)        */
     uint32_t tag;           /* opaque, echoed back              (H7 -> R0)       */
+    /* Host-supplied band limits min(max_ins, max_del) per side — the RTL's header words H5 / H6
+     * (sw_pe_array_proc_element.v:925,933; applied at sw_pe_array_sw_extend.v:1881,1890).
+     * 0 = let the library compute them with bwa's formula from the scoring parameters. */
+    int32_t  wlim_l, wlim_r;
 } bsw_task;
 
 /* Raw outputs of the last ksw_extend2 pass of one side (K9) + bookkeeping. */
@@ -111,12 +115,22 @@ typedef struct bsw_ext_task {
     int32_t w, end_bonus, h0;
 } bsw_ext_task;
 
+#define BSW_MAX_DEVICES 16
 typedef struct bsw_config {
-    int32_t device;         /* HIP device ordinal                                */
+    int32_t device;         /* HIP device ordinal (used when n_devices == 0)      */
     int32_t kernel;         /* BSW_KERNEL_*                                      */
-    int32_t streams;        /* staging slots = streams = pipeline threads of bsw_submit (1..8, def 4) */
-    int32_t pack_threads;   /* host packer threads, shared by the slots (def 16)  */
+    int32_t streams;        /* staging slots per device = streams = pipeline threads of bsw_submit (1..8, def 4) */
+    int32_t pack_threads;   /* extra host threads that gather sequences which are NOT in registered memory
+                               into pinned staging, shared by the slots (def 4; registered arenas need none) */
     size_t  chunk_tasks;    /* tasks per H2D/launch chunk in bsw_submit (def 64Ki) */
+    /* One context can drive several GPUs, as the reference's batch manager drives its 4 PE arrays
+     * round-robin (batch_manager.v:343-348,418; bwa_mem_sw.v:162): chunk k of a bsw_submit goes to
+     * devices[k mod n_devices].  n_devices == 0 means the single `device` above.  The same ordinal
+     * may appear more than once (more slots on that GPU). */
+    int32_t n_devices;
+    int32_t devices[BSW_MAX_DEVICES];
+    int32_t timeout_ms;     /* watchdog on every wait for the GPU (def 120000); on expiry the call fails
+                               with BSW_E_HIP and the context is dead (every later call fails fast)  */
 } bsw_config;
 
 #define BSW_KERNEL_AUTO  0  /* per-bin choice (batch manager)                    */
@@ -126,7 +140,11 @@ typedef struct bsw_config {
 typedef struct bsw_ctx bsw_ctx;
 typedef struct bsw_dev_batch bsw_dev_batch;
 
-/* ---- drop-in scalar ABI (bwa ksw.h).  Each call is a 1-task GPU launch. ---- */
+/* ---- drop-in scalar ABI (bwa ksw.h).  Thread-safe: concurrent callers (bwa mem -t N worker threads)
+ * are coalesced into one device batch per round trip (leader/follower; no per-call allocation).
+ * Contract at the edges: h0 <= 0 or qlen <= 0 (outside bwa's assert(h0 > 0) domain) returns
+ * max(h0,0) with qle = tle = gtle = 0, gscore = -1, max_off = 0 without touching the GPU; on a device
+ * failure the call prints the reason to stderr, writes the same neutral outputs and returns -1. ---- */
 int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
                 int m, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins,
                 int w, int end_bonus, int zdrop, int h0,
@@ -137,6 +155,8 @@ int ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
                int *qle, int *tle, int *gtle, int *gscore, int *max_off);
 /* recurrence variant used by ksw_extend/ksw_extend2 (process-wide, default H) */
 void bsw_set_default_variant(int variant);
+/* calls served / device round trips made by the scalar ABI so far (their ratio = mean coalescing factor) */
+void bsw_scalar_stats(uint64_t *calls, uint64_t *trips);
 
 /* ---- batch API ------------------------------------------------------------ */
 void     bsw_default_params(bsw_params *p);          /* bwa defaults a=1,b=4,o=6,e=1,w=100,clip=5,zdrop=100 */
@@ -146,9 +166,18 @@ int      bsw_create(const bsw_config *cfg, bsw_ctx **out);
 void     bsw_destroy(bsw_ctx *ctx);
 const char *bsw_last_error(const bsw_ctx *ctx);      /* text of the last failure  */
 
-/* Asynchronous: bins + packs tasks into pinned staging, streams them to the
- * device in chunks, launches, copies results back into out[] in TASK ORDER.
- * out[] and the task sequences must stay valid until bsw_wait returns.        */
+/* ---- host memory the GPU can DMA directly.  Sequences and result arrays that live in memory obtained
+ * from bsw_host_alloc (or registered with bsw_host_register) cross PCIe with NO host copy: bsw_submit
+ * DMAs the byte-per-base arena of a chunk as it is and packs / bins it on the GPU.  Anything else is first
+ * gathered into pinned staging by `pack_threads` host threads (correct, but host-bound).  Process-wide. ---- */
+void    *bsw_host_alloc(size_t bytes);
+void     bsw_host_free(void *p);
+int      bsw_host_register(void *p, size_t bytes);
+int      bsw_host_unregister(void *p);
+
+/* Asynchronous: validates lengths, DMAs the raw sequences to the device in chunks (chunk k ->
+ * device k mod n_devices), packs + bins them there, launches, copies results back into out[] in
+ * TASK ORDER.  out[] and the task sequences must stay valid until bsw_wait returns.        */
 int      bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out);
 int      bsw_wait(bsw_ctx *ctx);
 /* Batched plain ksw_extend2 (one pass each, w/end_bonus/h0 per task); synchronous. */
@@ -160,6 +189,9 @@ int      bsw_run(bsw_ctx *ctx, bsw_dev_batch *b);          /* enqueue kernels on
 int      bsw_sync(bsw_ctx *ctx);                            /* hipStreamSynchronize        */
 int      bsw_download(bsw_ctx *ctx, bsw_dev_batch *b, bsw_result *out); /* task order      */
 int      bsw_batch_info(const bsw_dev_batch *b, uint64_t *n_tasks, uint64_t *in_bytes, uint64_t *out_bytes, uint64_t *n_launches);
+/* the launch order the device-side binning produced for a resident batch (same layout as bsw_plan_batch:
+ * order[] capacity 4*n+16, seg[BSW_PLAN_SEGS+1]); for tests and tools */
+int      bsw_batch_order(bsw_ctx *ctx, const bsw_dev_batch *b, uint32_t *order, uint32_t *seg);
 /* time of the kernels of the last bsw_run, measured with hipEvents on the
  * library's own stream; valid after bsw_sync.                                  */
 int      bsw_last_run_ms(bsw_ctx *ctx, float *ms);
@@ -168,8 +200,11 @@ int      bsw_last_run_ms(bsw_ctx *ctx, float *ms);
 int      bsw_run_history(bsw_ctx *ctx, float *ms, int cap);
 void     bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b);
 
-/* ---- batch plan (host only, no GPU needed): how the batch manager would cut tasks[0..n) into launches.
- * order[] (capacity 4*n+16) receives the launch order; seg[] receives BSW_PLAN_SEGS+1 offsets into order[]:
+/* ---- batch plan (host only, no GPU needed): how the batch manager cuts tasks[0..n) into launches.
+ * The device sorts the seeds (bsw_stage_kernel.hip); the host only counts them per class, with the same
+ * class functions, to size the launches.  order[] (capacity 4*n+16, may be NULL) receives a launch order
+ * built on the host with the device's rules (inside one query length the device's order is arbitrary);
+ * seg[] receives BSW_PLAN_SEGS+1 offsets into order[]:
  * segments 0..7 = wave-per-task classes (64,128,192,256,512,1024 columns, then 2 unused), 8 = all lane seeds,
  * 9..16 = lane left sides per lane class, 17..24 = lane right sides per lane class, 25 = redo list space.
  * kernel = BSW_KERNEL_*.  Returns the number of sequence words the batch needs, or <0. ---- */
@@ -192,6 +227,15 @@ int      bsw_refbatch_decode_results(const uint32_t *words, size_t n, bsw_result
 /* Run one 256 KiB task batch end to end on the GPU and fill the 16 KiB result
  * batch — what one RTL PE array does between task_start and TestCmp.           */
 int      bsw_refbatch_run(bsw_ctx *ctx, const uint32_t *in_words, uint32_t *out_words, int variant, int zdrop);
+/* Queue a task batch (asynchronous; the reference keeps 4 in flight, batch_manager.v:418,745-773; here up to
+ * BSW_REFBATCH_MAX_INFLIGHT).  in_words / out_words must stay valid until bsw_refbatch_wait, which runs
+ * everything queued as ONE device batch (the nibble streams are unpacked on the GPU), fills every out_words
+ * in TASK ORDER (the RTL emits completion order and relies on the tag, sw_pe_array_fill_resulBuf.v:377-429)
+ * and returns the number of batches completed or <0.  All batches of one wait share variant / zdrop.
+ * The header's H5/H6 (max_ins/max_del) are honoured as the band limits, as in the RTL. */
+#define BSW_REFBATCH_MAX_INFLIGHT 256
+int      bsw_refbatch_submit(bsw_ctx *ctx, const uint32_t *in_words, uint32_t *out_words);
+int      bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop);
 
 /* ---- mem_chain2aln caller glue: what bwamem.c does either side of ksw_extend2.
  * Reference coordinates are bwa's: [0, l_pac) forward strand, [l_pac, 2*l_pac) reverse complement. ---- */

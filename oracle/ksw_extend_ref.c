@@ -28,11 +28,14 @@ static eh_t *eh_scratch(int qlen)
     return tl_eh;
 }
 
-int ksw_extend2_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
-                    int m, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins,
-                    int w, int end_bonus, int zdrop, int h0,
-                    int *qle_, int *tle_, int *gtle_, int *gscore_, int *max_off_,
-                    int variant, uint64_t *cells_)
+/* wlim > 0: the band is clamped by this host-supplied limit (the RTL's H5/H6 words,
+ * sw_pe_array_proc_element.v:925,933 -> sw_extend.v:1881,1890) instead of max_ins/max_del
+ * computed from the scoring parameters. */
+static int extend2_core(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
+                        int m, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins,
+                        int w, int end_bonus, int zdrop, int h0,
+                        int *qle_, int *tle_, int *gtle_, int *gscore_, int *max_off_,
+                        int variant, uint64_t *cells_, int wlim)
 {
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     eh_t *eh = eh_scratch(qlen);
@@ -52,9 +55,10 @@ int ksw_extend2_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *tar
     for (i = 0, max = 0, k = m * m; i < k; ++i) max = max > mat[i] ? max : mat[i];
     max_ins = (int)((double)(qlen * max + end_bonus - o_ins) / e_ins + 1.);
     if (max_ins < 1) max_ins = 1;
-    if (w > max_ins) w = max_ins;
     max_del = (int)((double)(qlen * max + end_bonus - o_del) / e_del + 1.);
     if (max_del < 1) max_del = 1;
+    if (wlim > 0) max_ins = max_del = wlim;
+    if (w > max_ins) w = max_ins;
     if (w > max_del) w = max_del;
 
     /* st1 init (:889,919,1009,929) */
@@ -131,6 +135,16 @@ int ksw_extend2_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *tar
     return max;
 }
 
+int ksw_extend2_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
+                    int m, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins,
+                    int w, int end_bonus, int zdrop, int h0,
+                    int *qle_, int *tle_, int *gtle_, int *gscore_, int *max_off_,
+                    int variant, uint64_t *cells_)
+{
+    return extend2_core(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop, h0,
+                        qle_, tle_, gtle_, gscore_, max_off_, variant, cells_, 0);
+}
+
 int ksw_extend_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
                    int m, const int8_t *mat, int gapo, int gape,
                    int w, int end_bonus, int zdrop, int h0,
@@ -144,16 +158,16 @@ int ksw_extend_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
 /* One side with the MAX_BAND_TRY loop (P1: sw_pe_array_sw_extend.v:1963,1878,1837,
  * 1859,1822,1969-1970): each pass starts from fresh state (quirk Q6 avoided). */
 static int side_ref(const bsw_params *p, int qlen, const uint8_t *q, int tlen, const uint8_t *t,
-                    int end_bonus, int h0, int prev_score, bsw_ext *x)
+                    int end_bonus, int h0, int prev_score, int wlim, bsw_ext *x)
 {
     int k, score = prev_score, tries = p->max_band_try > 0 ? p->max_band_try : 1;
     uint64_t cells = 0;
     memset(x, 0, sizeof(*x));
     for (k = 0; k < tries; ++k) {
         int prev = score, aw = p->w << k;
-        score = ksw_extend2_ref(qlen, q, tlen, t, 5, p->mat, p->o_del, p->e_del, p->o_ins, p->e_ins,
-                                aw, end_bonus, p->zdrop, h0,
-                                &x->qle, &x->tle, &x->gtle, &x->gscore, &x->max_off, p->variant, &cells);
+        score = extend2_core(qlen, q, tlen, t, 5, p->mat, p->o_del, p->e_del, p->o_ins, p->e_ins,
+                             aw, end_bonus, p->zdrop, h0,
+                             &x->qle, &x->tle, &x->gtle, &x->gscore, &x->max_off, p->variant, &cells, wlim);
         x->aw = aw;
         if (score == prev || x->max_off < (aw >> 1) + (aw >> 2)) break;
     }
@@ -170,7 +184,7 @@ void bsw_pair_ref(const bsw_params *p, const bsw_task *t, bsw_result *r)
     r->left.aw = r->right.aw = p->w;                      /* a->w = aw[0] = aw[1] = opt->w */
     /* P2 left (sw_pe_array_proc_element.v:1670-1675,1666-1667,1630,1640-1641) */
     if (t->lqlen > 0) {
-        score = side_ref(p, t->lqlen, t->lquery, t->ltlen, t->ltarget, p->pen_clip5, t->h0, score, &r->left);
+        score = side_ref(p, t->lqlen, t->lquery, t->ltlen, t->ltarget, p->pen_clip5, t->h0, score, t->wlim_l, &r->left);
         if (r->left.gscore <= 0 || r->left.gscore <= score - p->pen_clip5) {
             r->qb = t->qbeg - r->left.qle; r->rb = -r->left.tle; r->truesc = score;
         } else {
@@ -182,7 +196,7 @@ void bsw_pair_ref(const bsw_params *p, const bsw_task *t, bsw_result *r)
     /* P2 right: h0 = score after the left extension (:1671) */
     sc0 = score;
     if (t->rqlen > 0) {
-        score = side_ref(p, t->rqlen, t->rquery, t->rtlen, t->rtarget, p->pen_clip3, sc0, score, &r->right);
+        score = side_ref(p, t->rqlen, t->rquery, t->rtlen, t->rtarget, p->pen_clip3, sc0, score, t->wlim_r, &r->right);
         if (r->right.gscore <= 0 || r->right.gscore <= score - p->pen_clip3) {
             r->qe = r->right.qle; r->re = r->right.tle; r->truesc += score - sc0;
         } else {

@@ -69,7 +69,7 @@ def extend2(query, target, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop,
 def pair_batch(params, tasks, nthreads=1):
     """params: 1-element PARAMS array; tasks: TASK array -> RESULT array."""
     from_dtype = tasks.dtype
-    assert from_dtype.itemsize == 64
+    assert from_dtype.itemsize == 72
     import importlib
     host = importlib.import_module("bwa_mem_sw_amd.host")
     out = np.zeros(len(tasks), dtype=host.RESULT)

@@ -1,4 +1,4 @@
-// Sanitizer run of the C++ batch manager's host logic (validation, SWAR packing, binning): bsw_api.hip is compiled
+// Sanitizer run of the C++ batch manager's host logic (validation, chunk layout, class counts, plan replay): bsw_api.hip is compiled
 // host-only with -fsanitize=address,undefined and linked against stubs for the kernel launchers.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -7,6 +7,7 @@
 #include <vector>
 #include "bwa_sw_mi355.h"
 #include "../bwa-mem-sw_amd/csrc/bsw_device.h"
+#include "../bwa-mem-sw_amd/csrc/bsw_stage.h"
 
 namespace bsw {
 static const int kW[] = {1, 2, 3, 4, 8, 16};
@@ -20,6 +21,9 @@ hipError_t launch_wave(int, int, const bsw_dparams &, const uint64_t *, const bs
 hipError_t launch_lane(int, int, const bsw_dparams &, int, const uint64_t *, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, hipStream_t) { return hipSuccess; }
 hipError_t launch_finalize(const bsw_dparams &, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, uint32_t *, uint32_t *, hipStream_t) { return hipSuccess; }
 hipError_t launch_fetch(const uint8_t *, int64_t, const bsw_fetch_desc *, uint32_t, uint64_t *, hipStream_t) { return hipSuccess; }
+hipError_t launch_pack(const uint8_t *, const bsw_dtask *, const bsw_rawoff *, uint32_t, int, uint64_t *, hipStream_t) { return hipSuccess; }
+hipError_t launch_wire_pack(const uint32_t *, const bsw_dtask *, const bsw_wireoff *, uint32_t, uint64_t *, hipStream_t) { return hipSuccess; }
+hipError_t launch_bin(const bsw_binparams &, const bsw_dtask *, uint32_t, uint32_t *, uint32_t *, hipStream_t) { return hipSuccess; }
 }
 
 int main()

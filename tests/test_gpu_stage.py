@@ -1,0 +1,268 @@
+"""GPU tests of the round-2 batch manager: device-side packing and binning, DMA straight out of registered
+host memory, several devices behind one context, host-supplied band limits (H5/H6), queued wire-format
+batches, the coalescing scalar ABI and the watchdog.  Parity is always against the CPU oracle."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import _gen
+from test_gpu_parity import assert_same, FIELDS
+
+pytestmark = pytest.mark.gpu
+
+MIXED = dict(seed_len_min=19, seed_len_max=60, seed_at_start=0, sub_rate=0.02, indel_rate=0.01, junk_frac=0.1, n_rate=0.001)
+
+
+def rebase(tasks, arena, dst_u8, content=None):
+    """Copy `content` (default: the arena itself) into dst_u8 and return tasks whose pointers follow."""
+    src = arena if content is None else content
+    dst_u8[:src.size] = src
+    delta = dst_u8.ctypes.data - arena.ctypes.data
+    t = tasks.copy()
+    for f in ("lquery", "ltarget", "rquery", "rtarget"):
+        nz = t[f] != 0
+        t[f][nz] = (t[f][nz].astype(np.int64) + delta).astype(np.uint64)
+    return t
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_device_binning_matches_the_plan(host, kernel):
+    """bsw_bin_* on the GPU must produce the lists bsw_plan_batch promises: same segments, every list a
+    permutation of the host replay's, lane sides sorted by query length (longest first)."""
+    n = host.LANE_AUTO_MIN + 7000
+    tasks, arena = host.synth_tasks(n, seed=5, read_len=250, seed_len_min=19, seed_len_max=120, seed_at_start=0,
+                                    junk_frac=0.1, n_rate=0.001)
+    tasks["h0"][::7] = 300                     # some seeds outside the 8-bit score range
+    p = host.default_params()
+    want_order, want_seg, _ = host.plan_batch(p, tasks, kernel=kernel)
+    with host.BswContext(device=0, kernel=kernel) as c:
+        b = c.upload(p, tasks)
+        order, seg = c.batch_order(b)
+        b.free()
+    assert (seg == want_seg).all()
+    for s in range(25):
+        lo, hi = int(seg[s]), int(seg[s + 1])
+        assert sorted(order[lo:hi]) == sorted(want_order[lo:hi]), s
+    for base, qf in ((9, "lqlen"), (17, "rqlen")):
+        for c in range(4):
+            q = tasks[qf][order[seg[base + c]:seg[base + c + 1]]]
+            assert (np.diff(q.astype(np.int64)) <= 0).all()
+
+
+def test_codes_above_four_are_n(host, oracle, ctx):
+    """The pack kernel stores every code > 4 as N (4), like bsw_pack_bases."""
+    rng = np.random.default_rng(8)
+    seeds = _gen.random_seeds(rng, 600, qmax=200, nrate=0.01)
+    tasks, arena = host.make_tasks(seeds)
+    dirty = arena.copy()
+    pos = rng.random(arena.size) < 0.01
+    dirty[pos] = rng.choice([5, 6, 7, 8, 100, 255], pos.sum()).astype(np.uint8)
+    clean = np.minimum(dirty, 4)
+    p = host.default_params()
+    keep, keep2 = np.zeros(arena.size + 8, np.uint8), np.zeros(arena.size + 8, np.uint8)
+    t_dirty = rebase(tasks, arena, keep, dirty)
+    t_clean = rebase(tasks, arena, keep2, clean)
+    got = ctx.extend_pairs(p, t_dirty)
+    want = oracle.pair_batch(p, t_clean, nthreads=4)
+    assert_same(got, want)
+
+
+@pytest.mark.parametrize("kernel", [0, 2])
+def test_registered_arena_is_dma_direct(host, oracle, kernel):
+    """Sequences and results in bsw_host_alloc memory: no gather, no copy-out; results identical."""
+    n = 30000
+    tasks, arena = host.synth_tasks(n, seed=41, **MIXED)
+    p = host.default_params()
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    ha = host.HostArena(arena.size + 64)
+    ho = host.HostArena(n * host.RESULT.itemsize)
+    try:
+        t2 = rebase(tasks, arena, ha.u8)
+        out = ho.view(host.RESULT, n)
+        out[:] = 0
+        with host.BswContext(device=0, kernel=kernel, streams=3, chunk_tasks=7000, pack_threads=1) as c:
+            got = c.extend_pairs(p, t2, out=out)
+            assert_same(got, want, tasks)
+            # unregistered output, registered input, and the other way round
+            assert_same(c.extend_pairs(p, t2), want, tasks)
+            out[:] = 0
+            assert_same(c.extend_pairs(p, tasks, out=out), want, tasks)
+    finally:
+        ha.free()
+        ho.free()
+
+
+def test_host_register_existing_buffer(host, oracle, ctx):
+    n = 5000
+    tasks, arena = host.synth_tasks(n, seed=43, **MIXED)
+    p = host.default_params()
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    assert host.host_register(arena) == 0
+    try:
+        assert_same(ctx.extend_pairs(p, tasks), want, tasks)
+    finally:
+        assert host.host_unregister(arena) == 0
+    assert host.host_unregister(arena) != 0           # not registered any more
+    assert_same(ctx.extend_pairs(p, tasks), want, tasks)
+
+
+def test_one_context_several_devices(host, oracle):
+    """bsw_config.devices[]: chunk k -> devices[k mod n].  The box has one GPU, so the same ordinal is listed
+    twice (two independent slot sets); the batch manager logic is the one an 8-GPU node runs."""
+    n = 50000
+    tasks, arena = host.synth_tasks(n, seed=45, **MIXED)
+    p = host.default_params()
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    with host.BswContext(devices=[0, 0], kernel=host.KERNEL_LANE, streams=2, chunk_tasks=3000) as c:
+        assert_same(c.extend_pairs(p, tasks), want, tasks)
+        assert_same(c.extend_pairs(p, tasks[:2999]), want[:2999])
+    with host.BswContext(devices=[0, 0, 0], streams=1, chunk_tasks=4096) as c:
+        assert_same(c.extend_pairs(p, tasks), want, tasks)
+    with pytest.raises(host.BswError):
+        host.BswContext(devices=[0, 99])
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_host_supplied_band_limits(host, oracle, kernel):
+    """bsw_task.wlim_l/r (the RTL's H5/H6) replace the library's gap-limit formula, in both kernels."""
+    n = 6000
+    tasks, arena = host.synth_tasks(n, seed=47, **dict(MIXED, indel_rate=0.03))
+    rng = np.random.default_rng(2)
+    tasks["wlim_l"] = rng.choice([0, 1, 2, 5, 17, 300], n)
+    tasks["wlim_r"] = rng.choice([0, 1, 3, 8, 40, 1000], n)
+    p = host.default_params()
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    t0 = tasks.copy()
+    t0["wlim_l"] = 0
+    t0["wlim_r"] = 0
+    assert oracle.pair_batch(p, t0, nthreads=8).tobytes() != want.tobytes()      # the limits do bind somewhere
+    with host.BswContext(device=0, kernel=kernel) as c:
+        assert_same(c.extend_pairs(p, tasks), want, tasks)
+
+
+def test_wire_format_carries_h5_h6(host, oracle, ctx):
+    """A header whose max_ins/max_del differ from the library's formula must be honoured."""
+    tasks, arena = host.synth_tasks(500, seed=49, **dict(MIXED, indel_rate=0.03, n_rate=0.0))
+    rng = np.random.default_rng(3)
+    tasks["wlim_l"] = rng.choice([1, 2, 4, 9], len(tasks))
+    tasks["wlim_r"] = rng.choice([1, 3, 6, 12], len(tasks))
+    p = host.default_params(zdrop=0)
+    words, n = host.refbatch_encode(p, tasks)
+    assert n == len(tasks)
+    p2, t2, seqbuf = host.refbatch_decode(words)
+    assert (t2["wlim_l"] == tasks["wlim_l"]).all() and (t2["wlim_r"] == tasks["wlim_r"]).all()
+    out, nres = ctx.refbatch_run(words, variant=0, zdrop=0)
+    got = host.refbatch_decode_results(out, n)
+    want = oracle.pair_batch(p, tasks)
+    t0 = tasks.copy()
+    t0["wlim_l"] = 0
+    t0["wlim_r"] = 0
+    assert oracle.pair_batch(p, t0).tobytes() != want.tobytes()
+    for f in FIELDS:
+        assert (got[f] == want[f]).all(), f
+
+
+@pytest.mark.parametrize("kernel", [0, 2])
+def test_wire_batches_in_flight(host, oracle, kernel):
+    """bsw_refbatch_submit/wait: many 256 KiB task batches queued, unpacked on the GPU, run as one device batch."""
+    p = host.default_params(zdrop=0)
+    tasks, arena = host.synth_tasks(40000, seed=51, **dict(MIXED, n_rate=0.002))
+    ins, outs, counts, lo = [], [], [], 0
+    while lo < len(tasks) and len(ins) < 40:
+        words, n = host.refbatch_encode(p, tasks[lo:lo + 819])
+        assert n > 0
+        ins.append(words)
+        outs.append(np.full(host.REFBATCH_OUT_WORDS, 0xdeadbeef, dtype=np.uint32))
+        counts.append((lo, n))
+        lo += n
+    empty = np.zeros(host.REFBATCH_IN_WORDS, dtype=np.uint32)          # a batch with no tasks in the middle
+    empty[0], empty[1] = ins[0][0], ins[0][1]
+    ins.insert(3, empty)
+    outs.insert(3, np.full(host.REFBATCH_OUT_WORDS, 0xdeadbeef, dtype=np.uint32))
+    counts.insert(3, (0, 0))
+    want = oracle.pair_batch(p, tasks[:lo], nthreads=8)
+    with host.BswContext(device=0, kernel=kernel) as c:
+        for a, b in zip(ins, outs):
+            c.refbatch_submit(a, b)
+        assert c.refbatch_wait(variant=0, zdrop=0) == len(ins)
+        assert c.refbatch_wait() == 0
+    for (l0, n), o in zip(counts, outs):
+        got = host.refbatch_decode_results(o, n)
+        for f in FIELDS:
+            assert (got[f] == want[l0:l0 + n][f]).all(), (l0, f)
+        assert (o[5 * n:] == 0).all()
+
+
+def test_scalar_abi_from_many_threads(host, oracle):
+    """bwa's -t worker threads call ksw_extend2 concurrently: calls are coalesced into device batches."""
+    L = host.lib()
+    m = host.bwa_matrix()
+    nthr, per = 16, 300
+    rng = np.random.default_rng(4)
+    cases = []
+    for k in range(nthr * per):
+        ql, tl = int(rng.integers(1, 150)), int(rng.integers(0, 260))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = _gen.mutate(rng, t, ql, 0.04, 0.02)
+        cases.append((q, t, int(rng.choice([10, 100, 200])), int(rng.choice([0, 5])), int(rng.choice([0, 100])), int(rng.integers(1, 80))))
+    res = [None] * len(cases)
+    c0, t0 = host.scalar_stats()
+
+    def work(tid):
+        for k in range(tid * per, (tid + 1) * per):
+            q, t, w, eb, zd, h0 = cases[k]
+            outs = [C.c_int(0) for _ in range(5)]
+            sc = L.ksw_extend2(len(q), q.ctypes.data, len(t), t.ctypes.data if len(t) else None, 5, m.ctypes.data, 6, 1, 6, 1, w, eb, zd, h0,
+                               *[C.addressof(o) for o in outs])
+            res[k] = (sc,) + tuple(o.value for o in outs)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for k, (q, t, w, eb, zd, h0) in enumerate(cases):
+        r = oracle.extend2(q, t, m, 6, 1, 6, 1, w, eb, zd, h0)
+        assert res[k] == (r["score"], r["qle"], r["tle"], r["gtle"], r["gscore"], r["max_off"]), k
+    c1, t1 = host.scalar_stats()
+    assert c1 - c0 == len(cases) and 0 < t1 - t0 <= len(cases)
+    # neutral results outside bwa's domain (h0 <= 0, qlen == 0): no GPU round trip, outputs always written
+    outs = [C.c_int(7) for _ in range(5)]
+    q = np.array([0, 1, 2, 3], np.uint8)
+    assert L.ksw_extend2(4, q.ctypes.data, 4, q.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, 100, 5, 100, 0, *[C.addressof(o) for o in outs]) == 0
+    assert [o.value for o in outs] == [0, 0, 0, -1, 0]
+    assert L.ksw_extend2(0, None, 4, q.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, 100, 5, 100, 9, None, None, None, None, None) == 9
+
+
+def test_busy_context_refuses_other_entry_points(host):
+    tasks, arena = host.synth_tasks(200000, seed=53)
+    p = host.default_params()
+    with host.BswContext(device=0) as c:
+        out = c.submit(p, tasks)
+        with pytest.raises(host.BswError) as ei:
+            c.upload(p, tasks[:10])
+        assert ei.value.code == -6
+        with pytest.raises(host.BswError) as ei:
+            c.submit(p, tasks[:10])
+        assert ei.value.code == -6
+        c.wait()
+        assert (out["tag"] == np.arange(len(tasks), dtype=np.uint32)).all()
+
+
+def test_watchdog_marks_the_context_dead(host):
+    """A wait for the GPU that exceeds timeout_ms fails with BSW_E_HIP and every later call fails fast
+    (the batch here is simply larger than a 1 ms deadline allows; nothing hangs)."""
+    tasks, arena = host.synth_tasks(400000, seed=55)
+    p = host.default_params()
+    c = host.BswContext(device=0, timeout_ms=1, streams=1, chunk_tasks=400000)
+    with pytest.raises(host.BswError) as ei:
+        c.extend_pairs(p, tasks)
+    assert ei.value.code == -4 and "timeout" in str(ei.value)
+    with pytest.raises(host.BswError) as ei:
+        c.upload(p, tasks[:10])
+    assert ei.value.code == -4
+    c.close()
+    with host.BswContext(device=0) as c2:                   # the device itself is fine
+        assert len(c2.extend_pairs(p, tasks[:100])) == 100
