@@ -149,7 +149,18 @@ struct dev_state {
     int device = 0;
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> events;   /* one per stream, for the watchdog */
+    std::vector<hipEvent_t> h2d_done; /* one per stream: the chunk's input DMAs have finished */
     std::vector<stage_t> slots;
+};
+
+/* Input DMAs of one device run in chunk order, one chunk at a time: chunk k+1's transfer then overlaps chunk k's
+ * kernels instead of every slot transferring (and then computing) at the same moment — the TBB fill order of the
+ * reference's batch manager (batch_manager.v:418,745-773). */
+struct h2d_gate {
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t next = 0;                  /* sequence number of the chunk whose turn it is */
+    hipEvent_t last = nullptr;        /* recorded after the previous chunk's input DMAs */
 };
 
 struct refbatch_req {
@@ -198,19 +209,17 @@ static int sync_stream(bsw_ctx *ctx, errs &e, hipStream_t st, hipEvent_t ev)
     HIPCHK(e, hipEventRecord(ev, st));
     const auto t0 = std::chrono::steady_clock::now();
     const double limit = ctx->cfg.timeout_ms > 0 ? (double)ctx->cfg.timeout_ms : 120000.0;
-    for (unsigned spins = 0;; ++spins) {
+    for (;;) {
         const hipError_t q = hipEventQuery(ev);
         if (q == hipSuccess) return BSW_OK;
         if (q != hipErrorNotReady) return fail(e, BSW_E_HIP, "hipEventQuery: %s", hipGetErrorString(q));
-        if ((spins & 63u) == 63u) {
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (ms > limit) {
-                ctx->dead = true;
-                return fail(e, BSW_E_HIP, "timeout: the GPU did not finish within %d ms; context marked dead", (int)limit);
-            }
-            if (ms > 2.0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > limit) {
+            ctx->dead = true;
+            return fail(e, BSW_E_HIP, "timeout: the GPU did not finish within %d ms; context marked dead", (int)limit);
         }
-        if (spins < 4096u) std::this_thread::yield();
+        /* poll gently: the runtime serialises queries against the other slots' enqueues */
+        std::this_thread::sleep_for(std::chrono::microseconds(ms < 0.2 ? 5 : 25));
     }
 }
 
@@ -325,6 +334,7 @@ static void ctx_release(bsw_ctx *ctx)
         if (!dead) {
             for (auto s : d.streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
             for (auto ev : d.events) (void)hipEventDestroy(ev);
+            for (auto ev : d.h2d_done) (void)hipEventDestroy(ev);
             for (auto &sl : d.slots) sl.release();
         }
     }
@@ -383,6 +393,8 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
             d.streams.push_back(st);
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
             d.events.push_back(ev);
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
+            d.h2d_done.push_back(ev);
         }
     }
     if (hipSetDevice(ctx->device0()) != hipSuccess ||
@@ -707,8 +719,15 @@ static int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint6
 }
 
 /* the raw bytes and the task records are in st.h_* (or the caller's registered arena): move them, pack, bin */
+struct gate_turn {                    /* this chunk's place in its device's input-DMA order */
+    h2d_gate *gate = nullptr;
+    size_t seq = 0;
+    hipEvent_t ev = nullptr;
+    std::atomic<int> *abort_flag = nullptr;
+};
+
 static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &ci, size_t n, bool dev_targets,
-                        const bsw_ref *ref, size_t n_desc, uint64_t *h2d_bytes)
+                        const bsw_ref *ref, size_t n_desc, uint64_t *h2d_bytes, const gate_turn *turn = nullptr)
 {
     const size_t rawb = ci.direct ? (size_t)(ci.hi - ci.lo) : ci.sum_len;
     hipError_t he;
@@ -717,9 +736,26 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
         (he = st.d_order.reserve(order_capacity(n))) != hipSuccess || (he = st.d_bins.reserve(BSW_BIN_WORDS)) != hipSuccess ||
         (he = st.d_out.reserve(n + 1)) != hipSuccess || (n_desc && (he = st.d_desc.reserve(n_desc)) != hipSuccess))
         return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
-    if (rawb) HIPCHK(e, hipMemcpyAsync(st.d_raw.p, ci.direct ? ci.lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s));
-    HIPCHK(e, hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s));
-    HIPCHK(e, hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s));
+    {
+        std::unique_lock<std::mutex> lk;
+        if (turn) {
+            lk = std::unique_lock<std::mutex>(turn->gate->mu);
+            turn->gate->cv.wait(lk, [&]() { return turn->gate->next == turn->seq || *turn->abort_flag; });
+            if (*turn->abort_flag) return fail(e, BSW_E_HIP, "aborted: another chunk failed");
+            if (turn->gate->last) HIPCHK(e, hipStreamWaitEvent(s, turn->gate->last, 0));
+        }
+        hipError_t ce = hipSuccess;
+        if (rawb) ce = hipMemcpyAsync(st.d_raw.p, ci.direct ? ci.lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s);
+        if (turn) {
+            if (ce == hipSuccess) ce = hipEventRecord(turn->ev, s);
+            if (ce == hipSuccess) turn->gate->last = turn->ev;
+            turn->gate->next = turn->seq + 1;          /* pass the turn on even on failure: nobody may wait forever */
+            turn->gate->cv.notify_all();
+        }
+        if (ce != hipSuccess) return fail(e, BSW_E_HIP, "input DMA: %s", hipGetErrorString(ce));
+    }
     HIPCHK(e, bsw::launch_pack(st.d_raw.p, st.d_tasks.p, st.d_roff.p, (uint32_t)n, dev_targets ? 1 : 0, st.d_seq.p, s));
     if (n_desc) {
         HIPCHK(e, hipMemcpyAsync(st.d_desc.p, st.h_desc.p, n_desc * sizeof(bsw_fetch_desc), hipMemcpyHostToDevice, s));
@@ -1050,45 +1086,91 @@ extern "C" int bsw_batch_order(bsw_ctx *ctx, const bsw_dev_batch *b, uint32_t *o
 
 /* ---- one synchronous chunk through a staging slot (small batches; the streaming workers use the same steps) ---- */
 static int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params &p, const bsw_dparams &dp,
-                     const bsw_task *tasks, size_t n, bsw_result *out, int gather_threads)
+                     const bsw_task *tasks, size_t n, bsw_result *out, int gather_threads, const gate_turn *turn = nullptr)
 {
     if (n == 0) return BSW_OK;
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = dbg ? tnow() : 0;
     hipError_t he;
     if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess)
         return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
     chunk_info ci;
     int rc = prepare_chunk(e, &p, ctx->cfg.kernel, tasks, n, false, st.h_tasks.p, st.h_roff.p, ci);
     if (rc) return rc;
+    const double t_b = dbg ? tnow() : 0;
     if (!ci.direct) {
         if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
         gather_raw(tasks, st.h_roff.p, n, false, st.h_raw.p, gather_threads);
     }
-    rc = stage_device(e, st, s, ci, n, false, nullptr, 0, nullptr);
+    const double t_c = dbg ? tnow() : 0;
+    rc = stage_device(e, st, s, ci, n, false, nullptr, 0, nullptr, turn);
     if (rc) return rc;
     rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, s, nullptr);
     if (rc) return rc;
     const bool out_direct = is_registered(out, n * sizeof(bsw_result));
     if (!out_direct && (he = st.h_out.reserve(n)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
     HIPCHK(e, hipMemcpyAsync(out_direct ? out : st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
+    const double t_d = dbg ? tnow() : 0;
     rc = sync_stream(ctx, e, s, ev);
     if (rc) return rc;
+    const double t_e = dbg ? tnow() : 0;
     if (!out_direct) memcpy(out, st.h_out.p, n * sizeof(bsw_result));
+    if (dbg) fprintf(stderr, "[bsw] chunk n=%zu %s: prepare %.3f ms, gather %.3f, enqueue %.3f, gpu wait %.3f, copy-out %.3f (t0=%.3f)\n", n,
+                     ci.direct ? "direct" : "gather", t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, tnow() - t_e, t_a);
     return BSW_OK;
 }
 
 /* ---- streaming submit: one host thread per (device, slot); chunk k -> device k mod G, slot (k / G) mod S —
  * the round-robin of the reference's four TBB/RBB pairs over its PE arrays (batch_manager.v:343-348,418,745-773) ---- */
-static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp, const bsw_task *tasks, size_t n,
-                       bsw_result *out, size_t d, size_t s, int gather_threads, std::atomic<int> &abort_flag, errs &e)
+struct chunk_span {
+    size_t base, cnt;
+};
+
+/* tasks[0..n) -> per-device chunk lists.  Chunks are equal-sized (a short tail chunk would fall below the lane
+ * kernel's minimum batch), chunk c of the plan belongs to device c mod G, and every device's first
+ * chunk is cut in two so that its first DMA — the only one no kernel overlaps — is short. */
+static std::vector<std::vector<chunk_span>> plan_chunks(size_t n, size_t chunk, size_t G)
+{
+    std::vector<std::vector<chunk_span>> out(G);
+    if (n == 0) return out;
+    size_t nch = (n + chunk / 2) / chunk;
+    if (nch == 0) nch = 1;
+    size_t per = ((n + nch - 1) / nch + 255) & ~(size_t)255;
+    size_t c = 0;
+    for (size_t base = 0; base < n; base += per, ++c) {
+        const size_t cnt = std::min(per, n - base);
+        std::vector<chunk_span> &v = out[c % G];
+        if (v.empty() && cnt >= 3 * (size_t)LANE_AUTO_MIN + 1024) {
+            const size_t h = ((cnt / 3) + 255) & ~(size_t)255;
+            v.push_back(chunk_span{base, h});
+            v.push_back(chunk_span{base + h, cnt - h});
+        } else
+            v.push_back(chunk_span{base, cnt});
+    }
+    return out;
+}
+
+static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp, const bsw_task *tasks,
+                       bsw_result *out, const std::vector<chunk_span> &chunks, size_t d, size_t s, int gather_threads,
+                       std::atomic<int> &abort_flag, h2d_gate &gate, errs &e)
 {
     dev_state &dev = ctx->devs[d];
-    const size_t G = ctx->devs.size(), S = dev.slots.size(), chunk = ctx->cfg.chunk_tasks;
+    const size_t S = dev.slots.size();
+    auto bail = [&](int rc) {                       /* wake the slots waiting for their DMA turn */
+        abort_flag = 1;
+        { std::lock_guard<std::mutex> lk(gate.mu); }
+        gate.cv.notify_all();
+        return rc;
+    };
     hipError_t he = hipSetDevice(dev.device);
-    if (he != hipSuccess) { abort_flag = 1; return fail(e, BSW_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)); }
-    for (size_t ci = d + G * s; ci * chunk < n && !abort_flag; ci += G * S) {
-        const size_t base = ci * chunk, cnt = std::min(chunk, n - base);
-        const int rc = run_chunk(ctx, e, dev.slots[s], dev.streams[s], dev.events[s], p, dp, tasks + base, cnt, out + base, gather_threads);
-        if (rc) { abort_flag = 1; return rc; }
+    if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)));
+    for (size_t k = s; k < chunks.size() && !abort_flag; k += S) {            /* k-th chunk of this device */
+        gate_turn turn;
+        turn.gate = &gate; turn.seq = k; turn.ev = dev.h2d_done[s]; turn.abort_flag = &abort_flag;
+        const int rc = run_chunk(ctx, e, dev.slots[s], dev.streams[s], dev.events[s], p, dp, tasks + chunks[k].base, chunks[k].cnt,
+                                 out + chunks[k].base, gather_threads, &turn);
+        if (rc) return bail(rc);
     }
     return BSW_OK;
 }
@@ -1098,23 +1180,25 @@ static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, si
     bsw_dparams dp;
     int rc = check_params(ctx->err, &p, &dp);
     if (rc) return rc;
-    const size_t G = ctx->devs.size(), S = (size_t)ctx->cfg.streams, chunk = ctx->cfg.chunk_tasks;
-    const size_t nchunks = (n + chunk - 1) / chunk;
+    const size_t G = ctx->devs.size(), S = (size_t)ctx->cfg.streams;
+    const std::vector<std::vector<chunk_span>> chunks = plan_chunks(n, ctx->cfg.chunk_tasks, G);
     struct wk { size_t d, s; int rc = 0; errs e; };
     std::vector<wk> ws;
     for (size_t s = 0; s < S; ++s)
         for (size_t d = 0; d < G; ++d)
-            if (d + G * s < nchunks) { wk w; w.d = d; w.s = s; ws.push_back(w); }
+            if (s < chunks[d].size()) { wk w; w.d = d; w.s = s; ws.push_back(w); }
     if (ws.empty()) return BSW_OK;
     const int gather_threads = std::max(1, ctx->cfg.pack_threads / (int)ws.size());
     std::atomic<int> abort_flag{0};
+    std::vector<h2d_gate> gates(G);
     std::vector<std::thread> th;
     for (size_t k = 1; k < ws.size(); ++k)
-        th.emplace_back([&, k]() { ws[k].rc = slot_worker(ctx, p, dp, tasks, n, out, ws[k].d, ws[k].s, gather_threads, abort_flag, ws[k].e); });
-    ws[0].rc = slot_worker(ctx, p, dp, tasks, n, out, ws[0].d, ws[0].s, gather_threads, abort_flag, ws[0].e);
+        th.emplace_back([&, k]() { ws[k].rc = slot_worker(ctx, p, dp, tasks, out, chunks[ws[k].d], ws[k].d, ws[k].s, gather_threads, abort_flag, gates[ws[k].d], ws[k].e); });
+    ws[0].rc = slot_worker(ctx, p, dp, tasks, out, chunks[ws[0].d], ws[0].d, ws[0].s, gather_threads, abort_flag, gates[ws[0].d], ws[0].e);
     for (auto &t : th) t.join();
-    for (auto &w : ws)
-        if (w.rc) { ctx->err = w.e; return w.rc; }
+    for (int pass = 0; pass < 2; ++pass)             /* report the failure itself, not the slots it made give up */
+        for (auto &w : ws)
+            if (w.rc && (pass || w.e.msg.compare(0, 7, "aborted") != 0)) { ctx->err = w.e; return w.rc; }
     return BSW_OK;
 }
 

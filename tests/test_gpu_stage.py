@@ -253,12 +253,16 @@ def test_busy_context_refuses_other_entry_points(host):
 
 def test_watchdog_marks_the_context_dead(host):
     """A wait for the GPU that exceeds timeout_ms fails with BSW_E_HIP and every later call fails fast
-    (the batch here is simply larger than a 1 ms deadline allows; nothing hangs)."""
-    tasks, arena = host.synth_tasks(400000, seed=55)
+    (the batch here is simply larger than a 1 ms deadline allows; nothing hangs).  Sequences and results sit in
+    registered memory so that the whole round trip is asynchronous and the wait is where the time goes."""
+    n = 600000
+    ha = host.HostArena(host.synth_arena_bound(n) + 4096)
+    ho = host.HostArena(n * host.RESULT.itemsize)
+    tasks, _ = host.synth_tasks(n, arena=ha.u8, seed=55)
     p = host.default_params()
-    c = host.BswContext(device=0, timeout_ms=1, streams=1, chunk_tasks=400000)
+    c = host.BswContext(device=0, timeout_ms=1, streams=1, chunk_tasks=n)
     with pytest.raises(host.BswError) as ei:
-        c.extend_pairs(p, tasks)
+        c.extend_pairs(p, tasks, out=ho.view(host.RESULT, n))
     assert ei.value.code == -4 and "timeout" in str(ei.value)
     with pytest.raises(host.BswError) as ei:
         c.upload(p, tasks[:10])
@@ -266,3 +270,7 @@ def test_watchdog_marks_the_context_dead(host):
     c.close()
     with host.BswContext(device=0) as c2:                   # the device itself is fine
         assert len(c2.extend_pairs(p, tasks[:100])) == 100
+    import time
+    time.sleep(0.05)                                        # let the abandoned batch drain before its buffers go
+    ha.free()
+    ho.free()
