@@ -1,0 +1,334 @@
+/*
+ * bsw_lane2_core.h — per-lane arithmetic of the TWO-SEEDS-PER-LANE lane kernel (bsw_lane2_kernel.hip).
+ *
+ * Each lane runs the scalar ksw_extend2 recurrence (sw_pe_array_sw_extend.v:1639-1705, CPU semantics of
+ * SURVEY.md §8a, variant H) of two seeds at once: seed A in the low and seed B in the high 16 bits of every
+ * register, with packed 16-bit VALU ops (v_pk_max_u16 / v_pk_sub_u16 clamp / v_pk_mad_u16: two values per
+ * 4-cycle issue slot — the best per-value rate gfx950 offers for max/add work, profiles/r2/ubench3.txt).
+ *   eh[] row: one VGPR per column, each half = {e:8 | h:8} (legal when h0 + qlen*a <= 255 and qlen <= 135).
+ *   Scores are unsigned with saturating subtraction: max(x - c, 0) is one op.
+ *   Left edge: eh[j] == 0 for every j < beg is an invariant (zero-trimming only passes zeros; columns the band
+ *   clamp drops are zeroed explicitly) and the match mask is cleared below beg, so cells left of beg compute to
+ *   zero and need no masking — only blocks that hold some lane's `end` run the masked ("edge") body.
+ *   Next-row range (K8): non-zero bits of the stored eh entries accumulate in 16-column bit masks.
+ * This header is compiled twice: by hipcc into the kernel, and by g++ into the CPU model the tests check against
+ * the oracle (tests/lane2_model.cpp) — same source, so the arithmetic is verified without a GPU.
+ */
+#ifndef BSW_LANE2_CORE_H
+#define BSW_LANE2_CORE_H
+
+#include <stdint.h>
+#include <utility>
+
+#if defined(__HIPCC__)
+#define L2_FN __host__ __device__ __forceinline__
+#define L2_MFN __host__ __device__ __forceinline__ static
+#else
+#define L2_FN static inline
+#define L2_MFN static inline
+#endif
+
+namespace bsw {
+namespace l2 {
+
+/* ---- packed 16-bit primitives ---- */
+#if defined(__HIP_DEVICE_COMPILE__)
+L2_FN uint32_t pk_max(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+L2_FN uint32_t pk_min(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+L2_FN uint32_t pk_subs(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+L2_FN uint32_t pk_sub(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+L2_FN uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+/* an inline constant feeds only the LOW half of a packed op on gfx9 (its high 16 bits are 0): op_sel_hi:[0,1] makes the
+ * high half read the low 16 bits of src0 too */
+L2_FN uint32_t pk_shr8(uint32_t a) { uint32_t d; asm("v_pk_lshrrev_b16 %0, 8, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(a)); return d; }
+/* variants whose constant operand sits in an SGPR (one scalar per VOP3P instruction on gfx9) */
+L2_FN uint32_t pk_subs_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "s"(sb)); return d; }
+L2_FN uint32_t pk_min_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(sb)); return d; }
+L2_FN uint32_t pk_mad_vsv(uint32_t a, uint32_t sb, uint32_t c) { uint32_t d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(sb), "v"(c)); return d; }
+L2_FN uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { uint32_t d; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b)); return d; }   /* (m & a) | (~m & b) */
+/* (h << 8) | jj with the column constant in an SGPR: no VGPR and no VALU op spent on it */
+L2_FN uint32_t key_of(uint32_t h, uint32_t jj) { uint32_t d; asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(d) : "v"(h), "s"(jj)); return d; }
+L2_FN int ffs_lo(uint32_t x) { return (int)__builtin_ctz(x); }
+L2_FN int fls_hi(uint32_t x) { return 31 - (int)__builtin_clz(x); }
+#else
+L2_FN uint16_t lo16(uint32_t a) { return (uint16_t)a; }
+L2_FN uint16_t hi16(uint32_t a) { return (uint16_t)(a >> 16); }
+L2_FN uint32_t mk2(uint32_t lo, uint32_t hi) { return (lo & 0xffffu) | (hi << 16); }
+L2_FN uint32_t pk_max(uint32_t a, uint32_t b) { return mk2(lo16(a) > lo16(b) ? lo16(a) : lo16(b), hi16(a) > hi16(b) ? hi16(a) : hi16(b)); }
+L2_FN uint32_t pk_min(uint32_t a, uint32_t b) { return mk2(lo16(a) < lo16(b) ? lo16(a) : lo16(b), hi16(a) < hi16(b) ? hi16(a) : hi16(b)); }
+L2_FN uint32_t pk_subs(uint32_t a, uint32_t b) { return mk2(lo16(a) > lo16(b) ? lo16(a) - lo16(b) : 0, hi16(a) > hi16(b) ? hi16(a) - hi16(b) : 0); }
+L2_FN uint32_t pk_sub(uint32_t a, uint32_t b) { return mk2((uint32_t)(lo16(a) - lo16(b)), (uint32_t)(hi16(a) - hi16(b))); }
+L2_FN uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return mk2((uint32_t)lo16(a) * lo16(b) + lo16(c), (uint32_t)hi16(a) * hi16(b) + hi16(c)); }
+L2_FN uint32_t pk_shr8(uint32_t a) { return (a >> 8) & 0x00ff00ffu; }
+L2_FN uint32_t pk_subs_vs(uint32_t a, uint32_t sb) { return pk_subs(a, sb); }
+L2_FN uint32_t pk_min_vs(uint32_t a, uint32_t sb) { return pk_min(a, sb); }
+L2_FN uint32_t pk_mad_vsv(uint32_t a, uint32_t sb, uint32_t c) { return pk_mad(a, sb, c); }
+L2_FN uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
+L2_FN uint32_t key_of(uint32_t h, uint32_t jj) { return (h << 8) | jj; }
+L2_FN int ffs_lo(uint32_t x) { return __builtin_ctz(x); }
+L2_FN int fls_hi(uint32_t x) { return 31 - __builtin_clz(x); }
+#endif
+
+L2_FN uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x00010001u; }
+L2_FN uint32_t pack2(int a, int b) { return ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16); }
+L2_FN int imax(int a, int b) { return a > b ? a : b; }
+L2_FN int imin(int a, int b) { return a < b ? a : b; }
+
+template <class F, int... I>
+L2_FN void sfor_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+L2_FN void sfor(F &&f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+/* scoring constants of a launch (wave-uniform) */
+struct consts {
+    int a, pb, pn;                      /* match score, mismatch penalty (-mat[1]), N penalty (-mat[24]); pb >= pn >= 0 */
+    int o_del, e_del, oe_ins, e_ins, zdrop;
+    uint32_t OE2, ED2, ONE2;            /* {oe,oe}, {e,e}, {1,1}: symmetric gaps (o_del == o_ins, e_del == e_ins) */
+};
+
+struct seedv {                          /* the scalars of one ksw_extend2 call (K1/K9) */
+    int qlen, tlen, h0, w, beg, end;
+    int mx, max_i, max_j, max_ie, gscore, max_off;
+    unsigned cells;
+    bool alive;
+};
+
+struct rowv {                           /* per-lane values of the current row, both seeds */
+    bool act[2], bite[2];
+    int len[2], zlo[2], zhi[2];
+};
+
+struct uni {                            /* wave-uniform values of the current row */
+    int jlo, jhi, jem;                  /* min beg, max end, min end over the active seeds of the wave */
+    bool anybite;
+    int zl, zh;                         /* union of the column ranges the band clamp dropped this row */
+    uint32_t nblk;                      /* bit b: some query of the wave has an N in columns [8b, 8b+8) */
+};
+
+template <int QB>
+struct lane2 {
+    static constexpr int QMAX = QB * 8;
+    static constexpr int NW = (QMAX + 31) / 32;     /* 32-column match-mask words per seed */
+    static constexpr int NC = (QMAX + 15) / 16;     /* 16-column chunks (both seeds per register) */
+    static constexpr int NG = (QMAX + 63) / 64;     /* 64-column groups of the row-max key */
+
+    struct state {
+        uint32_t Pr[QMAX];              /* eh[] row: half = {e:8 | h:8} */
+        seedv s[2];
+    };
+
+    /* K2 first row, closed form: eh[0]=h0, eh[j]=max(h0-oe_ins-(j-1)e_ins,0), e=0 (sw_pe_array_sw_extend.v:1979,1957,1974) */
+    L2_MFN void init_row(state &S, const consts &k)
+    {
+        sfor<QMAX>([&](auto ci) {
+            constexpr int j = decltype(ci)::value;
+            const int v0 = j == 0 ? S.s[0].h0 : imax(S.s[0].h0 - k.oe_ins - (j - 1) * k.e_ins, 0);
+            const int v1 = j == 0 ? S.s[1].h0 : imax(S.s[1].h0 - k.oe_ins - (j - 1) * k.e_ins, 0);
+            S.Pr[j] = pack2(v0, v1);
+        });
+    }
+
+    L2_MFN void init_seed(seedv &s, int qlen, int tlen, int h0, int w)
+    {
+        s.qlen = qlen; s.tlen = tlen; s.h0 = h0; s.w = w; s.beg = 0; s.end = qlen;
+        s.mx = h0; s.max_i = s.max_j = s.max_ie = s.gscore = -1; s.max_off = 0; s.cells = 0;
+        s.alive = tlen > 0;
+    }
+
+    /* K3 band clamp (:1803,1894-1897,1842,1898).  A clamp that moves beg may drop non-zero eh entries: the columns
+     * [zlo, zhi) it drops are zeroed by zero_dropped() to keep the "eh[j] == 0 below beg" invariant. */
+    L2_MFN void row_begin(state &S, int i, rowv &r)
+    {
+        sfor<2>([&](auto xi) {
+            constexpr int x = decltype(xi)::value;
+            seedv &s = S.s[x];
+            r.act[x] = s.alive && i < s.tlen;
+            const int nb = imax(s.beg, i - s.w), ne = imin(imin(s.end, i + s.w + 1), s.qlen);
+            r.bite[x] = r.act[x] && nb > s.beg;
+            r.zlo[x] = s.beg; r.zhi[x] = nb;
+            s.beg = r.act[x] ? nb : s.beg;
+            s.end = r.act[x] ? ne : s.end;
+            r.len[x] = imax(s.end - s.beg, 0);
+            s.cells += r.act[x] ? (unsigned)r.len[x] : 0u;
+        });
+    }
+
+    L2_MFN void zero_dropped(state &S, const rowv &r, const uni &u)
+    {
+        sfor<QB>([&](auto bi) {
+            constexpr int j0 = decltype(bi)::value * 8;
+            if (j0 + 8 <= u.zl || j0 >= u.zh) return;
+            sfor<8>([&](auto ci) {
+                constexpr int J = j0 + decltype(ci)::value;
+                uint32_t keep = 0xffffffffu;
+                if (r.bite[0] && J >= r.zlo[0] && J < r.zhi[0]) keep &= 0xffff0000u;
+                if (r.bite[1] && J >= r.zlo[1] && J < r.zhi[1]) keep &= 0x0000ffffu;
+                S.Pr[J] &= keep;
+            });
+        });
+    }
+
+    /* One DP cell of column J for both seeds (K5: :1797-1798,1809,1866,1863,1776).
+     * EDGE: the block holds some seed's `end` -> writes, the row max and the non-zero bits are masked per half to
+     *       J < end (cells) / J <= end (the eh[end] = {h1, 0} store, :1775).  NQ: some query has an N in this block.
+     * Returns nothing; state flows through h1, f, mk, nz. */
+    template <int J, bool EDGE, bool NQ>
+    L2_MFN void cell(uint32_t &P, const uint32_t Wc, const uint32_t WNc, const uint32_t AB2, const uint32_t Bv2, const uint32_t D2,
+                           const consts &k, const uint32_t END2, uint32_t &mi_prev, uint32_t &h1, uint32_t &f, uint32_t &mk, uint32_t &nz)
+    {
+        constexpr uint32_t JJ = (uint32_t)(J & 63) * 0x00010001u;
+        uint32_t t = (J & 15) ? (Wc >> (J & 15)) : Wc;
+        t &= 0x00010001u;                                    /* 1 where q_j == t_i */
+        const uint32_t hd = P & 0x00ff00ffu;                 /* eh[j].h = H(i-1,j-1) */
+        const uint32_t e = pk_shr8(P);                       /* eh[j].e */
+        uint32_t X = pk_mad(t, AB2, hd);                     /* hd + (match ? a + pb : 0) */
+        if (NQ) {
+            uint32_t n = (J & 15) ? (WNc >> (J & 15)) : WNc;
+            n &= 0x00010001u;
+            X = pk_mad(n, D2, X);                            /* a query N scores -pn whatever the target base is */
+        }
+        const uint32_t M = pk_subs(X, Bv2);                  /* max(hd + s, 0): variant H, e and f are >= 0 anyway */
+        uint32_t h = pk_max(pk_max(M, e), f);                /* (:1798,1809) */
+        const uint32_t tD = pk_subs_vs(h, k.OE2);
+        uint32_t en = pk_max(pk_subs_vs(e, k.ED2), tD);         /* (:1866,1770-1771) */
+        f = pk_max(pk_subs_vs(f, k.ED2), tD);                   /* (:1863,1780-1781) */
+        if (!EDGE) {
+            mk = pk_max(mk, key_of(h, JJ));                  /* row max of this 64-column group, ties -> later j */
+            const uint32_t np = (en << 8) | h1;              /* eh[j] = {e', H(i,j-1)} (:1776) */
+            nz = pk_mad_vsv(pk_min_vs(np, k.ONE2), dup16(1 << (J & 15)), nz);
+            P = np;
+            h1 = h;
+        } else {
+            const uint32_t d = pk_subs_vs(END2, dup16(J));   /* non-zero iff J < end */
+            const uint32_t mi = pk_sub(0u, pk_min_vs(d, k.ONE2));   /* 0xffff where J < end */
+            const uint32_t mw = mi | mi_prev;                /* 0xffff where J <= end */
+            mi_prev = mi;
+            mk = pk_max(mk, key_of(h & mi, JJ));
+            en &= mi;
+            const uint32_t np = ((en << 8) | h1) & mw;
+            nz = pk_mad_vsv(pk_min_vs(np, k.ONE2), dup16(1 << (J & 15)), nz);
+            P = bfi(mw, np, P);
+            h1 = bfi(mi, h, h1);
+        }
+    }
+
+    /* match-mask words of one seed for target base tb: bit j = (q_j == t_i), neither an N, j >= beg */
+    template <class QP>
+    L2_MFN void match_words(const QP &qp, int x, int tb, int beg, const uni &u, uint32_t (&rm)[NW])
+    {
+        const uint32_t n0 = (uint32_t)((tb & 1) - 1), n1 = (uint32_t)(((tb >> 1) & 1) - 1);
+        const uint32_t tn = (uint32_t)((tb >> 2) - 1);       /* 0 when the target base is N, else ~0 */
+        sfor<NW>([&](auto wi) {
+            constexpr int wd = decltype(wi)::value;
+            rm[wd] = 0;
+            if (32 * wd + 32 <= u.jlo || 32 * wd > u.jhi) return;
+            const uint32_t v = (qp(x, 0, wd) ^ n0) & (qp(x, 1, wd) ^ n1) & tn & ~qp(x, 2, wd);
+            const int sh = beg - 32 * wd;                    /* clear the columns below beg */
+            const uint32_t keep = sh <= 0 ? 0xffffffffu : (sh >= 32 ? 0u : (0xffffffffu << sh));
+            rm[wd] = v & keep;
+        });
+    }
+
+    /* One DP row for both seeds, after the wave-uniform values are known.  tb[x] = target base of seed x (0..4).
+     * qp(x, plane, wd): query bit-planes (code bit 0, bit 1, N) of seed x; wn(c): N planes of both seeds interleaved
+     * per 16-column chunk (low half seed A). */
+    template <class QP, class WN>
+    L2_MFN void row_body(state &S, const consts &k, const int i, const rowv &r, const uni &u, const int (&tb)[2],
+                               const QP &qp, const WN &wn)
+    {
+        if (u.anybite) zero_dropped(S, r, u);
+        uint32_t rmA[NW], rmB[NW];
+        match_words(qp, 0, tb[0], S.s[0].beg, u, rmA);
+        match_words(qp, 1, tb[1], S.s[1].beg, u, rmB);
+        /* a row against a target N scores -pn everywhere (mat[4][.], :1915-1940) */
+        const int pbA = tb[0] < 4 ? k.pb : k.pn, pbB = tb[1] < 4 ? k.pb : k.pn;
+        const uint32_t AB2 = pack2(k.a + pbA, k.a + pbB), Bv2 = pack2(pbA, pbB), D2 = pack2(pbA - k.pn, pbB - k.pn);
+        const uint32_t END2 = pack2(S.s[0].end, S.s[1].end);
+        /* K4 column 0 (:1795-1796,1835), CPU semantics: only when beg == 0 */
+        const int hi0 = S.s[0].beg == 0 ? imax(S.s[0].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
+        const int hi1 = S.s[1].beg == 0 ? imax(S.s[1].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
+        uint32_t h1 = pack2(hi0, hi1), f = 0;
+        uint32_t mkg[NG], nzc[NC];
+        sfor<NG>([&](auto gi) { mkg[decltype(gi)::value] = 0; });
+        sfor<NC>([&](auto ci) { nzc[decltype(ci)::value] = 0; });
+
+        sfor<QB>([&](auto bi) {
+            constexpr int j0 = decltype(bi)::value * 8, g = j0 >> 6, c = j0 >> 4, wd = j0 >> 5;
+            if (j0 + 8 <= u.jlo || j0 > u.jhi) return;
+            /* both seeds' match bits of this 16-column chunk: low half seed A, high half seed B */
+            const uint32_t Wc = (c & 1) ? ((rmA[wd] >> 16) | (rmB[wd] & 0xffff0000u)) : ((rmA[wd] & 0xffffu) | (rmB[wd] << 16));
+            const bool nq = (u.nblk >> (j0 / 8)) & 1u;
+            const bool edge = j0 + 8 > u.jem;
+            if (!edge && !nq) {
+                uint32_t dummy = 0;
+                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, AB2, Bv2, D2, k, END2, dummy, h1, f, mkg[g], nzc[c]); });
+            } else if (!edge) {
+                uint32_t dummy = 0;
+                const uint32_t WNc = wn(c);
+                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, AB2, Bv2, D2, k, END2, dummy, h1, f, mkg[g], nzc[c]); });
+            } else {
+                /* mi of column j0 - 1 */
+                const uint32_t d0 = pk_subs_vs(pack2(S.s[0].end + 1, S.s[1].end + 1), dup16(j0));
+                uint32_t mi_prev = pk_sub(0u, pk_min_vs(d0, k.ONE2));
+                if (!nq) {
+                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, AB2, Bv2, D2, k, END2, mi_prev, h1, f, mkg[g], nzc[c]); });
+                } else {
+                    const uint32_t WNc = wn(c);
+                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, AB2, Bv2, D2, k, END2, mi_prev, h1, f, mkg[g], nzc[c]); });
+                }
+            }
+        });
+
+        /* ---- row tail per seed (K7, K8) ---- */
+        sfor<2>([&](auto xi) {
+            constexpr int x = decltype(xi)::value;
+            if (!r.act[x]) return;
+            seedv &s = S.s[x];
+            constexpr int sh = 16 * x;
+            const int h1x = (int)((h1 >> sh) & 0xffffu);
+            int mk = 0;                                      /* (m << 8) | mj over the groups; 0 = no positive cell */
+            sfor<NG>([&](auto gi) {
+                constexpr int g = decltype(gi)::value;
+                const int key = (int)((mkg[g] >> sh) & 0xffffu);
+                mk = imax(mk, ((key >> 8) << 8) | ((key & 63) + 64 * g));
+            });
+            if (imax(s.beg, s.end) == s.qlen) {              /* ties -> later i (:1829-1833) */
+                s.max_ie = s.gscore > h1x ? s.max_ie : i;
+                s.gscore = imax(s.gscore, h1x);
+            }
+            const int m = mk >> 8, mj = mk & 255;
+            bool stop = m == 0;                              /* (:1942) */
+            if (m > s.mx) {
+                s.mx = m; s.max_i = i; s.max_j = mj;
+                const int off = mj > i ? mj - i : i - mj;
+                s.max_off = imax(s.max_off, off);
+            } else if (k.zdrop > 0) {
+                const int di = i - s.max_i, dj = mj - s.max_j;
+                const int pen = di > dj ? (di - dj) * k.e_del : (dj - di) * k.e_ins;
+                stop = stop || (s.mx - m - pen > k.zdrop);
+            }
+            /* K8 next-row range (CPU semantics): first / last non-zero eh entry in [beg, end] from the bit masks */
+            int fnz = 1 << 20, lnz = -1;
+            sfor<NW>([&](auto wi) {
+                constexpr int wd = NW - 1 - decltype(wi)::value;      /* high to low: the lowest word wins fnz */
+                if (32 * wd + 32 <= u.jlo || 32 * wd > u.jhi) return;
+                constexpr int chi = 2 * wd + 1 < NC ? 2 * wd + 1 : 2 * wd;
+                const uint32_t lo = nzc[2 * wd], hic = 2 * wd + 1 < NC ? nzc[chi] : 0u;
+                const uint32_t word = x ? ((lo >> 16) | (hic & 0xffff0000u)) : ((lo & 0xffffu) | (hic << 16));
+                if (word) {
+                    fnz = ffs_lo(word) + 32 * wd;
+                    lnz = imax(lnz, fls_hi(word) + 32 * wd);
+                }
+            });
+            const int nbeg = fnz < s.end ? fnz : s.end;
+            const int last = lnz >= nbeg ? lnz : nbeg - 1;
+            s.beg = nbeg;
+            s.end = imin(last + 2, s.qlen);
+            s.alive = !stop;
+        });
+    }
+};
+
+}  // namespace l2
+}  // namespace bsw
+#endif

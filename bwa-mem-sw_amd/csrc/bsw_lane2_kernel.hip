@@ -1,0 +1,193 @@
+/*
+ * bsw_lane2_kernel.hip — gfx950 kernel: TWO EXTENSIONS PER LANE (inter-task SIMD with packed 16-bit math).
+ *
+ * The throughput path for the bins bwa's defaults produce: variant H, bwa-style matrix, symmetric gap penalties,
+ * h0 + qlen*a <= 255, qlen <= 135 (150 bp reads).  A wavefront walks DP row i of 128 seeds together: lane l holds
+ * seed A = order[128w + l] in the low and seed B = order[128w + 64 + l] in the high 16 bits of every register, and
+ * every max / saturating-subtract / multiply-add of the recurrence (sw_pe_array_sw_extend.v:1797-1816,1863-1866)
+ * is one v_pk_*_u16 instruction for both.  The per-lane arithmetic lives in bsw_lane2_core.h (shared with the CPU
+ * model of the tests); this file is the wave-level glue: operand staging through LDS, the wave-uniform block
+ * dispatch, result records.  As in bsw_lane_kernel.hip only the first band try runs here; bsw_pair_finalize
+ * sends seeds that need MAX_BAND_TRY's second pass to the wave-per-task kernel.
+ */
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "bsw_device.h"
+#include "bsw_lane2_core.h"
+
+namespace bsw {
+
+namespace {
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp2(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ int wave_max2(int x)
+{
+    x = max(x, dpp2<0x111>(INT_MIN, x));
+    x = max(x, dpp2<0x112>(INT_MIN, x));
+    x = max(x, dpp2<0x114>(INT_MIN, x));
+    x = max(x, dpp2<0x118>(INT_MIN, x));
+    x = max(x, dpp2<0x142, 0xa>(INT_MIN, x));
+    x = max(x, dpp2<0x143, 0xc>(INT_MIN, x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+/* every 4th bit of a 64-bit word (bit `b` of each nibble) gathered into 16 contiguous bits */
+__device__ __forceinline__ uint32_t nib_plane(uint64_t w, int b)
+{
+    uint64_t x = (w >> b) & 0x1111111111111111ull;
+    x = (x | (x >> 3)) & 0x0303030303030303ull;
+    x = (x | (x >> 6)) & 0x000F000F000F000Full;
+    x = (x | (x >> 12)) & 0x000000FF000000FFull;
+    x = (x | (x >> 24)) & 0xFFFFull;
+    return (uint32_t)x;
+}
+
+}  // namespace
+
+#define BSW_L2_TCHUNK 8         /* target words staged per seed in LDS = 128 DP rows */
+
+template <int QB, int WPS>
+__global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P, const int side,
+                                                             const uint64_t *__restrict__ seq,
+                                                             const bsw_dtask *__restrict__ tasks,
+                                                             const uint32_t *__restrict__ order, const uint32_t n,
+                                                             bsw_result *__restrict__ out)
+{
+    using L = l2::lane2<QB>;
+    constexpr int QMAX = L::QMAX, NW = L::NW, NC = L::NC;
+    __shared__ uint64_t lds_t[4][2][BSW_L2_TCHUNK][64];             /* [wave][seed][word][lane] */
+    __shared__ uint32_t lds_q[4][2][3 * NW][64];                    /* query bit-planes: code bit 0, bit 1, N */
+    __shared__ uint32_t lds_wn[4][NC][64];                          /* N planes of both seeds, 16 columns per half */
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t w0 = (blockIdx.x * 4u + (uint32_t)wv) * 128u + (uint32_t)lane;
+
+    typename L::state S;
+    uint32_t t_off[2], ti[2], nblk = 0, q2[2][NW];
+    int ntw[2];
+    bool valid[2];
+    l2::sfor<2>([&](auto xi) {
+        constexpr int x = decltype(xi)::value;
+        const uint32_t slot = w0 + 64u * x;
+        valid[x] = slot < n;
+        ti[x] = valid[x] ? order[slot] : order[0];
+        const bsw_dtask T = tasks[ti[x]];
+        int qlen, tlen, wlim, h0;
+        uint32_t q_off;
+        if (side == 0) {
+            qlen = T.lqlen; tlen = T.ltlen; wlim = T.wlim_l; q_off = T.lq_off; t_off[x] = T.lt_off; h0 = T.h0;
+        } else {
+            qlen = T.rqlen; tlen = T.rtlen; wlim = T.wlim_r; q_off = T.rq_off; t_off[x] = T.rt_off;
+            h0 = T.lqlen > 0 ? out[ti[x]].left.score : T.h0;          /* h0 = score after the left ext (:1671) */
+        }
+        if (!valid[x]) tlen = 0;
+        ntw[x] = (tlen + 15) >> 4;
+        L::init_seed(S.s[x], qlen, tlen, h0, min(P.w, wlim));
+#pragma unroll
+        for (int wd = 0; wd < NW; ++wd) {
+            uint32_t p0 = 0, p1 = 0, p2 = 0;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int v = wd * 2 + hlf;
+                if (v < (QMAX + 15) / 16) {
+                    const uint64_t qw = (valid[x] && v * 16 < qlen) ? seq[q_off + v] : 0ull;
+                    p0 |= nib_plane(qw, 0) << (hlf * 16);
+                    p1 |= nib_plane(qw, 1) << (hlf * 16);
+                    p2 |= nib_plane(qw, 2) << (hlf * 16);
+                }
+            }
+            lds_q[wv][x][3 * wd][lane] = p0;
+            lds_q[wv][x][3 * wd + 1][lane] = p1;
+            lds_q[wv][x][3 * wd + 2][lane] = p2;
+            q2[x][wd] = p2;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (wd * 4 + b < QB && __builtin_amdgcn_ballot_w64(((p2 >> (8 * b)) & 0xffu) != 0) != 0) nblk |= 1u << (wd * 4 + b);
+        }
+    });
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        lds_wn[wv][c][lane] = ((q2[0][c >> 1] >> (16 * (c & 1))) & 0xffffu) | ((q2[1][c >> 1] >> (16 * (c & 1))) << 16);
+
+    l2::consts k;
+    k.a = P.mat[0]; k.pb = -P.mat[1]; k.pn = -P.mat[24];
+    k.o_del = P.o_del; k.e_del = P.e_del; k.oe_ins = P.o_ins + P.e_ins; k.e_ins = P.e_ins; k.zdrop = P.zdrop;
+    k.OE2 = l2::dup16(P.o_del + P.e_del); k.ED2 = l2::dup16(P.e_del); k.ONE2 = 0x00010001u;
+    L::init_row(S, k);
+
+    const auto qp = [&](int x, int plane, int wd) { return lds_q[wv][x][3 * wd + plane][lane]; };
+    const auto wn = [&](int c) { return lds_wn[wv][c][lane]; };
+    uint64_t tw[2] = {0ull, 0ull};
+
+    for (int i = 0;; ++i) {
+        l2::rowv r;
+        L::row_begin(S, i, r);
+        if (__builtin_amdgcn_ballot_w64(r.act[0] || r.act[1]) == 0) break;
+        if ((i & (BSW_L2_TCHUNK * 16 - 1)) == 0) {                    /* stage the next 128 target bases of every seed */
+            const int wbase = i >> 4;
+            l2::sfor<2>([&](auto xi) {
+                constexpr int x = decltype(xi)::value;
+#pragma unroll
+                for (int q = 0; q < BSW_L2_TCHUNK; ++q)
+                    lds_t[wv][x][q][lane] = (r.act[x] && wbase + q < ntw[x]) ? seq[t_off[x] + wbase + q] : 0ull;
+            });
+        }
+        if ((i & 15) == 0) {
+            tw[0] = lds_t[wv][0][(i >> 4) & (BSW_L2_TCHUNK - 1)][lane];
+            tw[1] = lds_t[wv][1][(i >> 4) & (BSW_L2_TCHUNK - 1)][lane];
+        }
+        const int tb[2] = {(int)((tw[0] >> ((i & 15) * 4)) & 7), (int)((tw[1] >> ((i & 15) * 4)) & 7)};
+
+        /* wave-uniform column ranges over the active seeds: blocks outside [jlo, jhi] are skipped, blocks that
+         * reach past jem (the smallest `end`) run the masked body */
+        l2::uni u;
+        const int b0 = S.s[0].beg, b1 = S.s[1].beg, e0 = S.s[0].end, e1 = S.s[1].end;
+        u.jlo = -wave_max2(max(r.act[0] ? -b0 : INT_MIN, r.act[1] ? -b1 : INT_MIN));
+        u.jhi = wave_max2(max(r.act[0] ? e0 : INT_MIN, r.act[1] ? e1 : INT_MIN));
+        u.jem = -wave_max2(max(r.act[0] ? -e0 : INT_MIN, r.act[1] ? -e1 : INT_MIN));
+        u.anybite = __builtin_amdgcn_ballot_w64(r.bite[0] || r.bite[1]) != 0;
+        u.zl = 0; u.zh = 0;
+        if (u.anybite) {
+            u.zl = -wave_max2(max(r.bite[0] ? -r.zlo[0] : INT_MIN, r.bite[1] ? -r.zlo[1] : INT_MIN));
+            u.zh = wave_max2(max(r.bite[0] ? r.zhi[0] : INT_MIN, r.bite[1] ? r.zhi[1] : INT_MIN));
+        }
+        u.nblk = nblk;
+        L::row_body(S, k, i, r, u, tb, qp, wn);
+    }
+
+    l2::sfor<2>([&](auto xi) {
+        constexpr int x = decltype(xi)::value;
+        if (!valid[x]) return;
+        const l2::seedv &s = S.s[x];
+        bsw_ext e;
+        e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
+        e.gscore = s.gscore; e.max_off = s.max_off; e.aw = P.w; e.cells = s.cells;
+        if (side == 0) out[ti[x]].left = e; else out[ti[x]].right = e;
+    });
+}
+
+/* what the packed formulation needs from the scoring parameters (everything else takes bsw_lane_kernel) */
+bool lane2_params_ok(const bsw_dparams &P, int variant)
+{
+    static const bool off = getenv("BSW_NO_LANE2") != nullptr;
+    if (off || variant != BSW_VARIANT_H) return false;
+    if (P.o_del != P.o_ins || P.e_del != P.e_ins) return false;
+    const int a = P.mat[0], pb = -P.mat[1], pn = -P.mat[24];
+    return a > 0 && pb >= 0 && pn >= 0 && pb >= pn && a + pb < 256 && P.o_del + P.e_del < 256;
+}
+
+hipError_t launch_lane2(const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
+                        uint32_t n, bsw_result *out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL((bsw_lane2_kernel<17, 2>), dim3((n + 511u) / 512u), dim3(256), 0, s, P, side, seq, tasks, order, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace bsw

@@ -1,0 +1,127 @@
+// CPU model of bsw_lane2_kernel (TEST INFRASTRUCTURE): drives the product header bsw_lane2_core.h — the per-lane
+// arithmetic the GPU kernel is compiled from — with the wave-level glue restated in plain loops (64 lanes x 2 seeds
+// in lock step, wave-uniform minima/maxima, block dispatch).  tests/test_lane2_model.py checks it against the
+// oracle, so the two-seeds-per-lane algebra is verified here, where no GPU exists.
+// g++ -O2 -std=c++17 -shared -fPIC -I include -o lane2_model.so tests/lane2_model.cpp
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../include/bwa_sw_mi355.h"
+#include "../bwa-mem-sw_amd/csrc/bsw_lane2_core.h"
+
+using namespace bsw::l2;
+
+template <int QB>
+struct wave_model {
+    using L = lane2<QB>;
+    struct lane_t {
+        typename L::state S;
+        uint32_t qp[2][3][L::NW];       // query bit planes
+        uint32_t wn[L::NC];             // N planes, interleaved per 16 columns
+        const uint8_t *t[2];
+        bool valid[2];
+        uint32_t ti[2];
+    };
+
+    static void run(const bsw_params *p, const bsw_task *tasks, int side, const uint32_t *order, size_t n, size_t w0,
+                    const int32_t *h0s, bsw_ext *out)
+    {
+        consts k;
+        k.a = p->mat[0]; k.pb = -p->mat[1]; k.pn = -p->mat[24];
+        k.o_del = p->o_del; k.e_del = p->e_del; k.oe_ins = p->o_ins + p->e_ins; k.e_ins = p->e_ins; k.zdrop = p->zdrop;
+        k.OE2 = dup16(p->o_del + p->e_del); k.ED2 = dup16(p->e_del); k.ONE2 = 0x00010001u;
+        int mx = 0;
+        for (int i = 0; i < 25; ++i) mx = mx > p->mat[i] ? mx : p->mat[i];
+        std::vector<lane_t> ln(64);
+        uni u;
+        u.nblk = 0;
+        for (int l = 0; l < 64; ++l) {
+            lane_t &a = ln[l];
+            memset(a.qp, 0, sizeof(a.qp));
+            for (int x = 0; x < 2; ++x) {
+                const size_t slot = w0 + (size_t)l + 64 * (size_t)x;
+                a.valid[x] = slot < n;
+                a.ti[x] = a.valid[x] ? order[slot] : order[0];
+                const bsw_task &T = tasks[a.ti[x]];
+                int qlen = side ? T.rqlen : T.lqlen, tlen = side ? T.rtlen : T.ltlen;
+                const uint8_t *q = side ? T.rquery : T.lquery;
+                a.t[x] = side ? T.rtarget : T.ltarget;
+                const int eb = side ? p->pen_clip3 : p->pen_clip5;
+                int wl = side ? T.wlim_r : T.wlim_l;
+                if (wl <= 0) {
+                    int mi = (qlen * mx + eb - p->o_ins + p->e_ins) / p->e_ins, md = (qlen * mx + eb - p->o_del + p->e_del) / p->e_del;
+                    if (mi < 1) mi = 1;
+                    if (md < 1) md = 1;
+                    wl = mi < md ? mi : md;
+                }
+                if (!a.valid[x]) tlen = 0;
+                L::init_seed(a.S.s[x], qlen, tlen, h0s ? h0s[a.ti[x]] : T.h0, p->w < wl ? p->w : wl);
+                for (int j = 0; j < qlen; ++j) {
+                    const int c = q[j] > 4 ? 4 : q[j];
+                    if (c & 1) a.qp[x][0][j >> 5] |= 1u << (j & 31);
+                    if (c & 2) a.qp[x][1][j >> 5] |= 1u << (j & 31);
+                    if (c & 4) { a.qp[x][2][j >> 5] |= 1u << (j & 31); if (a.valid[x]) u.nblk |= 1u << (j >> 3); }
+                }
+            }
+            for (int c = 0; c < L::NC; ++c) {
+                const uint32_t wa = (a.qp[0][2][c >> 1] >> (16 * (c & 1))) & 0xffffu, wb = (a.qp[1][2][c >> 1] >> (16 * (c & 1))) & 0xffffu;
+                a.wn[c] = wa | (wb << 16);
+            }
+            L::init_row(a.S, k);
+        }
+        std::vector<rowv> rv(64);
+        for (int i = 0;; ++i) {
+            bool any = false;
+            u.jlo = 1 << 20; u.jhi = -1; u.jem = 1 << 20; u.anybite = false; u.zl = 1 << 20; u.zh = -1;
+            for (int l = 0; l < 64; ++l) {
+                L::row_begin(ln[l].S, i, rv[l]);
+                for (int x = 0; x < 2; ++x) {
+                    if (!rv[l].act[x]) continue;
+                    any = true;
+                    const seedv &s = ln[l].S.s[x];
+                    if (s.beg < u.jlo) u.jlo = s.beg;
+                    if (s.end > u.jhi) u.jhi = s.end;
+                    if (s.end < u.jem) u.jem = s.end;
+                    if (rv[l].bite[x]) {
+                        u.anybite = true;
+                        if (rv[l].zlo[x] < u.zl) u.zl = rv[l].zlo[x];
+                        if (rv[l].zhi[x] > u.zh) u.zh = rv[l].zhi[x];
+                    }
+                }
+            }
+            if (!any) break;
+            for (int l = 0; l < 64; ++l) {
+                lane_t &a = ln[l];
+                int tb[2];
+                for (int x = 0; x < 2; ++x) {
+                    int b = rv[l].act[x] ? a.t[x][i] : 0;
+                    tb[x] = b > 4 ? 4 : b;
+                }
+                auto qp = [&](int x, int plane, int wd) { return a.qp[x][plane][wd]; };
+                auto wn = [&](int c) { return a.wn[c]; };
+                L::row_body(a.S, k, i, rv[l], u, tb, qp, wn);
+            }
+        }
+        for (int l = 0; l < 64; ++l)
+            for (int x = 0; x < 2; ++x) {
+                if (!ln[l].valid[x]) continue;
+                const seedv &s = ln[l].S.s[x];
+                bsw_ext &e = out[ln[l].ti[x]];
+                e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
+                e.gscore = s.gscore; e.max_off = s.max_off; e.aw = p->w; e.cells = s.cells;
+            }
+    }
+};
+
+// One band try of one side of tasks[order[0..n)] exactly as bsw_lane2_kernel<17> would run it: 128 seeds per wave.
+// h0s: optional per-task h0 override (the score after the left extension); out is indexed by task.
+extern "C" int lane2_model_run(const bsw_params *p, const bsw_task *tasks, int side, const uint32_t *order, size_t n,
+                               const int32_t *h0s, bsw_ext *out)
+{
+    if (!p || !tasks || !order || !out) return -1;
+    if (p->o_del != p->o_ins || p->e_del != p->e_ins || p->mat[1] > 0 || p->mat[24] > 0 || -p->mat[1] < -p->mat[24]) return -2;
+    for (size_t w0 = 0; w0 < n; w0 += 128) wave_model<17>::run(p, tasks, side, order, n, w0, h0s, out);
+    return 0;
+}

@@ -1,0 +1,115 @@
+"""The two-seeds-per-lane algebra of bsw_lane2_kernel, verified on the CPU: tests/lane2_model.cpp drives the very
+header the GPU kernel is compiled from (csrc/bsw_lane2_core.h) with the wave-level glue restated in loops, and must
+agree with the oracle on every output of every seed — including the exact cell counts."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _gen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXTF = ["score", "qle", "tle", "gtle", "gscore", "max_off", "aw", "cells"]
+
+
+@pytest.fixture(scope="module")
+def model(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("l2") / "lane2_model.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           "-o", so, os.path.join(ROOT, "tests", "lane2_model.cpp")])
+    L = C.CDLL(so)
+    L.lane2_model_run.restype = C.c_int
+    L.lane2_model_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    return L
+
+
+def run_side(model, host, p, tasks, side, h0s=None):
+    qf = "rqlen" if side else "lqlen"
+    idx = np.nonzero(tasks[qf] > 0)[0]
+    order = idx[np.argsort(-tasks[qf][idx], kind="stable")].astype(np.uint32)     # longest queries first, as the device bins
+    out = np.zeros(len(tasks), dtype=host.EXT)
+    rc = model.lane2_model_run(p.ctypes.data, tasks.ctypes.data, side, order.ctypes.data, len(order),
+                               h0s.ctypes.data if h0s is not None else None, out.ctypes.data)
+    assert rc == 0
+    return out, idx
+
+
+def oracle_side(host, oracle, p, tasks, side, h0s=None):
+    et = np.zeros(len(tasks), dtype=host.EXT_TASK)
+    pre = "r" if side else "l"
+    et["query"], et["target"] = tasks[pre + "query"], tasks[pre + "target"]
+    et["qlen"], et["tlen"] = tasks[pre + "qlen"], tasks[pre + "tlen"]
+    et["w"], et["end_bonus"] = int(p["w"][0]), int(p["pen_clip3" if side else "pen_clip5"][0])
+    et["h0"] = tasks["h0"] if h0s is None else h0s
+    return oracle.ext_batch(p, et, nthreads=4)
+
+
+def check(model, host, oracle, p, tasks):
+    for side in (0, 1):
+        got, idx = run_side(model, host, p, tasks, side)
+        if len(idx) == 0:
+            continue
+        want = oracle_side(host, oracle, p, tasks, side)
+        for f in EXTF:
+            bad = np.nonzero(got[f][idx] != want[f][idx])[0]
+            assert bad.size == 0, "side %d field %s: task %s got %s want %s" % (side, f, idx[bad[:4]], got[f][idx[bad[:4]]], want[f][idx[bad[:4]]])
+
+
+@pytest.mark.parametrize("over", [
+    dict(), dict(zdrop=0), dict(w=5), dict(w=17, zdrop=0), dict(w=1), dict(w=40, zdrop=30),
+    dict(o_del=4, e_del=2, o_ins=4, e_ins=2), dict(o_del=0, e_del=1, o_ins=0, e_ins=1), dict(o_del=11, e_del=3, o_ins=11, e_ins=3, w=25),
+])
+def test_random_seeds_match_the_oracle(model, host, oracle, over):
+    rng = np.random.default_rng(abs(hash(str(sorted(over.items())))) % (2 ** 31))
+    seeds = _gen.random_seeds(rng, 700, qmin=1, qmax=135, tfac=2.2, sub=0.03, indel=0.02, junk=0.15, nrate=0.004, h0max=60)
+    for s in seeds:                                       # 8-bit score range of the kernel class
+        tot = len(s.get("lq", ())) + len(s.get("rq", ()))
+        s["h0"] = max(1, min(s["h0"], 255 - tot))
+    tasks, arena = host.make_tasks(seeds)
+    p = host.default_params(**over)
+    check(model, host, oracle, p, tasks)
+
+
+@pytest.mark.parametrize("ab_n", [(1, 4, -1), (2, 3, -1), (1, 1, 0), (1, 6, -2), (3, 5, -5)])
+def test_scoring_matrices(model, host, oracle, ab_n):
+    a, b, nn = ab_n
+    rng = np.random.default_rng(a * 100 + b)
+    seeds = _gen.random_seeds(rng, 400, qmin=1, qmax=135 // a, tfac=2.0, sub=0.05, indel=0.02, junk=0.1, nrate=0.01, h0max=40)
+    for s in seeds:
+        tot = len(s.get("lq", ())) + len(s.get("rq", ()))
+        s["h0"] = max(1, min(s["h0"], 255 - tot * a))
+    tasks, arena = host.make_tasks(seeds)
+    p = host.default_params()
+    p["mat"][0] = host.bwa_matrix(a, b, nn)
+    check(model, host, oracle, p, tasks)
+
+
+def test_bench_workload_shapes(model, host, oracle):
+    """The synthetic workloads bench.py times: single bin (qlen 131 / tlen 257) and mixed PE bins with Ns."""
+    p = host.default_params()
+    tasks, arena = host.synth_tasks(1500, seed=3)
+    check(model, host, oracle, p, tasks)
+    tasks, arena = host.synth_tasks(1500, seed=4, seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.1, n_rate=0.002)
+    check(model, host, oracle, p, tasks)
+
+
+def test_right_side_starts_from_the_left_score(model, host, oracle):
+    """h0 of the right extension = score after the left one (sw_pe_array_proc_element.v:1671)."""
+    p = host.default_params()
+    tasks, arena = host.synth_tasks(900, seed=5, seed_len_min=19, seed_len_max=50, seed_at_start=0, indel_rate=0.01)
+    full = oracle.pair_batch(p, tasks, nthreads=4)
+    h0s = np.where(tasks["lqlen"] > 0, full["left"]["score"], tasks["h0"]).astype(np.int32)
+    first_try = full["right"]["aw"] == int(p["w"][0])      # seeds whose right side needed no band retry
+    got, idx = run_side(model, host, p, tasks, 1, h0s)
+    sel = idx[first_try[idx]]
+    for f in EXTF:
+        assert (got[f][sel] == full["right"][f][sel]).all(), f
+
+
+def test_ragged_and_tiny_waves(model, host, oracle):
+    p = host.default_params()
+    for n in (1, 2, 63, 64, 65, 127, 129, 200):
+        tasks, arena = host.synth_tasks(n, seed=10 + n, seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.2, n_rate=0.003)
+        check(model, host, oracle, p, tasks)
