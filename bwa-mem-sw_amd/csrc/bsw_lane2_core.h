@@ -50,6 +50,8 @@ L2_FN uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { uint32_t d; asm("v_bfi_
 L2_FN uint32_t key_of(uint32_t h, uint32_t jj) { uint32_t d; asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(d) : "v"(h), "s"(jj)); return d; }
 L2_FN int ffs_lo(uint32_t x) { return (int)__builtin_ctz(x); }
 L2_FN int fls_hi(uint32_t x) { return 31 - (int)__builtin_clz(x); }
+/* a wave-uniform value the compiler must re-read here: keeps tests on it from being hoisted out of the row loop */
+L2_FN uint32_t opaque_s(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
 #else
 L2_FN uint16_t lo16(uint32_t a) { return (uint16_t)a; }
 L2_FN uint16_t hi16(uint32_t a) { return (uint16_t)(a >> 16); }
@@ -67,6 +69,7 @@ L2_FN uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & 
 L2_FN uint32_t key_of(uint32_t h, uint32_t jj) { return (h << 8) | jj; }
 L2_FN int ffs_lo(uint32_t x) { return __builtin_ctz(x); }
 L2_FN int fls_hi(uint32_t x) { return 31 - __builtin_clz(x); }
+L2_FN uint32_t opaque_s(uint32_t x) { return x; }
 #endif
 
 L2_FN uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x00010001u; }
@@ -91,6 +94,10 @@ struct seedv {                          /* the scalars of one ksw_extend2 call (
     int mx, max_i, max_j, max_ie, gscore, max_off;
     unsigned cells;
     bool alive;
+};
+
+struct u4 {                             /* four consecutive 32-bit words (one 128-bit LDS read) */
+    uint32_t v[4];
 };
 
 struct rowv {                           /* per-lane values of the current row, both seeds */
@@ -176,7 +183,10 @@ struct lane2 {
     L2_MFN void cell(uint32_t &P, const uint32_t Wc, const uint32_t WNc, const uint32_t AB2, const uint32_t Bv2, const uint32_t D2,
                            const consts &k, const uint32_t END2, uint32_t &mi_prev, uint32_t &h1, uint32_t &f, uint32_t &mk, uint32_t &nz)
     {
-        constexpr uint32_t JJ = (uint32_t)(J & 63) * 0x00010001u;
+        /* key and non-zero bit are relative to the 8-column block: 16 distinct SGPR constants in the whole kernel
+         * (column-absolute ones would be ~80, all hoisted out of the row loop, and spill) */
+        constexpr uint32_t JJ = (uint32_t)(J & 7) * 0x00010001u;
+        constexpr uint32_t BIT = (uint32_t)(1u << (J & 7)) * 0x00010001u;
         uint32_t t = (J & 15) ? (Wc >> (J & 15)) : Wc;
         t &= 0x00010001u;                                    /* 1 where q_j == t_i */
         const uint32_t hd = P & 0x00ff00ffu;                 /* eh[j].h = H(i-1,j-1) */
@@ -193,53 +203,63 @@ struct lane2 {
         uint32_t en = pk_max(pk_subs_vs(e, k.ED2), tD);         /* (:1866,1770-1771) */
         f = pk_max(pk_subs_vs(f, k.ED2), tD);                   /* (:1863,1780-1781) */
         if (!EDGE) {
-            mk = pk_max(mk, key_of(h, JJ));                  /* row max of this 64-column group, ties -> later j */
+            const uint32_t key = key_of(h, JJ);              /* row max of this block, ties -> later j */
+            mk = (J & 7) ? pk_max(mk, key) : key;
             const uint32_t np = (en << 8) | h1;              /* eh[j] = {e', H(i,j-1)} (:1776) */
-            nz = pk_mad_vsv(pk_min_vs(np, k.ONE2), dup16(1 << (J & 15)), nz);
+            const uint32_t nb = pk_min_vs(np, k.ONE2);
+            nz = (J & 7) ? pk_mad_vsv(nb, BIT, nz) : nb;
             P = np;
             h1 = h;
         } else {
-            const uint32_t d = pk_subs_vs(END2, dup16(J));   /* non-zero iff J < end */
+            const uint32_t d = pk_subs_vs(END2, dup16(J & 7));   /* END2 is relative to the block here: non-zero iff J < end */
             const uint32_t mi = pk_sub(0u, pk_min_vs(d, k.ONE2));   /* 0xffff where J < end */
             const uint32_t mw = mi | mi_prev;                /* 0xffff where J <= end */
             mi_prev = mi;
-            mk = pk_max(mk, key_of(h & mi, JJ));
+            const uint32_t key = key_of(h & mi, JJ);
+            mk = (J & 7) ? pk_max(mk, key) : key;
             en &= mi;
             const uint32_t np = ((en << 8) | h1) & mw;
-            nz = pk_mad_vsv(pk_min_vs(np, k.ONE2), dup16(1 << (J & 15)), nz);
+            const uint32_t nb = pk_min_vs(np, k.ONE2);
+            nz = (J & 7) ? pk_mad_vsv(nb, BIT, nz) : nb;
             P = bfi(mw, np, P);
             h1 = bfi(mi, h, h1);
         }
     }
 
-    /* match-mask words of one seed for target base tb: bit j = (q_j == t_i), neither an N, j >= beg */
-    template <class QP>
-    L2_MFN void match_words(const QP &qp, int x, int tb, int beg, const uni &u, uint32_t (&rm)[NW])
+    /* match-mask words of one seed for target base tb: bit j = (q_j == t_i), neither an N, j >= beg.
+     * mw(x, b, rm) loads the NW words precomputed for base b (0..3) of seed x's query: the kernel keeps the four
+     * per-base masks in LDS, so a row costs two LDS reads per seed and no plane arithmetic. */
+    template <class MW>
+    L2_MFN void match_words(const MW &mw, int x, int tb, int beg, uint32_t (&rm)[NW])
     {
-        const uint32_t n0 = (uint32_t)((tb & 1) - 1), n1 = (uint32_t)(((tb >> 1) & 1) - 1);
+        mw(x, tb & 3, rm);
         const uint32_t tn = (uint32_t)((tb >> 2) - 1);       /* 0 when the target base is N, else ~0 */
+        const int bw = beg >> 5;                             /* words below bw are cleared, word bw partly */
+        const uint32_t km = (0xffffffffu << (beg & 31)) & tn;
         sfor<NW>([&](auto wi) {
             constexpr int wd = decltype(wi)::value;
-            rm[wd] = 0;
-            if (32 * wd + 32 <= u.jlo || 32 * wd > u.jhi) return;
-            const uint32_t v = (qp(x, 0, wd) ^ n0) & (qp(x, 1, wd) ^ n1) & tn & ~qp(x, 2, wd);
-            const int sh = beg - 32 * wd;                    /* clear the columns below beg */
-            const uint32_t keep = sh <= 0 ? 0xffffffffu : (sh >= 32 ? 0u : (0xffffffffu << sh));
-            rm[wd] = v & keep;
+            const uint32_t keep = wd < bw ? 0u : (wd == bw ? km : tn);   /* clear the columns below beg */
+            rm[wd] &= keep;
         });
     }
 
+    /* the four per-base match words of one 32-column query word from its bit-planes (code bit 0, bit 1, N) */
+    L2_MFN uint32_t base_match(uint32_t p0, uint32_t p1, uint32_t p2, int b)
+    {
+        return ((b & 1) ? p0 : ~p0) & ((b & 2) ? p1 : ~p1) & ~p2;
+    }
+
     /* One DP row for both seeds, after the wave-uniform values are known.  tb[x] = target base of seed x (0..4).
-     * qp(x, plane, wd): query bit-planes (code bit 0, bit 1, N) of seed x; wn(c): N planes of both seeds interleaved
-     * per 16-column chunk (low half seed A). */
+     * qp(x, b, rm): per-base match words of seed x (see match_words); wn(c): N planes of both seeds interleaved per
+     * 16-column chunk (low half seed A). */
     template <class QP, class WN>
     L2_MFN void row_body(state &S, const consts &k, const int i, const rowv &r, const uni &u, const int (&tb)[2],
                                const QP &qp, const WN &wn)
     {
         if (u.anybite) zero_dropped(S, r, u);
         uint32_t rmA[NW], rmB[NW];
-        match_words(qp, 0, tb[0], S.s[0].beg, u, rmA);
-        match_words(qp, 1, tb[1], S.s[1].beg, u, rmB);
+        match_words(qp, 0, tb[0], S.s[0].beg, rmA);
+        match_words(qp, 1, tb[1], S.s[1].beg, rmB);
         /* a row against a target N scores -pn everywhere (mat[4][.], :1915-1940) */
         const int pbA = tb[0] < 4 ? k.pb : k.pn, pbB = tb[1] < 4 ? k.pb : k.pn;
         const uint32_t AB2 = pack2(k.a + pbA, k.a + pbB), Bv2 = pack2(pbA, pbB), D2 = pack2(pbA - k.pn, pbB - k.pn);
@@ -252,31 +272,40 @@ struct lane2 {
         sfor<NG>([&](auto gi) { mkg[decltype(gi)::value] = 0; });
         sfor<NC>([&](auto ci) { nzc[decltype(ci)::value] = 0; });
 
+        const int blo = u.jlo >> 3, bhi = u.jhi >> 3, bem = u.jem >> 3;      /* block granularity of the dispatch */
+        const uint32_t nblk = opaque_s(u.nblk);
         sfor<QB>([&](auto bi) {
-            constexpr int j0 = decltype(bi)::value * 8, g = j0 >> 6, c = j0 >> 4, wd = j0 >> 5;
-            if (j0 + 8 <= u.jlo || j0 > u.jhi) return;
+            constexpr int b = decltype(bi)::value, j0 = b * 8, g = j0 >> 6, c = j0 >> 4, wd = j0 >> 5;
+            if (b < blo) return;                              /* j0 + 8 <= jlo */
+            if (b > bhi) return;                              /* j0 > jhi */
             /* both seeds' match bits of this 16-column chunk: low half seed A, high half seed B */
             const uint32_t Wc = (c & 1) ? ((rmA[wd] >> 16) | (rmB[wd] & 0xffff0000u)) : ((rmA[wd] & 0xffffu) | (rmB[wd] << 16));
-            const bool nq = (u.nblk >> (j0 / 8)) & 1u;
-            const bool edge = j0 + 8 > u.jem;
-            if (!edge && !nq) {
+            uint32_t mkb = 0, nz8 = 0;                        /* this block's row-max key and non-zero bits */
+            /* nested scalar branches (a combined condition would be materialised as lane masks for all 17 blocks
+             * before the loop and spill) */
+            if (b < bem) {                                    /* j0 + 8 <= jem: inside every active seed's range */
                 uint32_t dummy = 0;
-                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, AB2, Bv2, D2, k, END2, dummy, h1, f, mkg[g], nzc[c]); });
-            } else if (!edge) {
-                uint32_t dummy = 0;
-                const uint32_t WNc = wn(c);
-                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, AB2, Bv2, D2, k, END2, dummy, h1, f, mkg[g], nzc[c]); });
-            } else {
-                /* mi of column j0 - 1 */
-                const uint32_t d0 = pk_subs_vs(pack2(S.s[0].end + 1, S.s[1].end + 1), dup16(j0));
-                uint32_t mi_prev = pk_sub(0u, pk_min_vs(d0, k.ONE2));
-                if (!nq) {
-                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, AB2, Bv2, D2, k, END2, mi_prev, h1, f, mkg[g], nzc[c]); });
+                if (!(nblk & (1u << b))) {
+                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, AB2, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
                 } else {
                     const uint32_t WNc = wn(c);
-                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, AB2, Bv2, D2, k, END2, mi_prev, h1, f, mkg[g], nzc[c]); });
+                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, AB2, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
+                }
+            } else {
+                /* mi of column j0 - 1 */
+                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
+                uint32_t mi_prev = pk_sub(0u, pk_min_vs(d0, k.ONE2));
+                const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
+                if (!(nblk & (1u << b))) {
+                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, AB2, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
+                } else {
+                    const uint32_t WNc = wn(c);
+                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, AB2, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
                 }
             }
+            /* fold the block into its 64-column group / 16-column chunk (column offsets only touch the low key bits) */
+            mkg[g] = pk_max(mkg[g], mkb + (uint32_t)(j0 & 63) * 0x00010001u);
+            nzc[c] |= (b & 1) ? (nz8 << 8) : nz8;
         });
 
         /* ---- row tail per seed (K7, K8) ---- */

@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t nib_plane(uint64_t w, int b)
 
 }  // namespace
 
-#define BSW_L2_TCHUNK 8         /* target words staged per seed in LDS = 128 DP rows */
+#define BSW_L2_TCHUNK 4         /* target words staged per seed in LDS = 64 DP rows */
 
 template <int QB, int WPS>
 __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P, const int side,
@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     using L = l2::lane2<QB>;
     constexpr int QMAX = L::QMAX, NW = L::NW, NC = L::NC;
     __shared__ uint64_t lds_t[4][2][BSW_L2_TCHUNK][64];             /* [wave][seed][word][lane] */
-    __shared__ uint32_t lds_q[4][2][3 * NW][64];                    /* query bit-planes: code bit 0, bit 1, N */
+    static_assert(NW == 5, "match-word staging below is laid out for 5 words (129..160 columns)");
+    __shared__ uint4 lds_m4[4][2][4][64];                           /* per-base match words 0..3: [wave][seed][base][lane] */
+    __shared__ uint32_t lds_m1[4][2][4][64];                        /* per-base match word 4 */
     __shared__ uint32_t lds_wn[4][NC][64];                          /* N planes of both seeds, 16 columns per half */
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t w0 = (blockIdx.x * 4u + (uint32_t)wv) * 128u + (uint32_t)lane;
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         if (!valid[x]) tlen = 0;
         ntw[x] = (tlen + 15) >> 4;
         L::init_seed(S.s[x], qlen, tlen, h0, min(P.w, wlim));
+        uint32_t mb[4][NW];
 #pragma unroll
         for (int wd = 0; wd < NW; ++wd) {
             uint32_t p0 = 0, p1 = 0, p2 = 0;
@@ -102,13 +105,17 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
                     p2 |= nib_plane(qw, 2) << (hlf * 16);
                 }
             }
-            lds_q[wv][x][3 * wd][lane] = p0;
-            lds_q[wv][x][3 * wd + 1][lane] = p1;
-            lds_q[wv][x][3 * wd + 2][lane] = p2;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mb[b][wd] = L::base_match(p0, p1, p2, b);
             q2[x][wd] = p2;
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 if (wd * 4 + b < QB && __builtin_amdgcn_ballot_w64(((p2 >> (8 * b)) & 0xffu) != 0) != 0) nblk |= 1u << (wd * 4 + b);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            lds_m4[wv][x][b][lane] = make_uint4(mb[b][0], mb[b][1], mb[b][2], mb[b][3]);
+            lds_m1[wv][x][b][lane] = mb[b][4];
         }
     });
 #pragma unroll
@@ -121,7 +128,11 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     k.OE2 = l2::dup16(P.o_del + P.e_del); k.ED2 = l2::dup16(P.e_del); k.ONE2 = 0x00010001u;
     L::init_row(S, k);
 
-    const auto qp = [&](int x, int plane, int wd) { return lds_q[wv][x][3 * wd + plane][lane]; };
+    const auto qp = [&](int x, int b, uint32_t (&rm)[NW]) {
+        const uint4 v = lds_m4[wv][x][b][lane];
+        rm[0] = v.x; rm[1] = v.y; rm[2] = v.z; rm[3] = v.w;
+        rm[4] = lds_m1[wv][x][b][lane];
+    };
     const auto wn = [&](int c) { return lds_wn[wv][c][lane]; };
     uint64_t tw[2] = {0ull, 0ull};
 
@@ -131,11 +142,19 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         if (__builtin_amdgcn_ballot_w64(r.act[0] || r.act[1]) == 0) break;
         if ((i & (BSW_L2_TCHUNK * 16 - 1)) == 0) {                    /* stage the next 128 target bases of every seed */
             const int wbase = i >> 4;
+            /* all 16 loads are issued before the first is waited for: the index is clamped instead of branched on
+             * (words past the end are never used: row i reads word i >> 4 < ntw; seq has slack behind the last word) */
+            uint64_t tv[2][BSW_L2_TCHUNK];
+            l2::sfor<2>([&](auto xi) {
+                constexpr int x = decltype(xi)::value;
+                const int last = max(ntw[x] - 1, 0);
+#pragma unroll
+                for (int q = 0; q < BSW_L2_TCHUNK; ++q) tv[x][q] = seq[t_off[x] + (uint32_t)min(wbase + q, last)];
+            });
             l2::sfor<2>([&](auto xi) {
                 constexpr int x = decltype(xi)::value;
 #pragma unroll
-                for (int q = 0; q < BSW_L2_TCHUNK; ++q)
-                    lds_t[wv][x][q][lane] = (r.act[x] && wbase + q < ntw[x]) ? seq[t_off[x] + wbase + q] : 0ull;
+                for (int q = 0; q < BSW_L2_TCHUNK; ++q) lds_t[wv][x][q][lane] = tv[x][q];
             });
         }
         if ((i & 15) == 0) {

@@ -99,7 +99,9 @@ struct wave_model {
                     int b = rv[l].act[x] ? a.t[x][i] : 0;
                     tb[x] = b > 4 ? 4 : b;
                 }
-                auto qp = [&](int x, int plane, int wd) { return a.qp[x][plane][wd]; };
+                auto qp = [&](int x, int b, uint32_t (&rm)[L::NW]) {
+                    for (int wd = 0; wd < L::NW; ++wd) rm[wd] = L::base_match(a.qp[x][0][wd], a.qp[x][1][wd], a.qp[x][2][wd], b);
+                };
                 auto wn = [&](int c) { return a.wn[c]; };
                 L::row_body(a.S, k, i, rv[l], u, tb, qp, wn);
             }

@@ -4,7 +4,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-prof}
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-extra ${BENCH_ARGS:-}"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json
