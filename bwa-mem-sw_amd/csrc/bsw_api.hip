@@ -185,6 +185,11 @@ struct bsw_ctx {
     int worker_rc = 0;
     /* small synchronous batches (bsw_extend_batch, scalar ABI, wire format) */
     stage_t small;
+    /* banded global alignment (F4) */
+    dbuf<bsw_gdtask> g_tasks;
+    dbuf<uint8_t> g_z;
+    dbuf<uint32_t> g_cig, g_order;
+    dbuf<bsw_gresult> g_res;
     std::vector<refbatch_req> ref_queue;
     int device0() const { return devs[0].device; }
     hipStream_t stream0() const { return devs[0].streams[0]; }
@@ -344,6 +349,7 @@ static void ctx_release(bsw_ctx *ctx)
         if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
         for (auto &pr : ctx->hist) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         ctx->small.release();
+        ctx->g_tasks.release(); ctx->g_z.release(); ctx->g_cig.release(); ctx->g_order.release(); ctx->g_res.release();
     }
     delete ctx;
 }
@@ -1595,4 +1601,183 @@ extern "C" int bsw_refbatch_run(bsw_ctx *ctx, const uint32_t *in_words, uint32_t
     const uint32_t n = in_words[2];
     rc = bsw_refbatch_wait(ctx, variant, zdrop);
     return rc < 0 ? rc : (int)n;
+}
+
+/* ---- banded global alignment with CIGAR (bwa ksw_global2) ------------------------------
+ * Host side: lay the alignments out as right-side-only seeds so the byte-per-base sequences travel and are packed
+ * exactly like extension tasks (registered arenas are DMA'd as they are), give every alignment its slice of the
+ * backtrack matrix, sort by eh[] columns per lane, launch bsw_global_kernel, bring scores and CIGARs back. */
+static int global_chunk(bsw_ctx *ctx, errs &e, const bsw_dparams &dp, const bsw_gtask *tasks, size_t n, int max_cigar,
+                        bsw_gresult *res, uint32_t *cigars)
+{
+    stage_t &st = ctx->small;
+    hipStream_t s = ctx->stream0();
+    hipError_t he;
+    if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess)
+        return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    std::vector<bsw_gdtask> gt(n);
+    const int ncls = bsw::global_class_count();
+    std::vector<uint32_t> order(n), cnt((size_t)ncls + 1, 0), cls(n);
+    uint64_t acc = 0, accb = 0, zacc = 0;
+    const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_gtask &t = tasks[i];
+        bsw_dtask &d = st.h_tasks.p[i];
+        bsw_rawoff &r = st.h_roff.p[i];
+        memset(&d, 0, sizeof(d));
+        memset(&r, 0, sizeof(r));
+        d.rq_off = (uint32_t)acc; acc += nwords(t.qlen);
+        d.rt_off = (uint32_t)acc; acc += nwords(t.tlen);
+        d.rqlen = (uint16_t)t.qlen; d.rtlen = (uint16_t)t.tlen;
+        r.rq = (uint32_t)accb; accb += (uint64_t)t.qlen;
+        r.rt = (uint32_t)accb; accb += (uint64_t)t.tlen;
+        if (t.qlen) { if (t.query < lo) lo = t.query; if (t.query + t.qlen > hi) hi = t.query + t.qlen; }
+        if (t.tlen) { if (t.target < lo) lo = t.target; if (t.target + t.tlen > hi) hi = t.target + t.tlen; }
+        bsw_gdtask &g = gt[i];
+        g.q_off = d.rq_off; g.t_off = d.rt_off; g.qlen = t.qlen; g.tlen = t.tlen; g.w = t.w; g.pad = 0; g.z_off = zacc;
+        const int n_col = t.qlen < 2 * t.w + 1 ? t.qlen : 2 * t.w + 1;
+        if (cigars) zacc += (uint64_t)n_col * (uint64_t)t.tlen;
+        int c = 0;
+        while (c < ncls && t.qlen + 1 > bsw::global_class_cols(c)) ++c;
+        cls[i] = (uint32_t)c;
+        ++cnt[(size_t)c + 1];
+    }
+    for (int c = 0; c < ncls; ++c) cnt[(size_t)c + 1] += cnt[(size_t)c];
+    {
+        std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
+        for (size_t i = 0; i < n; ++i) order[pos[cls[i]]++] = (uint32_t)i;
+    }
+    const size_t spanb = hi ? (size_t)(hi - lo) : 0;
+    const bool direct = spanb > 0 && spanb < (1ull << 32) - RAW_SLACK && spanb <= 2 * accb + (1u << 20) && is_registered(lo, spanb);
+    if (direct) {
+        for (size_t i = 0; i < n; ++i) {
+            bsw_rawoff &r = st.h_roff.p[i];
+            r.rq = tasks[i].qlen ? (uint32_t)(tasks[i].query - lo) : 0;
+            r.rt = tasks[i].tlen ? (uint32_t)(tasks[i].target - lo) : 0;
+        }
+    } else {
+        if ((he = st.h_raw.reserve((size_t)accb + RAW_SLACK)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+        for (size_t i = 0; i < n; ++i) {
+            if (tasks[i].qlen) memcpy(st.h_raw.p + st.h_roff.p[i].rq, tasks[i].query, (size_t)tasks[i].qlen);
+            if (tasks[i].tlen) memcpy(st.h_raw.p + st.h_roff.p[i].rt, tasks[i].target, (size_t)tasks[i].tlen);
+        }
+    }
+    const size_t rawb = direct ? spanb : (size_t)accb;
+    if ((he = st.d_raw.reserve(rawb + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve((size_t)acc + 4)) != hipSuccess ||
+        (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_roff.reserve(n + 1)) != hipSuccess ||
+        (he = ctx->g_tasks.reserve(n + 1)) != hipSuccess || (he = ctx->g_order.reserve(n + 1)) != hipSuccess ||
+        (he = ctx->g_res.reserve(n + 1)) != hipSuccess || (cigars && (he = ctx->g_z.reserve((size_t)zacc + 64)) != hipSuccess) ||
+        (cigars && (he = ctx->g_cig.reserve(n * (size_t)max_cigar + 1)) != hipSuccess))
+        return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    if (rawb) HIPCHK(e, hipMemcpyAsync(st.d_raw.p, direct ? lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(ctx->g_tasks.p, gt.data(), n * sizeof(bsw_gdtask), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(ctx->g_order.p, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(e, bsw::launch_pack(st.d_raw.p, st.d_tasks.p, st.d_roff.p, (uint32_t)n, 0, st.d_seq.p, s));
+    for (int c = 0; c < ncls; ++c) {
+        const uint32_t k = cnt[(size_t)c + 1] - cnt[(size_t)c];
+        if (!k) continue;
+        HIPCHK(e, bsw::launch_global(c, dp, st.d_seq.p, ctx->g_tasks.p, ctx->g_order.p + cnt[(size_t)c], k,
+                                     cigars ? ctx->g_z.p : nullptr, cigars ? ctx->g_cig.p : nullptr, max_cigar, ctx->g_res.p, s));
+    }
+    int rc = sync_stream(ctx, e, s, ctx->devs[0].events[0]);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpy(res, ctx->g_res.p, n * sizeof(bsw_gresult), hipMemcpyDeviceToHost));
+    if (cigars) HIPCHK(e, hipMemcpy(cigars, ctx->g_cig.p, n * (size_t)max_cigar * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return BSW_OK;
+}
+
+extern "C" int bsw_global_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_gtask *tasks, size_t n, int max_cigar,
+                                bsw_gresult *res, uint32_t *cigars)
+{
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!p || (!tasks && n) || (!res && n) || (cigars && max_cigar < 1)) return fail(e, BSW_E_INVAL, "bsw_global_batch: bad argument");
+    int rc = busy_check(ctx, "bsw_global_batch");
+    if (rc) return rc;
+    bsw_params pp = *p;
+    pp.w = 0;                                         /* the band is per task here */
+    bsw_dparams dp;
+    rc = check_params(e, &pp, &dp);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_gtask &t = tasks[i];
+        if (t.qlen < 0 || t.tlen < 0 || t.w < 0) return fail(e, BSW_E_INVAL, "global task %zu: negative length or band", i);
+        if (t.qlen > BSW_MAX_QLEN || t.tlen > BSW_MAX_TLEN || t.w > BSW_MAX_TLEN) return fail(e, BSW_E_LIMIT, "global task %zu: beyond BSW_MAX_QLEN/BSW_MAX_TLEN", i);
+        if ((t.qlen && !t.query) || (t.tlen && !t.target)) return fail(e, BSW_E_INVAL, "global task %zu: NULL sequence pointer", i);
+    }
+    HIPCHK(e, hipSetDevice(ctx->device0()));
+    /* sub-batches: bounded backtrack memory (1 byte per banded cell) and sequence arena */
+    const uint64_t zcap = 4ull << 30;
+    for (size_t a = 0; a < n;) {
+        size_t b = a;
+        uint64_t zb = 0, sb = 0;
+        while (b < n && b - a < (1u << 20)) {
+            const bsw_gtask &t = tasks[b];
+            const uint64_t nz = (uint64_t)(t.qlen < 2 * t.w + 1 ? t.qlen : 2 * t.w + 1) * (uint64_t)t.tlen;
+            if (b > a && (zb + nz > zcap || sb + (uint64_t)(t.qlen + t.tlen) > (1ull << 31))) break;
+            zb += cigars ? nz : 0;
+            sb += (uint64_t)(t.qlen + t.tlen);
+            ++b;
+        }
+        rc = global_chunk(ctx, e, dp, tasks + a, b - a, max_cigar, res + a, cigars ? cigars + a * (size_t)max_cigar : nullptr);
+        if (rc) return rc;
+        a = b;
+    }
+    return BSW_OK;
+}
+
+/* drop-in scalar ABI: one alignment per call through the process-wide context (serialised; the batch API above is
+ * the fast path).  Failure contract as ksw_extend2: message on stderr, *n_cigar = 0, return -1. */
+extern "C" int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                           int o_del, int e_del, int o_ins, int e_ins, int w, int *n_cigar_, uint32_t **cigar_)
+{
+    if (n_cigar_) *n_cigar_ = 0;
+    if (cigar_) *cigar_ = nullptr;
+    if (m != 5 || !mat || qlen < 0 || tlen < 0 || (qlen > 0 && !query) || (tlen > 0 && !target)) {
+        fprintf(stderr, "ksw_global2(libbwasw_mi355): unsupported arguments (m must be 5)\n");
+        return -1;
+    }
+    std::unique_lock<std::mutex> lk(g_mu);
+    while (g_leader) g_cv.wait(lk);                   /* share the scalar context with the ksw_extend2 round trips */
+    g_leader = true;
+    lk.unlock();
+    int score = -1;
+    {
+        std::vector<scalar_req *> none;
+        if (!g_ctx && !g_ctx_rc) scalar_round_trip(none);          /* creates the context */
+        if (g_ctx) {
+            bsw_params p;
+            bsw_default_params(&p);
+            memcpy(p.mat, mat, 25);
+            p.o_del = o_del; p.e_del = e_del; p.o_ins = o_ins; p.e_ins = e_ins;
+            bsw_gtask t;
+            memset(&t, 0, sizeof(t));
+            t.query = query; t.target = target; t.qlen = qlen; t.tlen = tlen; t.w = w < 0 ? 0 : w;
+            const bool want = n_cigar_ && cigar_;
+            const int cap = qlen + tlen + 2;
+            std::vector<uint32_t> cg(want ? (size_t)cap : 1);
+            bsw_gresult r;
+            const int rc = bsw_global_batch(g_ctx, &p, &t, 1, cap, &r, want ? cg.data() : nullptr);
+            if (rc) fprintf(stderr, "ksw_global2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
+            else {
+                score = r.score;
+                if (want && r.n_cigar > 0) {
+                    *cigar_ = (uint32_t *)malloc((size_t)r.n_cigar * sizeof(uint32_t));
+                    if (*cigar_) { memcpy(*cigar_, cg.data(), (size_t)r.n_cigar * sizeof(uint32_t)); *n_cigar_ = r.n_cigar; }
+                }
+            }
+        }
+    }
+    lk.lock();
+    g_leader = false;
+    g_cv.notify_all();
+    return score;
+}
+
+extern "C" int ksw_global(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                          int gapo, int gape, int w, int *n_cigar_, uint32_t **cigar_)
+{
+    return ksw_global2(qlen, query, tlen, target, m, mat, gapo, gape, gapo, gape, w, n_cigar_, cigar_);
 }

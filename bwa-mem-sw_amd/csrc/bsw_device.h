@@ -56,6 +56,14 @@ typedef struct bsw_fetch_desc {
     int32_t  pad;
 } bsw_fetch_desc;
 
+/* one banded global alignment (bsw_global_kernel.hip) */
+typedef struct bsw_gdtask {
+    uint32_t q_off, t_off;    /* word offsets into seq */
+    int32_t  qlen, tlen, w;
+    uint32_t pad;
+    uint64_t z_off;           /* byte offset of this alignment's backtrack matrix */
+} bsw_gdtask;
+
 #define BSW_KEY_BITS 10                        /* column index bits in the arg-max key */
 
 /* ---- binning: which kernel class a seed goes to.  The host counts seeds per class with these

@@ -33,6 +33,10 @@ hipError_t launch_fetch(const uint8_t *pac, int64_t l_pac, const bsw_fetch_desc 
 hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, int skip_targets,
                        uint64_t *seq, hipStream_t s);
 hipError_t launch_wire_pack(const uint32_t *wire, const bsw_dtask *tasks, const bsw_wireoff *woffs, uint32_t n, uint64_t *seq, hipStream_t s);
+int global_class_count();
+int global_class_cols(int cls);
+hipError_t launch_global(int cls, const bsw_dparams &P, const uint64_t *seq, const bsw_gdtask *tasks, const uint32_t *order, uint32_t n,
+                         uint8_t *z, uint32_t *cigars, int max_cigar, bsw_gresult *out, hipStream_t s);
 hipError_t launch_bin(const bsw_binparams &bp, const bsw_dtask *tasks, uint32_t n, uint32_t *bins, uint32_t *order, hipStream_t s);
 }  // namespace bsw
 

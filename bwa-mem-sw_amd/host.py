@@ -33,6 +33,8 @@ SYNTH = np.dtype([("seed", "<u8"), ("read_len", "<i4"), ("seed_len_min", "<i4"),
 SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
 ALNREG = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("score", "<i4"), ("truesc", "<i4"),
                    ("w", "<i4"), ("_pad", "<i4")])
+GTASK = np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("_pad", "<i4")])
+GRESULT = np.dtype([("score", "<i4"), ("n_cigar", "<i4")])
 REF_TASK = np.dtype([("query", "<u8"), ("l_query", "<i4"), ("init_score", "<i4"), ("seed", SEED),
                      ("rmax0", "<i8"), ("rmax1", "<i8"), ("tag", "<u4"), ("_pad", "<u4")])
 MAX_DEVICES = 16
@@ -105,6 +107,9 @@ def lib():
             "bsw_host_register": (C.c_int, [vp, sz]), "bsw_host_unregister": (C.c_int, [vp]),
             "bsw_batch_order": (C.c_int, [vp, vp, vp, vp]),
             "bsw_scalar_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+            "bsw_global_batch": (C.c_int, [vp, vp, vp, sz, C.c_int, vp, vp]),
+            "ksw_global2": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp] + [C.c_int] * 5 + [vp, vp]),
+            "ksw_global": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp] + [C.c_int] * 3 + [vp, vp]),
             "bsw_ref_upload": (C.c_int, [vp, vp, C.c_int64, C.POINTER(vp)]),
             "bsw_ref_free": (None, [vp, vp]),
             "bsw_upload_ref": (C.c_int, [vp, vp, vp, vp, sz, C.POINTER(vp)]),
@@ -130,7 +135,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_scalar_stats", "bsw_host_alloc", "bsw_host_free",
+EXPORTS = ["ksw_global2", "ksw_global", "bsw_global_batch", "ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_scalar_stats", "bsw_host_alloc", "bsw_host_free",
            "bsw_host_register", "bsw_host_unregister", "bsw_batch_order", "bsw_refbatch_submit", "bsw_refbatch_wait", "bsw_default_params", "bsw_default_config",
            "bsw_device_count", "bsw_create", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
@@ -316,6 +321,14 @@ class BswContext:
         out = np.zeros(batch.n, dtype=RESULT)
         self._chk(lib().bsw_download(self.handle, batch.handle, out.ctypes.data), "bsw_download")
         return out
+
+    def global_batch(self, params, gtasks, max_cigar=64, want_cigar=True):
+        """Batched ksw_global2.  Returns (GRESULT array, cigars uint32[n, max_cigar] or None)."""
+        res = np.zeros(len(gtasks), dtype=GRESULT)
+        cig = np.zeros((len(gtasks), max_cigar), dtype=np.uint32) if want_cigar else None
+        self._chk(lib().bsw_global_batch(self.handle, params.ctypes.data, gtasks.ctypes.data, len(gtasks), max_cigar,
+                                         res.ctypes.data, cig.ctypes.data if want_cigar else None), "bsw_global_batch")
+        return res, cig
 
     def batch_order(self, batch):
         """Launch order the device-side binning produced (order, seg) — same layout as plan_batch."""

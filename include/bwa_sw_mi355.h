@@ -183,6 +183,28 @@ int      bsw_wait(bsw_ctx *ctx);
 /* Batched plain ksw_extend2 (one pass each, w/end_bonus/h0 per task); synchronous. */
 int      bsw_extend_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_ext_task *tasks, size_t n, bsw_ext *out);
 
+/* ---- banded global alignment with CIGAR: bwa's ksw_global2 / ksw_global (ksw.c), the
+ * Smith-Waterman user after seed extension inside mem_reg2aln (bwa_gen_cigar2).  Not in the reference RTL — it
+ * belongs to the host software named at reference README.md:7-18.  CIGAR encoding is BAM's: len << 4 | op,
+ * op 0 = M, 1 = I, 2 = D. ---- */
+typedef struct bsw_gtask {
+    const uint8_t *query, *target;   /* codes 0..4, one per byte */
+    int32_t qlen, tlen, w;           /* w = band half-width */
+    int32_t _pad;
+} bsw_gtask;
+typedef struct bsw_gresult {
+    int32_t score;                   /* eh[qlen].h of the last row, exactly as bwa returns it */
+    int32_t n_cigar;                 /* CIGAR operations written; < 0: -n operations did not fit max_cigar */
+} bsw_gresult;
+/* Batched ksw_global2 on the GPU.  cigars (may be NULL: scores only) receives max_cigar words per task. */
+int      bsw_global_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_gtask *tasks, size_t n, int max_cigar,
+                          bsw_gresult *res, uint32_t *cigars);
+/* drop-in scalar ABI (bwa ksw.h): *cigar is malloc'ed, the caller frees it; n_cigar / cigar may be NULL */
+int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                int o_del, int e_del, int o_ins, int e_ins, int w, int *n_cigar, uint32_t **cigar);
+int ksw_global(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+               int gapo, int gape, int w, int *n_cigar, uint32_t **cigar);
+
 /* ---- device-resident batches (inputs in HBM before the timed region) ------- */
 int      bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out);
 int      bsw_run(bsw_ctx *ctx, bsw_dev_batch *b);          /* enqueue kernels only        */

@@ -42,6 +42,10 @@ int ksw_extend_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
                    int *qle, int *tle, int *gtle, int *gscore, int *max_off,
                    int variant, uint64_t *cells);
 
+/* bwa's banded global alignment with CIGAR (oracle/ksw_global_ref.c).  *cigar_ is malloc'ed. */
+int ksw_global2_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                    int o_del, int e_del, int o_ins, int e_ins, int w, int *n_cigar_, uint32_t **cigar_, uint64_t *cells_);
+
 /* mem_chain2aln left/right extension + MAX_BAND_TRY + clip decision for one seed. */
 void bsw_pair_ref(const bsw_params *p, const bsw_task *t, bsw_result *r);
 

@@ -55,3 +55,40 @@ def full_dp(query, target, mat, o_del, e_del, o_ins, e_ins, h0, variant=0, m=5):
             max_off = max(max_off, abs(mj - i))
     return dict(score=int(best), qle=max_j + 1, tle=max_i + 1, gtle=max_ie + 1,
                 gscore=int(gscore), max_off=int(max_off), minH=int(H.min()) if H.size else 0)
+
+
+NEG = -(1 << 40)
+
+
+def global_dp(query, target, mat, o_del, e_del, o_ins, e_ins, m=5):
+    """Independent unbanded global affine-gap alignment score (Gotoh; three full matrices), written from the textbook
+    recurrence — the second opinion for oracle/ksw_global_ref.c when its band cannot bind.  Deletion = gap in the
+    query (consumes target), insertion = gap in the target (consumes query)."""
+    q = np.asarray(query, dtype=np.int64)
+    t = np.asarray(target, dtype=np.int64)
+    mat = np.asarray(mat, dtype=np.int64).reshape(m, m)
+    ql, tl = len(q), len(t)
+    H = np.full((tl + 1, ql + 1), NEG, dtype=np.int64)
+    E = np.full((tl + 1, ql + 1), NEG, dtype=np.int64)     # ends with a deletion
+    F = np.full((tl + 1, ql + 1), NEG, dtype=np.int64)     # ends with an insertion
+    H[0][0] = 0
+    for j in range(1, ql + 1):
+        F[0][j] = H[0][j] = -(o_ins + e_ins * j)
+    for i in range(1, tl + 1):
+        E[i][0] = H[i][0] = -(o_del + e_del * i)
+        for j in range(1, ql + 1):
+            Mv = H[i - 1][j - 1] + mat[t[i - 1]][q[j - 1]]
+            # bwa opens gaps from M only (ksw.c comment: "10M3I3D10M" is disallowed by global())
+            E[i][j] = max(E[i - 1][j] - e_del, _M(H, E, F, i - 1, j, mat, t, q) - o_del - e_del)
+            F[i][j] = max(F[i][j - 1] - e_ins, _M(H, E, F, i, j - 1, mat, t, q) - o_ins - e_ins)
+            H[i][j] = max(Mv, E[i][j], F[i][j])
+    return int(H[tl][ql])
+
+
+def _M(H, E, F, i, j, mat, t, q):
+    """M(i,j) = H(i-1,j-1) + s: the score of a path that ends with a (mis)match at (i,j); borders: the leading gap."""
+    if i == 0 and j == 0:
+        return 0
+    if i == 0 or j == 0:
+        return NEG          # a border cell ends with a gap, not with a match
+    return H[i - 1][j - 1] + mat[t[i - 1]][q[j - 1]]

@@ -42,6 +42,9 @@ def lib():
         L.bsw_pair_batch_ref.restype = None
         L.bsw_ext_batch_ref.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.bsw_ext_batch_ref.restype = None
+        L.ksw_global2_ref.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, I32P, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint64)]
+        L.ksw_global2_ref.restype = C.c_int
         _lib = L
     return _lib
 
@@ -83,3 +86,23 @@ def ext_batch(params, etasks, nthreads=1):
     out = np.zeros(len(etasks), dtype=host.EXT)
     lib().bsw_ext_batch_ref(params.ctypes.data, etasks.ctypes.data, len(etasks), out.ctypes.data, nthreads)
     return out
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def global2(query, target, mat, o_del, e_del, o_ins, e_ins, w, want_cigar=True, m=5):
+    """bwa ksw_global2 on the oracle.  Returns dict(score, cigar=[(op, len), ...], cells); ops 0=M 1=I 2=D."""
+    q, qp = _u8(query)
+    t, tp = _u8(target)
+    mt = np.ascontiguousarray(mat, dtype=np.int8)
+    n = C.c_int32(0)
+    cig = C.POINTER(C.c_uint32)()
+    cells = C.c_uint64(0)
+    score = lib().ksw_global2_ref(len(q), qp, len(t), tp, m, mt.ctypes.data, o_del, e_del, o_ins, e_ins, w,
+                                  C.byref(n) if want_cigar else None, C.byref(cig) if want_cigar else None, C.byref(cells))
+    ops = [(int(cig[i]) & 0xf, int(cig[i]) >> 4) for i in range(n.value)]
+    if want_cigar and cig:
+        _libc.free(cig)
+    return dict(score=score, cigar=ops, cells=cells.value)

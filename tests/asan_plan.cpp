@@ -24,6 +24,9 @@ hipError_t launch_fetch(const uint8_t *, int64_t, const bsw_fetch_desc *, uint32
 hipError_t launch_pack(const uint8_t *, const bsw_dtask *, const bsw_rawoff *, uint32_t, int, uint64_t *, hipStream_t) { return hipSuccess; }
 hipError_t launch_wire_pack(const uint32_t *, const bsw_dtask *, const bsw_wireoff *, uint32_t, uint64_t *, hipStream_t) { return hipSuccess; }
 hipError_t launch_bin(const bsw_binparams &, const bsw_dtask *, uint32_t, uint32_t *, uint32_t *, hipStream_t) { return hipSuccess; }
+int global_class_count() { return 5; }
+int global_class_cols(int c) { return (1 << c) * 64; }
+hipError_t launch_global(int, const bsw_dparams &, const uint64_t *, const bsw_gdtask *, const uint32_t *, uint32_t, uint8_t *, uint32_t *, int, bsw_gresult *, hipStream_t) { return hipSuccess; }
 }
 
 int main()

