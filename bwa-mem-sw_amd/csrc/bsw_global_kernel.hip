@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void bsw_global_kernel(const bsw_dparams P, co
 #pragma unroll
         for (int c = C - 1; c >= 0; --c) {
             const int j = jbase + c;
-            const bool wr = j >= beg && j <= end;
+            const bool wr = (j >= beg && j <= end) || j == end;      /* eh[end] is written even when the band has left the query (end < beg) */
             const int hp = c == 0 ? hleft : hv[c - 1];
-            const int xn = j == beg ? h1_init : hp;
+            const int xn = (j == beg || end <= beg) ? h1_init : hp;
             X[c] = wr ? xn : X[c];
             E[c] = j == end ? GMINF : E[c];
         }
@@ -210,7 +210,10 @@ __global__ __launch_bounds__(256) void bsw_global_kernel(const bsw_dparams P, co
                 } else last += (uint32_t)len << 4;
             };
             while (i >= 0 && k >= 0) {
-                const uint8_t d = zt[(size_t)i * (size_t)n_col + (size_t)(k - (i > w ? i - w : 0))];
+                /* a band narrower than |qlen - tlen| cannot hold the path: bwa then walks through z entries of other
+                 * cells (unspecified result); here such a step reads as "diagonal" and never leaves the matrix */
+                const int col = k - (i > w ? i - w : 0);
+                const uint8_t d = (col >= 0 && col < n_col) ? zt[(size_t)i * (size_t)n_col + (size_t)col] : (uint8_t)0;
                 which = (d >> (which << 1)) & 3;
                 if (which == 0) { push(0u, 1); --i; --k; }
                 else if (which == 1) { push(2u, 1); --i; }
