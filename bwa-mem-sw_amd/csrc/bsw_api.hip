@@ -208,10 +208,17 @@ struct bsw_dev_batch {
 
 /* ---- watchdog: never block in the runtime without a deadline (the RTL documents an
  * inactivity timeout, bwa_mem_sw.v:84-101, but a wedged PE array leaves its busy bit set forever) ---- */
+static int wait_event(bsw_ctx *ctx, errs &e, hipEvent_t ev);
 static int sync_stream(bsw_ctx *ctx, errs &e, hipStream_t st, hipEvent_t ev)
 {
     if (ctx->dead) return fail(e, BSW_E_HIP, "context is dead (an earlier wait for the GPU timed out)");
     HIPCHK(e, hipEventRecord(ev, st));
+    return wait_event(ctx, e, ev);
+}
+
+static int wait_event(bsw_ctx *ctx, errs &e, hipEvent_t ev)
+{
+    if (ctx->dead) return fail(e, BSW_E_HIP, "context is dead (an earlier wait for the GPU timed out)");
     const auto t0 = std::chrono::steady_clock::now();
     const double limit = ctx->cfg.timeout_ms > 0 ? (double)ctx->cfg.timeout_ms : 120000.0;
     for (;;) {
@@ -312,7 +319,7 @@ extern "C" void bsw_default_config(bsw_config *c)
     c->kernel = BSW_KERNEL_AUTO;
     c->streams = 4;
     c->pack_threads = 4;
-    c->chunk_tasks = 65536;
+    c->chunk_tasks = 131072;
     c->n_devices = 0;
     c->timeout_ms = 120000;
 }
@@ -363,7 +370,7 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
     if (c.streams < 1) c.streams = 2;
     if (c.streams > 8) c.streams = 8;
     if (c.pack_threads < 1) c.pack_threads = 1;
-    if (c.chunk_tasks == 0) c.chunk_tasks = 65536;
+    if (c.chunk_tasks == 0) c.chunk_tasks = 131072;
     if (c.timeout_ms <= 0) c.timeout_ms = 120000;
     if (const char *t = getenv("BSW_TIMEOUT_MS")) { if (atoi(t) > 0) c.timeout_ms = atoi(t); }
     if (c.n_devices < 0 || c.n_devices > BSW_MAX_DEVICES) return BSW_E_INVAL;
@@ -1157,28 +1164,67 @@ static std::vector<std::vector<chunk_span>> plan_chunks(size_t n, size_t chunk, 
     return out;
 }
 
+/* One slot = one host thread + one stream + one set of staging buffers.  Per chunk: host pass (validate, lay out,
+ * count) -> wait for the slot's previous chunk -> input DMAs in the device's chunk order -> pack, bin, DP kernels,
+ * result DMA.  The host pass of chunk k+S runs while chunk k is still on the GPU: it only needs the pinned host
+ * staging, which is free again as soon as chunk k's input DMAs are done. */
 static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp, const bsw_task *tasks,
                        bsw_result *out, const std::vector<chunk_span> &chunks, size_t d, size_t s, int gather_threads,
                        std::atomic<int> &abort_flag, h2d_gate &gate, errs &e)
 {
     dev_state &dev = ctx->devs[d];
     const size_t S = dev.slots.size();
-    auto bail = [&](int rc) {                       /* wake the slots waiting for their DMA turn */
+    stage_t &st = dev.slots[s];
+    hipStream_t stream = dev.streams[s];
+    struct { bool active = false; size_t n = 0; bsw_result *out = nullptr; bool direct = false; } pend;
+    auto bail = [&](int rc) {                       /* wake the slots waiting for their DMA turn; leave nothing in flight */
         abort_flag = 1;
         { std::lock_guard<std::mutex> lk(gate.mu); }
         gate.cv.notify_all();
+        if (pend.active) { errs quiet; (void)sync_stream(ctx, quiet, stream, dev.events[s]); pend.active = false; }
         return rc;
     };
     hipError_t he = hipSetDevice(dev.device);
     if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)));
+    auto finish = [&]() -> int {                    /* the slot's chunk in flight: wait (watchdog), hand the results over */
+        if (!pend.active) return BSW_OK;
+        pend.active = false;
+        const int rc = sync_stream(ctx, e, stream, dev.events[s]);
+        if (rc) return rc;
+        if (!pend.direct) memcpy(pend.out, st.h_out.p, pend.n * sizeof(bsw_result));
+        return BSW_OK;
+    };
     for (size_t k = s; k < chunks.size() && !abort_flag; k += S) {            /* k-th chunk of this device */
+        const bsw_task *ct = tasks + chunks[k].base;
+        const size_t n = chunks[k].cnt;
+        int rc = BSW_OK;
+        if (pend.active) rc = wait_event(ctx, e, dev.h2d_done[s]);           /* pinned host staging is free again */
+        if (rc) return bail(rc);
+        if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess)
+            return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
+        chunk_info ci;
+        rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci);
+        if (rc) return bail(rc);
+        if (!ci.direct) {
+            if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
+            gather_raw(ct, st.h_roff.p, n, false, st.h_raw.p, gather_threads);
+        }
+        rc = finish();
+        if (rc) return bail(rc);
         gate_turn turn;
         turn.gate = &gate; turn.seq = k; turn.ev = dev.h2d_done[s]; turn.abort_flag = &abort_flag;
-        const int rc = run_chunk(ctx, e, dev.slots[s], dev.streams[s], dev.events[s], p, dp, tasks + chunks[k].base, chunks[k].cnt,
-                                 out + chunks[k].base, gather_threads, &turn);
+        rc = stage_device(e, st, stream, ci, n, false, nullptr, 0, nullptr, &turn);
+        if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr);
         if (rc) return bail(rc);
+        bsw_result *co = out + chunks[k].base;
+        pend.direct = is_registered(co, n * sizeof(bsw_result));
+        if (!pend.direct && (he = st.h_out.reserve(n)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
+        he = hipMemcpyAsync(pend.direct ? co : st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, stream);
+        if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(he)));
+        pend.active = true; pend.n = n; pend.out = co;
     }
-    return BSW_OK;
+    const int rc = finish();
+    return rc ? bail(rc) : BSW_OK;
 }
 
 static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, size_t n, bsw_result *out)
@@ -1490,43 +1536,79 @@ static int refbatch_group(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int z
     uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0};
     uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0;
     uint64_t acc = 0;
-    size_t ti = 0;
+    /* pass 1 (cheap): where every batch's tasks and sequence words start */
+    std::vector<uint64_t> wbase(nb + 1, 0), tbase(nb + 1, 0);
     for (size_t q = q0; q < q1; ++q) {
         const uint32_t *W = ctx->ref_queue[q].in;
         const uint32_t nt = W[2];
-        if (nt == 0) continue;
-        const int64_t base = (int64_t)(8 + 8 * nt) - (int64_t)W[8 + 2];
-        for (uint32_t i = 0; i < nt; ++i, ++ti) {
+        uint64_t words = 0;
+        for (uint32_t i = 0; i < nt; ++i) {
             const uint32_t *H = &W[8 + 8 * i];
-            bsw_dtask &d = st.h_tasks.p[ti];
-            bsw_wireoff &wo = st.h_woff.p[ti];
-            memset(&d, 0, sizeof(d));
             const int lq = (int)(H[0] & 0xff), lt = (int)((H[0] >> 16) & 0x7ff), rq = (int)(H[1] & 0xff), rt = (int)((H[1] >> 16) & 0x7ff);
-            const int64_t pos = base + (int64_t)H[2];
-            if (pos < 8 + 8 * (int64_t)nt || pos + (lq + rq + lt + rt + 7) / 8 > BSW_REFBATCH_IN_WORDS)
-                return fail(e, BSW_E_INVAL, "malformed task batch (task %u: data position)", i);
-            const int h0 = (int)(H[4] & 0xff);
-            if (h0 <= 0) return fail(e, BSW_E_INVAL, "task batch: task %u has h0 <= 0", i);
-            wo.nib = ((uint64_t)(q - q0) * BSW_REFBATCH_IN_WORDS + (uint64_t)pos) * 8u;
-            wo.lqlen = (uint16_t)lq; wo.rqlen = (uint16_t)rq; wo.ltlen = (uint16_t)lt; wo.rtlen = (uint16_t)rt;
-            if (lq) { d.lq_off = (uint32_t)acc; acc += nwords(lq); d.lt_off = (uint32_t)acc; acc += nwords(lt); }
-            if (rq) { d.rq_off = (uint32_t)acc; acc += nwords(rq); d.rt_off = (uint32_t)acc; acc += nwords(rt); }
-            d.lqlen = (uint16_t)lq; d.rqlen = (uint16_t)rq; d.ltlen = (uint16_t)lt; d.rtlen = (uint16_t)rt;
-            /* H5/H6 = {max_del[31:16], max_ins[15:0]}: the band limit the RTL applies (proc_element.v:925,933) */
-            auto lim = [](uint32_t h) {
-                const int mi = (int)(int16_t)(h & 0xffff), md = (int)(int16_t)(h >> 16);
-                const int l = mi < md ? mi : md;
-                return (uint16_t)(l < 0 ? 0 : l);
-            };
-            d.wlim_l = lim(H[5]); d.wlim_r = lim(H[6]);
-            d.h0 = h0; d.init_score = (int)(int16_t)(H[3] & 0xffff); d.qbeg = (int)(H[3] >> 16); d.tag = H[7];
-            const int wc = bsw_wave_class_of(&bp, std::max(lq, rq));
-            ++cw_all[wc];
-            const int bits = bsw_seed_lane_bits(&bp, lq, rq, h0);
-            if (!bits) ++cw[wc];
-            else { ++n_lane; if (lq) ++cl[bsw_side_lane_class(&bp, bits, lq)]; if (rq) ++cr[bsw_side_lane_class(&bp, bits, rq)]; }
+            words += (lq ? nwords(lq) + nwords(lt) : 0) + (rq ? nwords(rq) + nwords(rt) : 0);
         }
-        memcpy((uint32_t *)st.h_raw.p + (q - q0) * (size_t)BSW_REFBATCH_IN_WORDS, W, BSW_REFBATCH_IN_WORDS * sizeof(uint32_t));
+        wbase[q - q0 + 1] = wbase[q - q0] + words;
+        tbase[q - q0 + 1] = tbase[q - q0] + nt;
+    }
+    acc = wbase[nb];
+    /* pass 2 (parallel over batches): records, class counts, and the batch itself into pinned staging */
+    struct part { uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0; int rc = 0; errs e; };
+    const size_t nth = std::max<size_t>(1, std::min<size_t>((size_t)ctx->cfg.pack_threads, nb / 4));
+    std::vector<part> parts(nth);
+    auto parse = [&](size_t t) {
+        part &pt = parts[t];
+        for (size_t q = q0 + t; q < q1; q += nth) {
+            const uint32_t *W = ctx->ref_queue[q].in;
+            const uint32_t nt = W[2];
+            uint64_t a2 = wbase[q - q0];
+            size_t ti = (size_t)tbase[q - q0];
+            const int64_t base = nt ? (int64_t)(8 + 8 * nt) - (int64_t)W[8 + 2] : 0;
+            for (uint32_t i = 0; i < nt; ++i, ++ti) {
+                const uint32_t *H = &W[8 + 8 * i];
+                bsw_dtask &d = st.h_tasks.p[ti];
+                bsw_wireoff &wo = st.h_woff.p[ti];
+                memset(&d, 0, sizeof(d));
+                const int lq = (int)(H[0] & 0xff), lt = (int)((H[0] >> 16) & 0x7ff), rq = (int)(H[1] & 0xff), rt = (int)((H[1] >> 16) & 0x7ff);
+                const int64_t pos = base + (int64_t)H[2];
+                if (pos < 8 + 8 * (int64_t)nt || pos + (lq + rq + lt + rt + 7) / 8 > BSW_REFBATCH_IN_WORDS) {
+                    pt.rc = fail(pt.e, BSW_E_INVAL, "malformed task batch (task %u: data position)", i);
+                    return;
+                }
+                const int h0 = (int)(H[4] & 0xff);
+                if (h0 <= 0) { pt.rc = fail(pt.e, BSW_E_INVAL, "task batch: task %u has h0 <= 0", i); return; }
+                wo.nib = ((uint64_t)(q - q0) * BSW_REFBATCH_IN_WORDS + (uint64_t)pos) * 8u;
+                wo.lqlen = (uint16_t)lq; wo.rqlen = (uint16_t)rq; wo.ltlen = (uint16_t)lt; wo.rtlen = (uint16_t)rt;
+                if (lq) { d.lq_off = (uint32_t)a2; a2 += nwords(lq); d.lt_off = (uint32_t)a2; a2 += nwords(lt); }
+                if (rq) { d.rq_off = (uint32_t)a2; a2 += nwords(rq); d.rt_off = (uint32_t)a2; a2 += nwords(rt); }
+                d.lqlen = (uint16_t)lq; d.rqlen = (uint16_t)rq; d.ltlen = (uint16_t)lt; d.rtlen = (uint16_t)rt;
+                /* H5/H6 = {max_del[31:16], max_ins[15:0]}: the band limit the RTL applies (proc_element.v:925,933) */
+                auto lim = [](uint32_t h) {
+                    const int mi = (int)(int16_t)(h & 0xffff), md = (int)(int16_t)(h >> 16);
+                    const int l = mi < md ? mi : md;
+                    return (uint16_t)(l < 0 ? 0 : l);
+                };
+                d.wlim_l = lim(H[5]); d.wlim_r = lim(H[6]);
+                d.h0 = h0; d.init_score = (int)(int16_t)(H[3] & 0xffff); d.qbeg = (int)(H[3] >> 16); d.tag = H[7];
+                const int wc = bsw_wave_class_of(&bp, std::max(lq, rq));
+                ++pt.cw_all[wc];
+                const int bits = bsw_seed_lane_bits(&bp, lq, rq, h0);
+                if (!bits) ++pt.cw[wc];
+                else { ++pt.n_lane; if (lq) ++pt.cl[bsw_side_lane_class(&bp, bits, lq)]; if (rq) ++pt.cr[bsw_side_lane_class(&bp, bits, rq)]; }
+            }
+            memcpy((uint32_t *)st.h_raw.p + (q - q0) * (size_t)BSW_REFBATCH_IN_WORDS, W, BSW_REFBATCH_IN_WORDS * sizeof(uint32_t));
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nth; ++t) th.emplace_back(parse, t);
+        parse(0);
+        for (auto &x : th) x.join();
+    }
+    for (const part &pt : parts) {
+        if (pt.rc) { e = pt.e; return pt.rc; }
+        for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) { cw_all[c] += pt.cw_all[c]; cw[c] += pt.cw[c]; }
+        for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { cl[c] += pt.cl[c]; cr[c] += pt.cr[c]; }
+        n_lane += pt.n_lane;
     }
     if (ctx->cfg.kernel == BSW_KERNEL_AUTO && n_lane < LANE_AUTO_MIN) bp.lane_on = 0;
     if (!bp.lane_on) { memcpy(cw, cw_all, sizeof(cw)); memset(cl, 0, sizeof(cl)); memset(cr, 0, sizeof(cr)); n_lane = 0; }
@@ -1561,7 +1643,7 @@ static int refbatch_group(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int z
     HIPCHK(e, hipMemcpyAsync(st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
     rc = sync_stream(ctx, e, s, ctx->devs[0].events[0]);
     if (rc) return rc;
-    ti = 0;
+    size_t ti = 0;
     for (size_t q = q0; q < q1; ++q) {
         const uint32_t nt = ctx->ref_queue[q].in[2];
         memset(ctx->ref_queue[q].out, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
