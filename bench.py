@@ -226,7 +226,7 @@ def main():
                 "achieved": round(tops, 4), "peak": round(PEAK_VALU_TOPS, 2), "unit": "T lane-ops/s",
                 "frac": round(tops / PEAK_VALU_TOPS, 5),
                 "peak_opcode_weighted": pmc.get("peak_opcode_weighted_tops"),
-                "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"),
+                "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"), "valu_issue_busy": pmc.get("valu_issue_busy"),
                 "traffic": traffic, "traffic_kernels": pmc.get("traffic_kernels"),
                 "kernel_ms_avg": round(kavg_ms, 4),
                 "note": "integer max/add DP at ~0.02 B/cell: VALU issue binds, not HBM and not MFMA; see roofline_hbm",

@@ -28,6 +28,14 @@
 #define L2_MFN static inline
 #endif
 
+/* profiling build only (-DBSW_L2_STAMP): section time stamps inside the row loop (tools/profile notes in DESIGN.md) */
+#if defined(BSW_L2_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+#define L2_STAMP(k) bsw_l2_stamp(k)
+__device__ void bsw_l2_stamp(int k);
+#else
+#define L2_STAMP(k) ((void)0)
+#endif
+
 namespace bsw {
 namespace l2 {
 
@@ -268,6 +276,7 @@ struct lane2 {
         const int hi0 = S.s[0].beg == 0 ? imax(S.s[0].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
         const int hi1 = S.s[1].beg == 0 ? imax(S.s[1].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
         uint32_t h1 = pack2(hi0, hi1), f = 0;
+        L2_STAMP(2);
         uint32_t mkg[NG], nzc[NC];
         sfor<NG>([&](auto gi) { mkg[decltype(gi)::value] = 0; });
         sfor<NC>([&](auto ci) { nzc[decltype(ci)::value] = 0; });
@@ -308,6 +317,7 @@ struct lane2 {
             nzc[c] |= (b & 1) ? (nz8 << 8) : nz8;
         });
 
+        L2_STAMP(3);
         /* ---- row tail per seed (K7, K8) ---- */
         sfor<2>([&](auto xi) {
             constexpr int x = decltype(xi)::value;

@@ -16,6 +16,18 @@
 #include <stdlib.h>
 
 #include "bsw_device.h"
+#ifdef BSW_L2_STAMP
+/* profiling build only: per-wave cycle accumulators of the row-loop sections (s_memtime), reported through the
+ * result records instead of the alignment results */
+__shared__ unsigned long long l2_acc[4][8];
+__shared__ unsigned long long l2_last[4];
+__device__ void bsw_l2_stamp(int k)
+{
+    const int wv = threadIdx.x >> 6;
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) { l2_acc[wv][k] += t - l2_last[wv]; l2_last[wv] = t; }
+}
+#endif
 #include "bsw_lane2_core.h"
 
 namespace bsw {
@@ -62,6 +74,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
 {
     using L = l2::lane2<QB>;
     constexpr int QMAX = L::QMAX, NW = L::NW, NC = L::NC;
+    static_assert(QMAX <= BSW_LANE_QBINS && QMAX <= 256, "row-max key and binning assume at most 256 eh[] columns");
     __shared__ uint64_t lds_t[4][2][BSW_L2_TCHUNK][64];             /* [wave][seed][word][lane] */
     static_assert(NW == 5, "match-word staging below is laid out for 5 words (129..160 columns)");
     __shared__ uint4 lds_m4[4][2][4][64];                           /* per-base match words 0..3: [wave][seed][base][lane] */
@@ -136,10 +149,14 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     const auto wn = [&](int c) { return lds_wn[wv][c][lane]; };
     uint64_t tw[2] = {0ull, 0ull};
 
+#ifdef BSW_L2_STAMP
+    if (lane == 0) { for (int q = 0; q < 8; ++q) l2_acc[wv][q] = 0; l2_last[wv] = __builtin_amdgcn_s_memtime(); }
+#endif
     for (int i = 0;; ++i) {
         l2::rowv r;
         L::row_begin(S, i, r);
         if (__builtin_amdgcn_ballot_w64(r.act[0] || r.act[1]) == 0) break;
+        L2_STAMP(0);
         if ((i & (BSW_L2_TCHUNK * 16 - 1)) == 0) {                    /* stage the next 128 target bases of every seed */
             const int wbase = i >> 4;
             /* all 16 loads are issued before the first is waited for: the index is clamped instead of branched on
@@ -177,7 +194,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
             u.zh = wave_max2(max(r.bite[0] ? r.zhi[0] : INT_MIN, r.bite[1] ? r.zhi[1] : INT_MIN));
         }
         u.nblk = nblk;
+        L2_STAMP(1);
         L::row_body(S, k, i, r, u, tb, qp, wn);
+        L2_STAMP(4);
     }
 
     l2::sfor<2>([&](auto xi) {
@@ -187,6 +206,10 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         bsw_ext e;
         e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
         e.gscore = s.gscore; e.max_off = s.max_off; e.aw = P.w; e.cells = s.cells;
+#ifdef BSW_L2_STAMP
+        e.score = (int)(l2_acc[wv][0] >> 4); e.qle = (int)(l2_acc[wv][1] >> 4); e.tle = (int)(l2_acc[wv][2] >> 4);
+        e.gtle = (int)(l2_acc[wv][3] >> 4); e.gscore = (int)(l2_acc[wv][4] >> 4);
+#endif
         if (side == 0) out[ti[x]].left = e; else out[ti[x]].right = e;
     });
 }

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
                                                             bsw_result *__restrict__ out)
 {
     constexpr int QMAX = QB * 8;
+    static_assert(QMAX <= BSW_LANE_QBINS, "a lane class holds at most 256 eh[] columns: the row-max key keeps the column in 8 bits and the binning sorts by query length in 256 bins");
     constexpr int NW = (QMAX + 31) / 32;
     constexpr int NP = B8 ? QMAX / 2 : QMAX;
     __shared__ uint64_t lds_t[4][BSW_LANE_TCHUNK][64];              /* [wave][word][lane]          */

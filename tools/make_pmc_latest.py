@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""profiles/pmc_latest.json: the counters bench.py quotes in its `roofline` object, from a tools/profile.sh output
+directory (separate rocprofv3 --pmc passes) + tools/isa_histogram.py.  HBM bytes per MI355X_MICROARCH.md's gfx950
+correction: FETCH_SIZE (KiB) x 2 + WRITE_SIZE (KiB), summed over the DP kernels of one bsw_run step."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = sys.argv[1]
+workload, seeds, cells = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+allk = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), d, "bsw"]))
+step = {k: v for k, v in allk.items() if any(x in k for x in ("lane2_kernel", "lane_kernel", "pair_finalize", "wave_kernel"))}
+fetch = sum(v.get("FETCH_SIZE", 0) for v in step.values())
+write = sum(v.get("WRITE_SIZE", 0) for v in step.values())
+main = max(step.items(), key=lambda kv: kv[1].get("avg_ns", 0))
+isa = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_histogram.py")]))
+out = {"workload": workload, "seeds_per_gpu": seeds, "source": os.path.basename(d.rstrip("/")),
+       "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+       "traffic_kernels": {k[:40]: int((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) for k, v in step.items()},
+       "dominant_kernel": main[0][:60], "dominant_kernel_avg_ms": round(main[1]["avg_ns"] / 1e6, 4),
+       "valu_lane_insts_per_cell": round(main[1]["SQ_INSTS_VALU"] * 64 / cells, 2),
+       "valu_issue_busy": round(main[1]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (main[1]["GRBM_GUI_ACTIVE"] / 8), 3),
+       "waves_per_simd_avg": round(main[1]["SQ_WAVE_CYCLES"] * 4 / 1024 / (main[1]["GRBM_GUI_ACTIVE"] / 8), 2),
+       "peak_opcode_weighted_tops": isa["peak_opcode_weighted_tops"], "dense_path_valu_insts_per_pair_cell": isa["valu_insts_per_pair_cell"],
+       "clock_ghz": round(main[1]["GRBM_GUI_ACTIVE"] / 8 / main[1]["avg_ns"], 3)}
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+print(json.dumps(out))
