@@ -28,15 +28,15 @@
 #include "bsw_stage.h"
 
 struct bsw_ref {
-    uint8_t *d_pac = nullptr;
+    std::vector<uint8_t *> d_pac;     /* one copy per device of the context that uploaded it (index = position in devs) */
     int64_t l_pac = 0;
-    int device = 0;
 };
 
 /* BSW_KERNEL_AUTO: a lane launch costs one wave's full duration (~1.3 ms for 150 bp seeds) however few seeds it
  * holds, the wave-per-task kernel scales with the seed count; measured crossover ~22k seeds (tools/crossover.py) */
 #define LANE_AUTO_MIN 20000
 #define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
+#define RAW_FRONT 32                 /* ... and in front of the first one (reversed left queries) */
 
 /* How one batch is cut into kernel launches (all offsets index the device `order` array).
  *   [wave classes][lane seeds, any order][lane left sides by qlen][lane right sides by qlen][redo list] + counter */
@@ -528,6 +528,7 @@ struct chunk_info {
     const uint8_t *lo = nullptr, *hi = nullptr;   /* span of every sequence the chunk references */
     size_t sum_len = 0;               /* bytes referenced (= gather size) */
     bool direct = false;              /* raw bytes are DMA'd straight out of registered memory */
+    bool rev_left = false;            /* left queries sit forwards in raw, their offsets point at the last base (bsw_submit_ref) */
     batch_plan plan;
     bsw_binparams bp;
 };
@@ -553,7 +554,7 @@ static int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams 
 
 /* tasks[0..n) -> dt[0..n) (device task records), ro[0..n) (gather layout of the raw bytes), class counts -> plan */
 static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task *tasks, size_t n, bool dev_targets,
-                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci)
+                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left = false)
 {
     const int mx = mat_max(p->mat);
     int rc = fill_binparams(e, p, kern, ci.bp);
@@ -587,7 +588,7 @@ static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task 
             d.lq_off = (uint32_t)acc; acc += nwords(t.lqlen);
             d.lt_off = (uint32_t)acc; acc += nwords(t.ltlen);
             r.lq = (uint32_t)accb; accb += (uint64_t)t.lqlen;
-            span(t.lquery, t.lqlen);
+            span(rev_left ? t.lquery - (t.lqlen - 1) : t.lquery, t.lqlen);    /* rev_left: lquery points at the LAST base, read backwards */
             if (!dev_targets) { r.lt = (uint32_t)accb; accb += (uint64_t)t.ltlen; span(t.ltarget, t.ltlen); }
         }
         if (t.rqlen) {
@@ -658,6 +659,7 @@ static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task 
     /* DMA the caller's arena as it is when it is registered memory and not much larger than what it holds */
     const size_t spanb = hi ? (size_t)(hi - lo) : 0;
     ci.direct = spanb > 0 && spanb < (1ull << 32) - RAW_SLACK && spanb <= 2 * ci.sum_len + (1u << 20) && is_registered(lo, spanb);
+    ci.rev_left = rev_left && ci.direct;            /* the gather path mirrors the left queries while copying */
     if (ci.direct) {
         for (size_t i = 0; i < n; ++i) {
             const bsw_task &t = tasks[i];
@@ -670,14 +672,15 @@ static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task 
 }
 
 /* copy the sequences of tasks[0..n) into the pinned staging arena laid out by prepare_chunk */
-static void gather_raw(const bsw_task *tasks, const bsw_rawoff *ro, size_t n, bool dev_targets, uint8_t *dst, int threads)
+static void gather_raw(const bsw_task *tasks, const bsw_rawoff *ro, size_t n, bool dev_targets, uint8_t *dst, int threads, bool rev_left = false)
 {
     auto work = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const bsw_task &t = tasks[i];
             const bsw_rawoff &r = ro[i];
             if (t.lqlen) {
-                memcpy(dst + r.lq, t.lquery, (size_t)t.lqlen);
+                if (rev_left) for (int k = 0; k < t.lqlen; ++k) dst[r.lq + (uint32_t)k] = *(t.lquery - k);
+                else memcpy(dst + r.lq, t.lquery, (size_t)t.lqlen);
                 if (!dev_targets && t.ltlen) memcpy(dst + r.lt, t.ltarget, (size_t)t.ltlen);
             }
             if (t.rqlen) {
@@ -740,11 +743,11 @@ struct gate_turn {                    /* this chunk's place in its device's inpu
 };
 
 static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &ci, size_t n, bool dev_targets,
-                        const bsw_ref *ref, size_t n_desc, uint64_t *h2d_bytes, const gate_turn *turn = nullptr)
+                        const bsw_ref *ref, size_t n_desc, uint64_t *h2d_bytes, const gate_turn *turn = nullptr, size_t dev_index = 0)
 {
     const size_t rawb = ci.direct ? (size_t)(ci.hi - ci.lo) : ci.sum_len;
     hipError_t he;
-    if ((he = st.d_raw.reserve(rawb + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve(ci.words + 4)) != hipSuccess ||
+    if ((he = st.d_raw.reserve(rawb + RAW_FRONT + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve(ci.words + 4)) != hipSuccess ||
         (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_roff.reserve(n + 1)) != hipSuccess ||
         (he = st.d_order.reserve(order_capacity(n))) != hipSuccess || (he = st.d_bins.reserve(BSW_BIN_WORDS)) != hipSuccess ||
         (he = st.d_out.reserve(n + 1)) != hipSuccess || (n_desc && (he = st.d_desc.reserve(n_desc)) != hipSuccess))
@@ -758,9 +761,10 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
             if (turn->gate->last) HIPCHK(e, hipStreamWaitEvent(s, turn->gate->last, 0));
         }
         hipError_t ce = hipSuccess;
-        if (rawb) ce = hipMemcpyAsync(st.d_raw.p, ci.direct ? ci.lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s);
+        if (rawb) ce = hipMemcpyAsync(st.d_raw.p + RAW_FRONT, ci.direct ? ci.lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s);
         if (ce == hipSuccess) ce = hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s);
         if (ce == hipSuccess) ce = hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s);
+        if (ce == hipSuccess && n_desc) ce = hipMemcpyAsync(st.d_desc.p, st.h_desc.p, n_desc * sizeof(bsw_fetch_desc), hipMemcpyHostToDevice, s);
         if (turn) {
             if (ce == hipSuccess) ce = hipEventRecord(turn->ev, s);
             if (ce == hipSuccess) turn->gate->last = turn->ev;
@@ -769,10 +773,9 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
         }
         if (ce != hipSuccess) return fail(e, BSW_E_HIP, "input DMA: %s", hipGetErrorString(ce));
     }
-    HIPCHK(e, bsw::launch_pack(st.d_raw.p, st.d_tasks.p, st.d_roff.p, (uint32_t)n, dev_targets ? 1 : 0, st.d_seq.p, s));
+    HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, (uint32_t)n, dev_targets ? 1 : 0, ci.rev_left ? 1 : 0, st.d_seq.p, s));
     if (n_desc) {
-        HIPCHK(e, hipMemcpyAsync(st.d_desc.p, st.h_desc.p, n_desc * sizeof(bsw_fetch_desc), hipMemcpyHostToDevice, s));
-        HIPCHK(e, bsw::launch_fetch(ref->d_pac, ref->l_pac, st.d_desc.p, (uint32_t)n_desc, st.d_seq.p, s));
+        HIPCHK(e, bsw::launch_fetch(ref->d_pac[dev_index], ref->l_pac, st.d_desc.p, (uint32_t)n_desc, st.d_seq.p, s));
     }
     HIPCHK(e, bsw::launch_bin(ci.bp, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
     if (h2d_bytes) *h2d_bytes = rawb + n * (sizeof(bsw_dtask) + sizeof(bsw_rawoff)) + n_desc * sizeof(bsw_fetch_desc);
@@ -863,6 +866,8 @@ static int busy_check(bsw_ctx *ctx, const char *what)
     return BSW_OK;
 }
 
+static size_t fetch_descs(const bsw_dtask *dt, const bsw_ref_task *rt, size_t n, bsw_fetch_desc *desc);
+
 static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out,
                          const bsw_ref *ref /* NULL: targets come from the host */, const bsw_ref_task *rtasks)
 {
@@ -887,12 +892,7 @@ static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *task
     size_t n_desc = 0;
     if (ref) {
         if (st.h_desc.reserve(2 * n + 1) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
-        for (size_t i = 0; i < n; ++i) {
-            const bsw_dtask &d = st.h_tasks.p[i];
-            const bsw_seed &sd = rtasks[i].seed;
-            if (d.lqlen && d.ltlen) st.h_desc.p[n_desc++] = bsw_fetch_desc{sd.rbeg - 1, d.lt_off, d.ltlen, -1, 0};
-            if (d.rqlen && d.rtlen) st.h_desc.p[n_desc++] = bsw_fetch_desc{sd.rbeg + sd.len, d.rt_off, d.rtlen, 1, 0};
-        }
+        n_desc = fetch_descs(st.h_tasks.p, rtasks, n, st.h_desc.p);
     }
     b->n = n; b->P = dp; b->variant = p->variant; b->seq_words = ci.words; b->plan = ci.plan;
     hipStream_t s = ctx->stream0();
@@ -919,23 +919,28 @@ extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tas
 }
 
 /* ---- device-resident reference (F3) ------------------------------------------------ */
+extern "C" void bsw_ref_free(bsw_ctx *ctx, bsw_ref *ref);
+
 extern "C" int bsw_ref_upload(bsw_ctx *ctx, const uint8_t *pac, int64_t l_pac, bsw_ref **out)
 {
     if (!ctx) return BSW_E_INVAL;
     errs &e = ctx->err;
     if (!pac || !out || l_pac <= 0) return fail(e, BSW_E_INVAL, "bsw_ref_upload: bad argument");
     *out = nullptr;
-    HIPCHK(e, hipSetDevice(ctx->device0()));
     bsw_ref *r = new bsw_ref();
     r->l_pac = l_pac;
-    r->device = ctx->device0();
+    r->d_pac.assign(ctx->devs.size(), nullptr);
     const size_t bytes = (size_t)((l_pac + 3) >> 2);
-    hipError_t he;
-    if ((he = hipMalloc((void **)&r->d_pac, bytes + 8)) != hipSuccess) { delete r; return fail(e, BSW_E_NOMEM, "hipMalloc: %s", hipGetErrorString(he)); }
-    if ((he = hipMemcpy(r->d_pac, pac, bytes, hipMemcpyHostToDevice)) != hipSuccess) {
-        (void)hipFree(r->d_pac); delete r;
-        return fail(e, BSW_E_HIP, "pac upload: %s", hipGetErrorString(he));
+    for (size_t d = 0; d < ctx->devs.size(); ++d) {               /* every GPU of the context keeps its own copy */
+        hipError_t he = hipSetDevice(ctx->devs[d].device);
+        if (he == hipSuccess) he = hipMalloc((void **)&r->d_pac[d], bytes + 8);
+        if (he == hipSuccess) he = hipMemcpy(r->d_pac[d], pac, bytes, hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            bsw_ref_free(ctx, r);
+            return fail(e, BSW_E_HIP, "pac upload to device %d: %s", ctx->devs[d].device, hipGetErrorString(he));
+        }
     }
+    (void)hipSetDevice(ctx->device0());
     *out = r;
     return BSW_OK;
 }
@@ -943,9 +948,56 @@ extern "C" int bsw_ref_upload(bsw_ctx *ctx, const uint8_t *pac, int64_t l_pac, b
 extern "C" void bsw_ref_free(bsw_ctx *ctx, bsw_ref *ref)
 {
     if (!ref) return;
+    for (size_t d = 0; d < ref->d_pac.size(); ++d) {
+        if (!ref->d_pac[d]) continue;
+        if (ctx && d < ctx->devs.size()) (void)hipSetDevice(ctx->devs[d].device);
+        (void)hipFree(ref->d_pac[d]);
+    }
     if (ctx) (void)hipSetDevice(ctx->device0());
-    if (ref->d_pac) (void)hipFree(ref->d_pac);
     delete ref;
+}
+
+/* mem_chain2aln's task extraction minus the target bases, which stay on the device: one seed of a
+ * read -> one task.  rev_left: the left query is NOT copied reversed; lquery points at its last base (query[qbeg-1]). */
+static int ref_to_task(errs &e, const bsw_params *p, int64_t l_pac, const bsw_ref_task &r, size_t i, bool rev_left,
+                       uint8_t *scratch, size_t &so, bsw_task &t)
+{
+    const bsw_seed &sd = r.seed;
+    const int64_t two = l_pac << 1;
+    if (!r.query || r.l_query < 1 || sd.qbeg < 0 || sd.len < 1 || sd.qbeg + sd.len > r.l_query)
+        return fail(e, BSW_E_INVAL, "ref task %zu: bad seed / read", i);
+    if (r.rmax0 < 0 || r.rmax1 > two || r.rmax0 > sd.rbeg || r.rmax1 < sd.rbeg + sd.len || (r.rmax0 < l_pac && l_pac < r.rmax1))
+        return fail(e, BSW_E_INVAL, "ref task %zu: window outside the reference or bridging the strands", i);
+    const int64_t lt = sd.rbeg - r.rmax0, rtl = r.rmax1 - (sd.rbeg + sd.len);
+    if (lt > BSW_MAX_TLEN || rtl > BSW_MAX_TLEN) return fail(e, BSW_E_LIMIT, "ref task %zu: window beyond BSW_MAX_TLEN", i);
+    memset(&t, 0, sizeof(t));
+    if (sd.qbeg > 0) {
+        if (rev_left) t.lquery = r.query + sd.qbeg - 1;
+        else {
+            for (int k = 0; k < sd.qbeg; ++k) scratch[so + (size_t)k] = r.query[sd.qbeg - 1 - k];
+            t.lquery = scratch + so;
+            so += (size_t)sd.qbeg;
+        }
+        t.lqlen = sd.qbeg; t.ltlen = (int32_t)lt;
+    }
+    if (sd.qbeg + sd.len != r.l_query) {
+        t.rquery = r.query + sd.qbeg + sd.len; t.rqlen = r.l_query - (sd.qbeg + sd.len); t.rtlen = (int32_t)rtl;
+    }
+    t.h0 = sd.len * p->mat[0]; t.init_score = r.init_score; t.qbeg = sd.qbeg; t.tag = r.tag;
+    return BSW_OK;
+}
+
+/* one 24-byte fetch descriptor per target the device reads out of the resident pac */
+static size_t fetch_descs(const bsw_dtask *dt, const bsw_ref_task *rt, size_t n, bsw_fetch_desc *desc)
+{
+    size_t nd = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_dtask &d = dt[i];
+        const bsw_seed &sd = rt[i].seed;
+        if (d.lqlen && d.ltlen) desc[nd++] = bsw_fetch_desc{sd.rbeg - 1, d.lt_off, d.ltlen, -1, 0};
+        if (d.rqlen && d.rtlen) desc[nd++] = bsw_fetch_desc{sd.rbeg + sd.len, d.rt_off, d.rtlen, 1, 0};
+    }
+    return nd;
 }
 
 extern "C" int bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rt, size_t n, bsw_dev_batch **out)
@@ -955,34 +1007,14 @@ extern "C" int bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *
     if (!p || !ref || !out || (!rt && n)) return fail(e, BSW_E_INVAL, "bsw_upload_ref: NULL argument");
     int rc = busy_check(ctx, "bsw_upload_ref");
     if (rc) return rc;
-    /* mem_chain2aln's task extraction minus the target bases, which stay on the device */
     std::vector<bsw_task> tasks(n ? n : 1);
     size_t scratch_len = 0;
     for (size_t i = 0; i < n; ++i) scratch_len += (size_t)(rt[i].seed.qbeg > 0 ? rt[i].seed.qbeg : 0);
     std::vector<uint8_t> scratch(scratch_len + 1);
     size_t so = 0;
-    const int64_t two = ref->l_pac << 1;
     for (size_t i = 0; i < n; ++i) {
-        const bsw_ref_task &r = rt[i];
-        const bsw_seed &sd = r.seed;
-        if (!r.query || r.l_query < 1 || sd.qbeg < 0 || sd.len < 1 || sd.qbeg + sd.len > r.l_query)
-            return fail(e, BSW_E_INVAL, "ref task %zu: bad seed / read", i);
-        if (r.rmax0 < 0 || r.rmax1 > two || r.rmax0 > sd.rbeg || r.rmax1 < sd.rbeg + sd.len ||
-            (r.rmax0 < ref->l_pac && ref->l_pac < r.rmax1))
-            return fail(e, BSW_E_INVAL, "ref task %zu: window outside the reference or bridging the strands", i);
-        const int64_t lt = sd.rbeg - r.rmax0, rtl = r.rmax1 - (sd.rbeg + sd.len);
-        if (lt > BSW_MAX_TLEN || rtl > BSW_MAX_TLEN) return fail(e, BSW_E_LIMIT, "ref task %zu: window beyond BSW_MAX_TLEN", i);
-        bsw_task &t = tasks[i];
-        memset(&t, 0, sizeof(t));
-        if (sd.qbeg > 0) {
-            for (int k = 0; k < sd.qbeg; ++k) scratch[so + (size_t)k] = r.query[sd.qbeg - 1 - k];
-            t.lquery = scratch.data() + so; t.lqlen = sd.qbeg; t.ltlen = (int32_t)lt;
-            so += (size_t)sd.qbeg;
-        }
-        if (sd.qbeg + sd.len != r.l_query) {
-            t.rquery = r.query + sd.qbeg + sd.len; t.rqlen = r.l_query - (sd.qbeg + sd.len); t.rtlen = (int32_t)rtl;
-        }
-        t.h0 = sd.len * p->mat[0]; t.init_score = r.init_score; t.qbeg = sd.qbeg; t.tag = r.tag;
+        rc = ref_to_task(e, p, ref->l_pac, rt[i], i, false, scratch.data(), so, tasks[i]);
+        if (rc) return rc;
     }
     return upload_common(ctx, p, tasks.data(), n, out, ref, rt);
 }
@@ -1169,9 +1201,11 @@ static std::vector<std::vector<chunk_span>> plan_chunks(size_t n, size_t chunk, 
  * result DMA.  The host pass of chunk k+S runs while chunk k is still on the GPU: it only needs the pinned host
  * staging, which is free again as soon as chunk k's input DMAs are done. */
 static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp, const bsw_task *tasks,
+                       const bsw_ref *ref, const bsw_ref_task *rtasks,   /* non-NULL: seeds against the device-resident reference */
                        bsw_result *out, const std::vector<chunk_span> &chunks, size_t d, size_t s, int gather_threads,
                        std::atomic<int> &abort_flag, h2d_gate &gate, errs &e)
 {
+    std::vector<bsw_task> rt_tasks;                 /* ref mode: this chunk's seeds as tasks (left queries by reference) */
     dev_state &dev = ctx->devs[d];
     const size_t S = dev.slots.size();
     stage_t &st = dev.slots[s];
@@ -1195,25 +1229,35 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         return BSW_OK;
     };
     for (size_t k = s; k < chunks.size() && !abort_flag; k += S) {            /* k-th chunk of this device */
-        const bsw_task *ct = tasks + chunks[k].base;
+        const bsw_task *ct = tasks ? tasks + chunks[k].base : nullptr;
         const size_t n = chunks[k].cnt;
         int rc = BSW_OK;
         if (pend.active) rc = wait_event(ctx, e, dev.h2d_done[s]);           /* pinned host staging is free again */
         if (rc) return bail(rc);
-        if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess)
+        if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess ||
+            (rtasks && (he = st.h_desc.reserve(2 * n + 1)) != hipSuccess))
             return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
+        if (rtasks) {                               /* mem_chain2aln's task extraction; the targets stay on the device */
+            rt_tasks.resize(n);
+            size_t so = 0;
+            for (size_t i = 0; i < n && !rc; ++i)
+                rc = ref_to_task(e, &p, ref->l_pac, rtasks[chunks[k].base + i], chunks[k].base + i, true, nullptr, so, rt_tasks[i]);
+            if (rc) return bail(rc);
+            ct = rt_tasks.data();
+        }
         chunk_info ci;
-        rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci);
+        rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, rtasks != nullptr, st.h_tasks.p, st.h_roff.p, ci, rtasks != nullptr);
         if (rc) return bail(rc);
         if (!ci.direct) {
             if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
-            gather_raw(ct, st.h_roff.p, n, false, st.h_raw.p, gather_threads);
+            gather_raw(ct, st.h_roff.p, n, rtasks != nullptr, st.h_raw.p, gather_threads, rtasks != nullptr);
         }
+        const size_t n_desc = rtasks ? fetch_descs(st.h_tasks.p, rtasks + chunks[k].base, n, st.h_desc.p) : 0;
         rc = finish();
         if (rc) return bail(rc);
         gate_turn turn;
         turn.gate = &gate; turn.seq = k; turn.ev = dev.h2d_done[s]; turn.abort_flag = &abort_flag;
-        rc = stage_device(e, st, stream, ci, n, false, nullptr, 0, nullptr, &turn);
+        rc = stage_device(e, st, stream, ci, n, rtasks != nullptr, ref, n_desc, nullptr, &turn, d);
         if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr);
         if (rc) return bail(rc);
         bsw_result *co = out + chunks[k].base;
@@ -1227,7 +1271,8 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
     return rc ? bail(rc) : BSW_OK;
 }
 
-static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, size_t n, bsw_result *out)
+static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, const bsw_ref *ref, const bsw_ref_task *rtasks,
+                           size_t n, bsw_result *out)
 {
     bsw_dparams dp;
     int rc = check_params(ctx->err, &p, &dp);
@@ -1245,8 +1290,8 @@ static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, si
     std::vector<h2d_gate> gates(G);
     std::vector<std::thread> th;
     for (size_t k = 1; k < ws.size(); ++k)
-        th.emplace_back([&, k]() { ws[k].rc = slot_worker(ctx, p, dp, tasks, out, chunks[ws[k].d], ws[k].d, ws[k].s, gather_threads, abort_flag, gates[ws[k].d], ws[k].e); });
-    ws[0].rc = slot_worker(ctx, p, dp, tasks, out, chunks[ws[0].d], ws[0].d, ws[0].s, gather_threads, abort_flag, gates[ws[0].d], ws[0].e);
+        th.emplace_back([&, k]() { ws[k].rc = slot_worker(ctx, p, dp, tasks, ref, rtasks, out, chunks[ws[k].d], ws[k].d, ws[k].s, gather_threads, abort_flag, gates[ws[k].d], ws[k].e); });
+    ws[0].rc = slot_worker(ctx, p, dp, tasks, ref, rtasks, out, chunks[ws[0].d], ws[0].d, ws[0].s, gather_threads, abort_flag, gates[ws[0].d], ws[0].e);
     for (auto &t : th) t.join();
     for (int pass = 0; pass < 2; ++pass)             /* report the failure itself, not the slots it made give up */
         for (auto &w : ws)
@@ -1266,7 +1311,26 @@ extern "C" int bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tas
     ctx->worker_active = true;
     ctx->worker_rc = 0;
     bsw_params pc = *p;
-    ctx->worker = std::thread([ctx, pc, tasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, tasks, n, out); });
+    ctx->worker = std::thread([ctx, pc, tasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, tasks, nullptr, nullptr, n, out); });
+    return BSW_OK;
+}
+
+/* bsw_submit for seeds against a DEVICE-RESIDENT reference (F3): only the reads cross PCIe; the targets are fetched
+ * from the 2-bit pac on the GPU, the left flank of every read is mirrored by the pack kernel.  Wait with bsw_wait. */
+extern "C" int bsw_submit_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rtasks, size_t n, bsw_result *out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!p || !ref || (!rtasks && n) || (!out && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_submit_ref: NULL argument");
+    if (ref->d_pac.size() != ctx->devs.size()) return fail(ctx->err, BSW_E_INVAL, "bsw_submit_ref: the reference was uploaded through another context");
+    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "bsw_submit_ref: context is dead (an earlier wait for the GPU timed out)");
+    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "previous bsw_submit not waited for");
+    bsw_dparams dp;
+    int rc = check_params(ctx->err, p, &dp);
+    if (rc) return rc;
+    ctx->worker_active = true;
+    ctx->worker_rc = 0;
+    bsw_params pc = *p;
+    ctx->worker = std::thread([ctx, pc, ref, rtasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, nullptr, ref, rtasks, n, out); });
     return BSW_OK;
 }
 
@@ -1756,7 +1820,7 @@ static int global_chunk(bsw_ctx *ctx, errs &e, const bsw_dparams &dp, const bsw_
     HIPCHK(e, hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(ctx->g_tasks.p, gt.data(), n * sizeof(bsw_gdtask), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(ctx->g_order.p, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(e, bsw::launch_pack(st.d_raw.p, st.d_tasks.p, st.d_roff.p, (uint32_t)n, 0, st.d_seq.p, s));
+    HIPCHK(e, bsw::launch_pack(st.d_raw.p, st.d_tasks.p, st.d_roff.p, (uint32_t)n, 0, 0, st.d_seq.p, s));
     for (int c = 0; c < ncls; ++c) {
         const uint32_t k = cnt[(size_t)c + 1] - cnt[(size_t)c];
         if (!k) continue;

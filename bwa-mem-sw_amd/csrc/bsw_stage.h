@@ -30,7 +30,7 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
 hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
                            bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, hipStream_t s);
 hipError_t launch_fetch(const uint8_t *pac, int64_t l_pac, const bsw_fetch_desc *desc, uint32_t nd, uint64_t *seq, hipStream_t s);
-hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, int skip_targets,
+hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, int skip_targets, int rev_left,
                        uint64_t *seq, hipStream_t s);
 hipError_t launch_wire_pack(const uint32_t *wire, const bsw_dtask *tasks, const bsw_wireoff *woffs, uint32_t n, uint64_t *seq, hipStream_t s);
 int global_class_count();

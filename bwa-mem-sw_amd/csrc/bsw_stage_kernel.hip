@@ -48,10 +48,12 @@ __device__ __forceinline__ uint64_t clamp_codes(uint64_t x)
     return x & ~((n >> 1) | (n >> 2));
 }
 
-/* 16 lanes per sequence, 4 sequences per seed (leftQ, leftT, rightQ, rightT); lane k packs words k, k+16, ... */
+/* 16 lanes per sequence, 4 sequences per seed (leftQ, leftT, rightQ, rightT); lane k packs words k, k+16, ...
+ * rev_left: the left query is read BACKWARDS from its offset (base k = raw[off - k]): a read DMA'd as it is holds
+ * query[0..qbeg) forwards, mem_chain2aln extends it reversed (the host's reversal loop, done here for free). */
 __global__ __launch_bounds__(256) void bsw_pack_kernel(const uint8_t *__restrict__ raw, const bsw_dtask *__restrict__ tasks,
                                                        const bsw_rawoff *__restrict__ roff, const uint32_t n,
-                                                       const int skip_targets, uint64_t *__restrict__ seq)
+                                                       const int skip_targets, const int rev_left, uint64_t *__restrict__ seq)
 {
     const uint32_t g = blockIdx.x * 16u + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
@@ -70,14 +72,21 @@ __global__ __launch_bounds__(256) void bsw_pack_kernel(const uint8_t *__restrict
     default: len = T.rqlen ? T.rtlen : 0; woff = T.rt_off; boff = R.rt; break;
     }
     const int nw = (len + 15) >> 4;
+    const bool rev = rev_left && which == 0;
     for (int k = l16; k < nw; k += 16) {
-        const uintptr_t a = (uintptr_t)(raw + boff) + 16u * (uint32_t)k;
+        /* forwards: bytes [off + 16k, +16); backwards: bytes (off - 16k - 16, off - 16k], then mirrored */
+        const uintptr_t a = rev ? (uintptr_t)(raw + boff) - 16u * (uint32_t)k - 15u : (uintptr_t)(raw + boff) + 16u * (uint32_t)k;
         const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
         const uint32_t sh = (uint32_t)(a & 3u);
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];   /* the raw buffer has >= 32 bytes of slack */
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];   /* the raw buffer has >= 32 bytes of slack on both sides */
         const uint32_t x0 = __builtin_amdgcn_alignbyte(d1, d0, sh), x1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
         const uint32_t x2 = __builtin_amdgcn_alignbyte(d3, d2, sh), x3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
         uint64_t lo = (uint64_t)x0 | ((uint64_t)x1 << 32), hi = (uint64_t)x2 | ((uint64_t)x3 << 32);
+        if (rev) {
+            const uint64_t t = __builtin_bswap64(hi);
+            hi = __builtin_bswap64(lo);
+            lo = t;
+        }
         const int valid = len - 16 * k;                     /* bases of this word */
         if (valid < 16) {
             if (valid <= 8) { hi = 0; lo = valid == 8 ? lo : lo & ((1ull << (8 * valid)) - 1ull); }
@@ -227,12 +236,12 @@ __global__ __launch_bounds__(256) void bsw_wire_pack_kernel(const uint32_t *__re
 }
 
 /* ---- launchers ---- */
-hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, int skip_targets,
+hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, int skip_targets, int rev_left,
                        uint64_t *seq, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     const uint32_t groups = n * 4u;
-    hipLaunchKernelGGL(bsw_pack_kernel, dim3((groups + 15u) / 16u), dim3(256), 0, s, raw, tasks, roff, n, skip_targets, seq);
+    hipLaunchKernelGGL(bsw_pack_kernel, dim3((groups + 15u) / 16u), dim3(256), 0, s, raw, tasks, roff, n, skip_targets, rev_left, seq);
     return hipGetLastError();
 }
 

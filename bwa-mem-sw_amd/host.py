@@ -114,6 +114,7 @@ def lib():
             "bsw_ref_free": (None, [vp, vp]),
             "bsw_upload_ref": (C.c_int, [vp, vp, vp, vp, sz, C.POINTER(vp)]),
             "bsw_extend_ref": (C.c_int, [vp, vp, vp, vp, sz, vp]),
+            "bsw_submit_ref": (C.c_int, [vp, vp, vp, vp, sz, vp]),
             "bsw_plan_batch": (C.c_int64, [vp, vp, sz, C.c_int, C.c_int, vp, vp]),
             "bsw_pack_bases": (C.c_int, [vp, C.c_int, vp]),
             "bsw_cal_max_gap": (C.c_int, [vp, C.c_int]),
@@ -141,7 +142,7 @@ EXPORTS = ["ksw_global2", "ksw_global", "bsw_global_batch", "ksw_extend2", "ksw_
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
            "bsw_refbatch_encode_results", "bsw_refbatch_decode_results", "bsw_refbatch_run",
-           "bsw_ref_upload", "bsw_ref_free", "bsw_upload_ref", "bsw_extend_ref",
+           "bsw_ref_upload", "bsw_ref_free", "bsw_upload_ref", "bsw_extend_ref", "bsw_submit_ref",
            "bsw_plan_batch", "bsw_pack_bases", "bsw_cal_max_gap", "bsw_chain_window", "bsw_seed_scratch_bytes", "bsw_seed_to_task",
            "bsw_result_to_alnreg", "bsw_pac_get_seq", "bsw_synth_generate", "bsw_synth_arena_bound"]
 
@@ -362,6 +363,14 @@ class BswContext:
     def extend_ref(self, params, ref, rtasks):
         out = np.zeros(len(rtasks), dtype=RESULT)
         self._chk(lib().bsw_extend_ref(self.handle, params.ctypes.data, ref, rtasks.ctypes.data, len(rtasks), out.ctypes.data), "bsw_extend_ref")
+        return out
+
+    def submit_ref(self, params, ref, rtasks, out=None):
+        """Streaming form of extend_ref (finish with wait()): only the reads cross PCIe."""
+        if out is None:
+            out = np.zeros(len(rtasks), dtype=RESULT)
+        self._keep = (params, rtasks, out)
+        self._chk(lib().bsw_submit_ref(self.handle, params.ctypes.data, ref, rtasks.ctypes.data, len(rtasks), out.ctypes.data), "bsw_submit_ref")
         return out
 
     def refbatch_run(self, in_words, variant=VARIANT_H, zdrop=0):

@@ -304,6 +304,10 @@ int      bsw_ref_upload(bsw_ctx *ctx, const uint8_t *pac, int64_t l_pac, bsw_ref
 void     bsw_ref_free(bsw_ctx *ctx, bsw_ref *ref);
 /* device-resident batch whose targets come from `ref`; then bsw_run / bsw_download as usual */
 int      bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *tasks, size_t n, bsw_dev_batch **out);
+/* streaming form (like bsw_submit; finish with bsw_wait): chunk k -> device k mod n_devices, every device holding
+ * its own copy of the reference (bsw_ref_upload puts one on each GPU of the context).  Only the reads cross PCIe
+ * (~1/2.5 of the bytes of bsw_submit at 150 bp); reads in bsw_host_alloc / registered memory are DMA'd as they are. */
+int      bsw_submit_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *tasks, size_t n, bsw_result *out);
 /* convenience: upload_ref + run + download + free (synchronous) */
 int      bsw_extend_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *tasks, size_t n, bsw_result *out);
 

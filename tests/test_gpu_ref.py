@@ -66,3 +66,49 @@ def test_device_fetch_equals_host_extraction(host, oracle, kernel):
         ctx.ref_free(ref)
     aln = host.results_to_alnregs(seeds, got)
     assert ((aln["re"] - aln["rb"]) > 0).all() and (aln["qe"] > aln["qb"]).all()
+
+
+@pytest.mark.parametrize("mode", ["pageable", "registered", "two devices"])
+def test_streaming_submit_against_the_resident_reference(host, oracle, mode):
+    """bsw_submit_ref: the streaming form of F3.  Reads in pageable memory (left flanks mirrored by the gather),
+    in registered memory (DMA'd as they are, mirrored by the pack kernel), and over two slot sets of one context."""
+    rng = np.random.default_rng(7)
+    lp = 80000
+    genome = rng.integers(0, 4, lp).astype(np.uint8)
+    pac = host.pack_pac(genome)
+    n = 24000
+    reads, seeds = _reads_and_seeds(host, rng, genome, n)
+    p = host.default_params()
+    tasks, keep = host.seeds_to_tasks(p, pac, lp, reads, seeds)
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    total = sum(len(r) for r in reads)
+    arena = host.HostArena(total + 64) if mode != "pageable" else None
+    buf = arena.u8 if arena else np.zeros(total + 64, np.uint8)
+    rt = np.zeros(n, dtype=host.REF_TASK)
+    rmax = np.zeros(2, dtype=np.int64)
+    off = 0
+    for i in range(n):
+        q = reads[i]
+        buf[off:off + len(q)] = q
+        host.lib().bsw_chain_window(p.ctypes.data, seeds[i:i + 1].ctypes.data, 1, len(q), lp, rmax.ctypes.data)
+        rt[i]["query"], rt[i]["l_query"], rt[i]["init_score"] = buf.ctypes.data + off, len(q), -1
+        rt[i]["seed"] = seeds[i]
+        rt[i]["rmax0"], rt[i]["rmax1"], rt[i]["tag"] = rmax[0], rmax[1], i
+        off += len(q)
+    kw = dict(devices=[0, 0], streams=2) if mode == "two devices" else dict(device=0, streams=3)
+    try:
+        with host.BswContext(kernel=host.KERNEL_LANE, chunk_tasks=5000, **kw) as ctx:
+            ref = ctx.ref_upload(pac, lp)
+            got = ctx.submit_ref(p, ref, rt)
+            ctx.wait()
+            assert_same(got, want, tasks)
+            assert_same(ctx.extend_ref(p, ref, rt[:777]), want[:777])
+            bad = rt.copy()
+            bad["rmax1"][n // 2] = 2 * lp + 10                                  # one bad window in the middle: an error, not a fallback
+            with pytest.raises(host.BswError):
+                ctx.submit_ref(p, ref, bad)
+                ctx.wait()
+            ctx.ref_free(ref)
+    finally:
+        if arena:
+            arena.free()
