@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the 250 bp and mixed-bin side measurements (N=1 only, outside the timed region)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bsw_submit (PCIe-inclusive) measurement")
     ap.add_argument("--e2e-reps", type=int, default=5, help="bsw_submit passes timed (median reported)")
+    ap.add_argument("--ref-mbp", type=int, default=64, help="synthetic genome size (Mbp) of the device-resident-reference e2e leg; 0 = skip")
     ap.add_argument("--check", type=int, default=100_000, help="seeds checked bit-exact against the oracle after timing")
     ap.add_argument("--spec", action="append", default=[], help="override a generator field, e.g. --spec n_rate=0 (experiments)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -186,6 +187,30 @@ def main():
         e2e_same = bool(got.tobytes() == res.tobytes())
         sctx.close()
 
+    # ---- same shape of work, seeds against a DEVICE-RESIDENT reference: only the reads cross PCIe ----
+    ref_leg = None
+    if not args.no_e2e and args.ref_mbp > 0 and args.scaling == "weak":
+        lp = args.ref_mbp * 1_000_000
+        hreads = host.HostArena(spec["read_len"] * n_local + 4096)
+        pac, rtasks, _ = host.synth_ref_tasks(n_local, lp, params, arena=hreads.u8, seed=3000 + rank, **spec)
+        rctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=4, pack_threads=4, chunk_tasks=chunk)
+        gref = rctx.ref_upload(pac, lp)
+        rctx.submit_ref(params, gref, rtasks, out=out_buf); rctx.wait()         # warm up
+        runs = []
+        for _ in range(args.e2e_reps):
+            barrier()
+            t1 = time.perf_counter()
+            rctx.submit_ref(params, gref, rtasks, out=out_buf); rctx.wait()
+            barrier()
+            runs.append(time.perf_counter() - t1)
+        rcells = cells_of(out_buf)
+        nchk = min(50_000, n_local)
+        same = bool(rctx.extend_ref(params, gref, rtasks[:nchk]).tobytes() == out_buf[:nchk].tobytes())
+        ref_leg = (float(np.median(runs)), rcells, same, int(rtasks["l_query"].astype(np.int64).sum()), lp)
+        rctx.ref_free(gref)
+        rctx.close()
+        hreads.free()
+
     if dist is not None:
         v = torch.tensor([dt, float(cells), float(ext_calls), float(len(tasks)), float(nominal), e2e_dt or 0.0],
                          dtype=torch.float64, device=red_dev)
@@ -246,6 +271,17 @@ def main():
                 "path": "bsw_submit: registered host arena DMA'd as is, pack + bin on the GPU, results DMA'd into registered host memory",
                 "bytes_per_seed_h2d": round((harena_used(tasks) + len(tasks) * 60) / max(len(tasks), 1), 1),
                 "bit_exact_vs_resident_run": e2e_same,
+            }
+        if ref_leg is not None and world == 1:
+            rdt, rcells, rsame, rbytes, rlp = ref_leg
+            out["e2e_device_reference"] = {
+                "seeds_per_s": round(n_local / rdt, 1), "gcups": round(rcells / rdt / 1e9, 1),
+                "ratio_to_hbm_resident": round((n_local / rdt) / (tasks_all * args.steps / dt_all), 3),
+                "host_threads": "4 slot threads", "reps_median_of": args.e2e_reps,
+                "path": "bsw_submit_ref: %d Mbp synthetic genome resident in HBM (2 bits/base), reads DMA'd from registered host memory, "
+                        "targets fetched and left flanks mirrored on the GPU" % (rlp // 1_000_000),
+                "bytes_per_seed_h2d": round((rbytes + n_local * (44 + 16 + 16)) / max(n_local, 1), 1),
+                "bit_exact_vs_resident_fetch_path": rsame,
             }
         if world == 1 and not args.no_cpu_baseline:
             orc = graft.load_oracle()

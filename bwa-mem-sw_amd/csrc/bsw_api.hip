@@ -124,7 +124,7 @@ struct stage_t {
     hbuf<bsw_dtask> h_tasks;
     hbuf<bsw_rawoff> h_roff;
     hbuf<bsw_result> h_out;
-    hbuf<bsw_fetch_desc> h_desc;
+    hbuf<bsw_refx> h_desc;          /* ref mode: target coordinates per seed */
     hbuf<bsw_wireoff> h_woff;
     dbuf<uint8_t> d_raw;
     dbuf<uint64_t> d_seq;
@@ -132,7 +132,7 @@ struct stage_t {
     dbuf<bsw_rawoff> d_roff;
     dbuf<uint32_t> d_order, d_bins;
     dbuf<bsw_result> d_out;
-    dbuf<bsw_fetch_desc> d_desc;
+    dbuf<bsw_refx> d_desc;
     dbuf<bsw_wireoff> d_woff;
     void set_pinned(bool on) { h_raw.pinned = h_tasks.pinned = h_roff.pinned = h_out.pinned = h_desc.pinned = h_woff.pinned = on; }
     void release_host() { h_raw.release(); h_tasks.release(); h_roff.release(); h_out.release(); h_desc.release(); h_woff.release(); }
@@ -529,6 +529,7 @@ struct chunk_info {
     size_t sum_len = 0;               /* bytes referenced (= gather size) */
     bool direct = false;              /* raw bytes are DMA'd straight out of registered memory */
     bool rev_left = false;            /* left queries sit forwards in raw, their offsets point at the last base (bsw_submit_ref) */
+    uint32_t raw_bias = 0;            /* direct: rawoff holds the low 32 bits of the host pointers, raw byte = off - bias */
     batch_plan plan;
     bsw_binparams bp;
 };
@@ -553,8 +554,13 @@ static int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams 
 }
 
 /* tasks[0..n) -> dt[0..n) (device task records), ro[0..n) (gather layout of the raw bytes), class counts -> plan */
-static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task *tasks, size_t n, bool dev_targets,
-                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left = false)
+/* One pass over the seeds of a chunk: validate, lay the 4-bit arena out, count the kernel classes.  `src(i, tmp, rc)`
+ * hands out seed i as a bsw_task (a pointer into the caller's array, or `tmp` filled on the fly — bsw_submit_ref never
+ * materialises its tasks); NULL = error rc.  rawoff gets the low 32 bits of every host pointer: when the chunk goes
+ * out by direct DMA the pack kernel subtracts raw_bias, otherwise gather_offsets() replaces them. */
+template <class Src>
+static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, size_t n, bool dev_targets,
+                           bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left)
 {
     const int mx = mat_max(p->mat);
     int rc = fill_binparams(e, p, kern, ci.bp);
@@ -567,8 +573,11 @@ static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task 
     auto span = [&](const uint8_t *s, int len) {
         if (len > 0) { if (s < lo) lo = s; if (s + len > hi) hi = s + len; }
     };
+    bsw_task tmp;
     for (size_t i = 0; i < n; ++i) {
-        const bsw_task &t = tasks[i];
+        const bsw_task *tp = src(i, tmp, rc);
+        if (!tp) return rc;
+        const bsw_task &t = *tp;
         if (t.lqlen < 0 || t.rqlen < 0 || t.ltlen < 0 || t.rtlen < 0)
             return fail(e, BSW_E_INVAL, "task %zu: negative length", i);
         if (t.lqlen > BSW_MAX_QLEN || t.rqlen > BSW_MAX_QLEN || t.ltlen > BSW_MAX_TLEN || t.rtlen > BSW_MAX_TLEN)
@@ -587,16 +596,16 @@ static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task 
         if (t.lqlen) {
             d.lq_off = (uint32_t)acc; acc += nwords(t.lqlen);
             d.lt_off = (uint32_t)acc; acc += nwords(t.ltlen);
-            r.lq = (uint32_t)accb; accb += (uint64_t)t.lqlen;
+            r.lq = (uint32_t)(uintptr_t)t.lquery; accb += (uint64_t)t.lqlen;
             span(rev_left ? t.lquery - (t.lqlen - 1) : t.lquery, t.lqlen);    /* rev_left: lquery points at the LAST base, read backwards */
-            if (!dev_targets) { r.lt = (uint32_t)accb; accb += (uint64_t)t.ltlen; span(t.ltarget, t.ltlen); }
+            if (!dev_targets) { r.lt = (uint32_t)(uintptr_t)t.ltarget; accb += (uint64_t)t.ltlen; span(t.ltarget, t.ltlen); }
         }
         if (t.rqlen) {
             d.rq_off = (uint32_t)acc; acc += nwords(t.rqlen);
             d.rt_off = (uint32_t)acc; acc += nwords(t.rtlen);
-            r.rq = (uint32_t)accb; accb += (uint64_t)t.rqlen;
+            r.rq = (uint32_t)(uintptr_t)t.rquery; accb += (uint64_t)t.rqlen;
             span(t.rquery, t.rqlen);
-            if (!dev_targets) { r.rt = (uint32_t)accb; accb += (uint64_t)t.rtlen; span(t.rtarget, t.rtlen); }
+            if (!dev_targets) { r.rt = (uint32_t)(uintptr_t)t.rtarget; accb += (uint64_t)t.rtlen; span(t.rtarget, t.rtlen); }
         }
         d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
         d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
@@ -660,15 +669,35 @@ static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task 
     const size_t spanb = hi ? (size_t)(hi - lo) : 0;
     ci.direct = spanb > 0 && spanb < (1ull << 32) - RAW_SLACK && spanb <= 2 * ci.sum_len + (1u << 20) && is_registered(lo, spanb);
     ci.rev_left = rev_left && ci.direct;            /* the gather path mirrors the left queries while copying */
-    if (ci.direct) {
-        for (size_t i = 0; i < n; ++i) {
-            const bsw_task &t = tasks[i];
-            bsw_rawoff &r = ro[i];
-            if (t.lqlen) { r.lq = (uint32_t)(t.lquery - lo); if (!dev_targets && t.ltlen) r.lt = (uint32_t)(t.ltarget - lo); }
-            if (t.rqlen) { r.rq = (uint32_t)(t.rquery - lo); if (!dev_targets && t.rtlen) r.rt = (uint32_t)(t.rtarget - lo); }
+    ci.raw_bias = ci.direct ? (uint32_t)(uintptr_t)lo : 0u;
+    return BSW_OK;
+}
+
+/* the gather path: rawoff = where gather_raw puts each sequence in the pinned staging arena (back to back) */
+static void gather_offsets(const bsw_task *tasks, size_t n, bool dev_targets, bsw_rawoff *ro)
+{
+    uint64_t accb = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_task &t = tasks[i];
+        bsw_rawoff &r = ro[i];
+        memset(&r, 0, sizeof(r));
+        if (t.lqlen) {
+            r.lq = (uint32_t)accb; accb += (uint64_t)t.lqlen;
+            if (!dev_targets) { r.lt = (uint32_t)accb; accb += (uint64_t)t.ltlen; }
+        }
+        if (t.rqlen) {
+            r.rq = (uint32_t)accb; accb += (uint64_t)t.rqlen;
+            if (!dev_targets) { r.rt = (uint32_t)accb; accb += (uint64_t)t.rtlen; }
         }
     }
-    return BSW_OK;
+}
+
+static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task *tasks, size_t n, bool dev_targets,
+                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left = false)
+{
+    int rc = prepare_chunk_t(e, p, kern, [tasks](size_t i, bsw_task &, int &) { return tasks + i; }, n, dev_targets, dt, ro, ci, rev_left);
+    if (!rc && !ci.direct) gather_offsets(tasks, n, dev_targets, ro);
+    return rc;
 }
 
 /* copy the sequences of tasks[0..n) into the pinned staging arena laid out by prepare_chunk */
@@ -743,8 +772,9 @@ struct gate_turn {                    /* this chunk's place in its device's inpu
 };
 
 static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &ci, size_t n, bool dev_targets,
-                        const bsw_ref *ref, size_t n_desc, uint64_t *h2d_bytes, const gate_turn *turn = nullptr, size_t dev_index = 0)
+                        const bsw_ref *ref, uint64_t *h2d_bytes, const gate_turn *turn = nullptr, size_t dev_index = 0)
 {
+    const size_t n_desc = ref ? n : 0;              /* st.h_desc: one bsw_refx per seed */
     const size_t rawb = ci.direct ? (size_t)(ci.hi - ci.lo) : ci.sum_len;
     hipError_t he;
     if ((he = st.d_raw.reserve(rawb + RAW_FRONT + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve(ci.words + 4)) != hipSuccess ||
@@ -764,7 +794,7 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
         if (rawb) ce = hipMemcpyAsync(st.d_raw.p + RAW_FRONT, ci.direct ? ci.lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s);
         if (ce == hipSuccess) ce = hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s);
         if (ce == hipSuccess) ce = hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s);
-        if (ce == hipSuccess && n_desc) ce = hipMemcpyAsync(st.d_desc.p, st.h_desc.p, n_desc * sizeof(bsw_fetch_desc), hipMemcpyHostToDevice, s);
+        if (ce == hipSuccess && n_desc) ce = hipMemcpyAsync(st.d_desc.p, st.h_desc.p, n_desc * sizeof(bsw_refx), hipMemcpyHostToDevice, s);
         if (turn) {
             if (ce == hipSuccess) ce = hipEventRecord(turn->ev, s);
             if (ce == hipSuccess) turn->gate->last = turn->ev;
@@ -773,12 +803,11 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
         }
         if (ce != hipSuccess) return fail(e, BSW_E_HIP, "input DMA: %s", hipGetErrorString(ce));
     }
-    HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, (uint32_t)n, dev_targets ? 1 : 0, ci.rev_left ? 1 : 0, st.d_seq.p, s));
-    if (n_desc) {
-        HIPCHK(e, bsw::launch_fetch(ref->d_pac[dev_index], ref->l_pac, st.d_desc.p, (uint32_t)n_desc, st.d_seq.p, s));
-    }
+    (void)dev_targets;
+    HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, ci.raw_bias, (uint32_t)n, ci.rev_left ? 1 : 0,
+                               ref ? ref->d_pac[dev_index] : nullptr, ref ? ref->l_pac : 0, ref ? st.d_desc.p : nullptr, st.d_seq.p, s));
     HIPCHK(e, bsw::launch_bin(ci.bp, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
-    if (h2d_bytes) *h2d_bytes = rawb + n * (sizeof(bsw_dtask) + sizeof(bsw_rawoff)) + n_desc * sizeof(bsw_fetch_desc);
+    if (h2d_bytes) *h2d_bytes = rawb + n * (sizeof(bsw_dtask) + sizeof(bsw_rawoff)) + n_desc * sizeof(bsw_refx);
     return BSW_OK;
 }
 
@@ -866,7 +895,7 @@ static int busy_check(bsw_ctx *ctx, const char *what)
     return BSW_OK;
 }
 
-static size_t fetch_descs(const bsw_dtask *dt, const bsw_ref_task *rt, size_t n, bsw_fetch_desc *desc);
+static void fill_refx(const bsw_ref_task *rt, size_t n, bsw_refx *x);
 
 static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out,
                          const bsw_ref *ref /* NULL: targets come from the host */, const bsw_ref_task *rtasks)
@@ -889,14 +918,13 @@ static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *task
         if (st.h_raw.reserve(ci.sum_len + RAW_SLACK) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
         gather_raw(tasks, st.h_roff.p, n, ref != nullptr, st.h_raw.p, ctx->cfg.pack_threads);
     }
-    size_t n_desc = 0;
     if (ref) {
-        if (st.h_desc.reserve(2 * n + 1) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
-        n_desc = fetch_descs(st.h_tasks.p, rtasks, n, st.h_desc.p);
+        if (st.h_desc.reserve(n + 1) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
+        fill_refx(rtasks, n, st.h_desc.p);
     }
     b->n = n; b->P = dp; b->variant = p->variant; b->seq_words = ci.words; b->plan = ci.plan;
     hipStream_t s = ctx->stream0();
-    rc = stage_device(e, st, s, ci, n, ref != nullptr, ref, n_desc, &b->h2d_bytes);
+    rc = stage_device(e, st, s, ci, n, ref != nullptr, ref, &b->h2d_bytes);
     if (!rc && n) {
         hipError_t he = hipMemsetAsync(st.d_out.p, 0xff, n * sizeof(bsw_result), s);
         if (he != hipSuccess) rc = fail(e, BSW_E_HIP, "memset: %s", hipGetErrorString(he));
@@ -987,17 +1015,10 @@ static int ref_to_task(errs &e, const bsw_params *p, int64_t l_pac, const bsw_re
     return BSW_OK;
 }
 
-/* one 24-byte fetch descriptor per target the device reads out of the resident pac */
-static size_t fetch_descs(const bsw_dtask *dt, const bsw_ref_task *rt, size_t n, bsw_fetch_desc *desc)
+/* where the device finds the two targets of every seed in the resident pac */
+static void fill_refx(const bsw_ref_task *rt, size_t n, bsw_refx *x)
 {
-    size_t nd = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const bsw_dtask &d = dt[i];
-        const bsw_seed &sd = rt[i].seed;
-        if (d.lqlen && d.ltlen) desc[nd++] = bsw_fetch_desc{sd.rbeg - 1, d.lt_off, d.ltlen, -1, 0};
-        if (d.rqlen && d.rtlen) desc[nd++] = bsw_fetch_desc{sd.rbeg + sd.len, d.rt_off, d.rtlen, 1, 0};
-    }
-    return nd;
+    for (size_t i = 0; i < n; ++i) x[i] = bsw_refx{rt[i].seed.rbeg - 1, rt[i].seed.rbeg + rt[i].seed.len};
 }
 
 extern "C" int bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rt, size_t n, bsw_dev_batch **out)
@@ -1149,7 +1170,7 @@ static int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent
         gather_raw(tasks, st.h_roff.p, n, false, st.h_raw.p, gather_threads);
     }
     const double t_c = dbg ? tnow() : 0;
-    rc = stage_device(e, st, s, ci, n, false, nullptr, 0, nullptr, turn);
+    rc = stage_device(e, st, s, ci, n, false, nullptr, nullptr, turn);
     if (rc) return rc;
     rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, s, nullptr);
     if (rc) return rc;
@@ -1206,6 +1227,9 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
                        std::atomic<int> &abort_flag, h2d_gate &gate, errs &e)
 {
     std::vector<bsw_task> rt_tasks;                 /* ref mode: this chunk's seeds as tasks (left queries by reference) */
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_host = 0, t_staging = 0, t_finish = 0, t_stage = 0;
     dev_state &dev = ctx->devs[d];
     const size_t S = dev.slots.size();
     stage_t &st = dev.slots[s];
@@ -1232,32 +1256,47 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         const bsw_task *ct = tasks ? tasks + chunks[k].base : nullptr;
         const size_t n = chunks[k].cnt;
         int rc = BSW_OK;
+        const double t0 = dbg ? tnow() : 0;
         if (pend.active) rc = wait_event(ctx, e, dev.h2d_done[s]);           /* pinned host staging is free again */
         if (rc) return bail(rc);
+        const double t1 = dbg ? tnow() : 0;
         if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess ||
-            (rtasks && (he = st.h_desc.reserve(2 * n + 1)) != hipSuccess))
+            (rtasks && (he = st.h_desc.reserve(n + 1)) != hipSuccess))
             return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
-        if (rtasks) {                               /* mem_chain2aln's task extraction; the targets stay on the device */
-            rt_tasks.resize(n);
-            size_t so = 0;
-            for (size_t i = 0; i < n && !rc; ++i)
-                rc = ref_to_task(e, &p, ref->l_pac, rtasks[chunks[k].base + i], chunks[k].base + i, true, nullptr, so, rt_tasks[i]);
-            if (rc) return bail(rc);
-            ct = rt_tasks.data();
-        }
         chunk_info ci;
-        rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, rtasks != nullptr, st.h_tasks.p, st.h_roff.p, ci, rtasks != nullptr);
-        if (rc) return bail(rc);
+        if (rtasks) {                               /* mem_chain2aln's task extraction fused into the pass; the targets stay on the device */
+            const bsw_ref_task *crt = rtasks + chunks[k].base;
+            const size_t base = chunks[k].base;
+            bsw_refx *rx = st.h_desc.p;
+            size_t so = 0;
+            rc = prepare_chunk_t(e, &p, ctx->cfg.kernel, [&](size_t i, bsw_task &tmp, int &erc) -> const bsw_task * {
+                erc = ref_to_task(e, &p, ref->l_pac, crt[i], base + i, true, nullptr, so, tmp);
+                rx[i] = bsw_refx{crt[i].seed.rbeg - 1, crt[i].seed.rbeg + crt[i].seed.len};
+                return erc ? nullptr : &tmp;
+            }, n, true, st.h_tasks.p, st.h_roff.p, ci, true);
+            if (rc) return bail(rc);
+            if (!ci.direct) {                       /* reads in pageable memory: materialise the tasks for the gather */
+                rt_tasks.resize(n);
+                for (size_t i = 0; i < n && !rc; ++i) rc = ref_to_task(e, &p, ref->l_pac, crt[i], base + i, true, nullptr, so, rt_tasks[i]);
+                if (rc) return bail(rc);
+                ct = rt_tasks.data();
+                gather_offsets(ct, n, true, st.h_roff.p);
+            }
+        } else {
+            rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci);
+            if (rc) return bail(rc);
+        }
         if (!ci.direct) {
             if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
             gather_raw(ct, st.h_roff.p, n, rtasks != nullptr, st.h_raw.p, gather_threads, rtasks != nullptr);
         }
-        const size_t n_desc = rtasks ? fetch_descs(st.h_tasks.p, rtasks + chunks[k].base, n, st.h_desc.p) : 0;
+        const double t2 = dbg ? tnow() : 0;
         rc = finish();
         if (rc) return bail(rc);
+        const double t3 = dbg ? tnow() : 0;
         gate_turn turn;
         turn.gate = &gate; turn.seq = k; turn.ev = dev.h2d_done[s]; turn.abort_flag = &abort_flag;
-        rc = stage_device(e, st, stream, ci, n, rtasks != nullptr, ref, n_desc, nullptr, &turn, d);
+        rc = stage_device(e, st, stream, ci, n, rtasks != nullptr, ref, nullptr, &turn, d);
         if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr);
         if (rc) return bail(rc);
         bsw_result *co = out + chunks[k].base;
@@ -1266,8 +1305,12 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         he = hipMemcpyAsync(pend.direct ? co : st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, stream);
         if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(he)));
         pend.active = true; pend.n = n; pend.out = co;
+        if (dbg) { const double t4 = tnow(); t_staging += t1 - t0; t_host += t2 - t1; t_finish += t3 - t2; t_stage += t4 - t3; }
     }
+    const double t5 = dbg ? tnow() : 0;
     const int rc = finish();
+    if (dbg) fprintf(stderr, "[bsw] slot %zu.%zu: wait staging %.2f ms, host pass %.2f, wait results %.2f, DMA turn + enqueue %.2f, drain %.2f\n",
+                     d, s, t_staging, t_host, t_finish, t_stage, tnow() - t5);
     return rc ? bail(rc) : BSW_OK;
 }
 
@@ -1820,7 +1863,7 @@ static int global_chunk(bsw_ctx *ctx, errs &e, const bsw_dparams &dp, const bsw_
     HIPCHK(e, hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(ctx->g_tasks.p, gt.data(), n * sizeof(bsw_gdtask), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(ctx->g_order.p, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(e, bsw::launch_pack(st.d_raw.p, st.d_tasks.p, st.d_roff.p, (uint32_t)n, 0, 0, st.d_seq.p, s));
+    HIPCHK(e, bsw::launch_pack(st.d_raw.p, st.d_tasks.p, st.d_roff.p, 0u, (uint32_t)n, 0, nullptr, 0, nullptr, st.d_seq.p, s));
     for (int c = 0; c < ncls; ++c) {
         const uint32_t k = cnt[(size_t)c + 1] - cnt[(size_t)c];
         if (!k) continue;

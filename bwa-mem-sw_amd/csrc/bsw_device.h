@@ -47,14 +47,12 @@ typedef struct bsw_dparams {
     int32_t w, pen_clip5, pen_clip3, zdrop, max_band_try;
 } bsw_dparams;
 
-/* one target to fetch from the device-resident 2-bit reference (bsw_fetch_kernel.hip) */
-typedef struct bsw_fetch_desc {
-    int64_t  x0;          /* coordinate of base 0 in bwa's [0, 2*l_pac) space */
-    uint32_t dst_word;    /* word offset into seq */
-    uint32_t tlen;
-    int32_t  dir;         /* +1 right-extension target, -1 left-extension target (reversed) */
-    int32_t  pad;
-} bsw_fetch_desc;
+/* where a seed's two targets start in the device-resident 2-bit reference, in bwa's [0, 2*l_pac) coordinates
+ * (bsw_pack_kernel fetches them: ltlen bases downwards from xl, rtlen bases upwards from xr) */
+typedef struct bsw_refx {
+    int64_t xl;           /* seed.rbeg - 1            */
+    int64_t xr;           /* seed.rbeg + seed.len     */
+} bsw_refx;
 
 /* one banded global alignment (bsw_global_kernel.hip) */
 typedef struct bsw_gdtask {

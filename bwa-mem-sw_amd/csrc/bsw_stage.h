@@ -29,9 +29,10 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
                        const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
 hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
                            bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, hipStream_t s);
-hipError_t launch_fetch(const uint8_t *pac, int64_t l_pac, const bsw_fetch_desc *desc, uint32_t nd, uint64_t *seq, hipStream_t s);
-hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, int skip_targets, int rev_left,
-                       uint64_t *seq, hipStream_t s);
+/* raw byte of a sequence = raw[roff - bias] (uint32 arithmetic).  pac != NULL: the targets are not in raw, they are
+ * fetched from the resident reference at refx[] */
+hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t bias, uint32_t n, int rev_left,
+                       const uint8_t *pac, int64_t l_pac, const bsw_refx *refx, uint64_t *seq, hipStream_t s);
 hipError_t launch_wire_pack(const uint32_t *wire, const bsw_dtask *tasks, const bsw_wireoff *woffs, uint32_t n, uint64_t *seq, hipStream_t s);
 int global_class_count();
 int global_class_cols(int cls);

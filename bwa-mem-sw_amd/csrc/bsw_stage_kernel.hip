@@ -48,20 +48,83 @@ __device__ __forceinline__ uint64_t clamp_codes(uint64_t x)
     return x & ~((n >> 1) | (n >> 2));
 }
 
+/* ---- targets out of the device-resident 2-bit reference (replaces the host's bns_get_seq +
+ * reversal so that only the read crosses PCIe).  Coordinates are bwa's: x in [0, l_pac) is the forward strand,
+ * x in [l_pac, 2*l_pac) the reverse complement: base(x) = 3 - pac[2*l_pac - 1 - x].  pac packs 4 bases per byte,
+ * first base in the top two bits. ---- */
+
+/* the 16 bases at pac positions pos .. pos+15 as 32 big-endian bits (base pos in bits [31:30]).  pos may run off
+ * either end of the pac by up to 15 bases: the byte index is clamped, the caller masks those bases away */
+__device__ __forceinline__ uint32_t pac16(const uint8_t *__restrict__ pac, const int64_t last_byte, const int64_t pos)
+{
+    const int64_t b = pos >> 2;
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int64_t i = b + k;
+        i = i < 0 ? 0 : (i > last_byte ? last_byte : i);
+        v = (v << 8) | pac[i];
+    }
+    return (uint32_t)(v >> (8 - 2 * (int)(pos & 3)));
+}
+
+/* 16 two-bit bases (base k in bits [2k, 2k+1]) -> 16 nibbles */
+__device__ __forceinline__ uint64_t spread16(uint32_t u)
+{
+    uint64_t x = u;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    return x;
+}
+
+/* word w of a target of tlen bases whose base i sits at coordinate x0 + dir*i (one strand: the host rejects windows
+ * that bridge l_pac) */
+__device__ __forceinline__ uint64_t fetch_word(const uint8_t *__restrict__ pac, const int64_t l_pac, const int64_t x0, const int dir,
+                                               const int tlen, const int w)
+{
+    const bool fwd = x0 < l_pac;
+    const int64_t p0 = fwd ? x0 : (l_pac << 1) - 1 - x0;      /* pac position of base 0 */
+    const bool up = fwd == (dir > 0);                         /* pac positions ascend with i */
+    const int64_t last_byte = ((l_pac + 3) >> 2) - 1;
+    uint32_t u;
+    if (up) {
+        u = __builtin_bitreverse32(pac16(pac, last_byte, p0 + 16 * (int64_t)w));
+        u = ((u >> 1) & 0x55555555u) | ((u & 0x55555555u) << 1);
+    } else
+        u = pac16(pac, last_byte, p0 - 16 * (int64_t)w - 15); /* base 0 of the word is the LAST of the 16: already little-endian */
+    uint64_t v = spread16(u);
+    if (!fwd) v ^= 0x3333333333333333ull;
+    const int valid = tlen - 16 * w;
+    if (valid < 16) v &= (1ull << (4 * valid)) - 1ull;
+    return v;
+}
+
 /* 16 lanes per sequence, 4 sequences per seed (leftQ, leftT, rightQ, rightT); lane k packs words k, k+16, ...
  * rev_left: the left query is read BACKWARDS from its offset (base k = raw[off - k]): a read DMA'd as it is holds
- * query[0..qbeg) forwards, mem_chain2aln extends it reversed (the host's reversal loop, done here for free). */
+ * query[0..qbeg) forwards, mem_chain2aln extends it reversed (the host's reversal loop, done here for free).
+ * pac != NULL: the two target groups fetch from the resident reference instead of packing raw bytes. */
 __global__ __launch_bounds__(256) void bsw_pack_kernel(const uint8_t *__restrict__ raw, const bsw_dtask *__restrict__ tasks,
-                                                       const bsw_rawoff *__restrict__ roff, const uint32_t n,
-                                                       const int skip_targets, const int rev_left, uint64_t *__restrict__ seq)
+                                                       const bsw_rawoff *__restrict__ roff, const uint32_t bias, const uint32_t n,
+                                                       const int rev_left, const uint8_t *__restrict__ pac, const int64_t l_pac,
+                                                       const bsw_refx *__restrict__ refx, uint64_t *__restrict__ seq)
 {
     const uint32_t g = blockIdx.x * 16u + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
     const uint32_t ti = g >> 2;
     const int which = (int)(g & 3u);
     if (ti >= n) return;
-    if (skip_targets && (which & 1)) return;
     const bsw_dtask T = tasks[ti];
+    if (pac && (which & 1)) {
+        const bsw_refx X = refx[ti];
+        const bool left = which == 1;
+        const int tlen = left ? (T.lqlen ? T.ltlen : 0) : (T.rqlen ? T.rtlen : 0);
+        const uint32_t woff = left ? T.lt_off : T.rt_off;
+        const int nw = (tlen + 15) >> 4;
+        for (int k = l16; k < nw; k += 16) seq[woff + (uint32_t)k] = fetch_word(pac, l_pac, left ? X.xl : X.xr, left ? -1 : 1, tlen, k);
+        return;
+    }
     const bsw_rawoff R = roff[ti];
     int len;
     uint32_t woff, boff;
@@ -71,6 +134,7 @@ __global__ __launch_bounds__(256) void bsw_pack_kernel(const uint8_t *__restrict
     case 2: len = T.rqlen; woff = T.rq_off; boff = R.rq; break;
     default: len = T.rqlen ? T.rtlen : 0; woff = T.rt_off; boff = R.rt; break;
     }
+    boff -= bias;
     const int nw = (len + 15) >> 4;
     const bool rev = rev_left && which == 0;
     for (int k = l16; k < nw; k += 16) {
@@ -236,12 +300,11 @@ __global__ __launch_bounds__(256) void bsw_wire_pack_kernel(const uint32_t *__re
 }
 
 /* ---- launchers ---- */
-hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, int skip_targets, int rev_left,
-                       uint64_t *seq, hipStream_t s)
+hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t bias, uint32_t n, int rev_left,
+                       const uint8_t *pac, int64_t l_pac, const bsw_refx *refx, uint64_t *seq, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    const uint32_t groups = n * 4u;
-    hipLaunchKernelGGL(bsw_pack_kernel, dim3((groups + 15u) / 16u), dim3(256), 0, s, raw, tasks, roff, n, skip_targets, rev_left, seq);
+    hipLaunchKernelGGL(bsw_pack_kernel, dim3(n / 4u + (n % 4u ? 1u : 0u)), dim3(256), 0, s, raw, tasks, roff, bias, n, rev_left, pac, l_pac, refx, seq);
     return hipGetLastError();
 }
 

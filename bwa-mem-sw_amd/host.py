@@ -125,6 +125,7 @@ def lib():
             "bsw_pac_get_seq": (C.c_int64, [C.c_int64, vp, C.c_int64, C.c_int64, vp]),
             "bsw_synth_generate": (C.c_int64, [vp, sz, vp, vp, sz]),
             "bsw_synth_arena_bound": (sz, [vp, sz]),
+            "bsw_synth_ref_generate": (C.c_int64, [vp, vp, C.c_int64, vp, sz, vp, vp, sz]),
             "bsw_set_default_variant": (None, [C.c_int]),
             "ksw_extend2": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp] + [C.c_int] * 8 + [vp] * 5),
             "ksw_extend": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp] + [C.c_int] * 6 + [vp] * 5),
@@ -144,7 +145,7 @@ EXPORTS = ["ksw_global2", "ksw_global", "bsw_global_batch", "ksw_extend2", "ksw_
            "bsw_refbatch_encode_results", "bsw_refbatch_decode_results", "bsw_refbatch_run",
            "bsw_ref_upload", "bsw_ref_free", "bsw_upload_ref", "bsw_extend_ref", "bsw_submit_ref",
            "bsw_plan_batch", "bsw_pack_bases", "bsw_cal_max_gap", "bsw_chain_window", "bsw_seed_scratch_bytes", "bsw_seed_to_task",
-           "bsw_result_to_alnreg", "bsw_pac_get_seq", "bsw_synth_generate", "bsw_synth_arena_bound"]
+           "bsw_result_to_alnreg", "bsw_pac_get_seq", "bsw_synth_generate", "bsw_synth_arena_bound", "bsw_synth_ref_generate"]
 
 
 def default_params(**over):
@@ -194,6 +195,27 @@ def synth_tasks(n, arena=None, **spec):
     if used < 0:
         raise BswError(int(used), "bsw_synth_generate")
     return tasks, arena
+
+
+def synth_ref_tasks(n, l_pac, params, arena=None, **spec):
+    """Synthetic genome + reads against it (bsw_synth_ref_generate).  Returns (pac, rtasks, arena)."""
+    s = np.zeros(1, dtype=SYNTH)
+    d = dict(seed=1, read_len=150, seed_len_min=19, seed_len_max=19, seed_at_start=1, sub_rate=0.01,
+             indel_rate=0.001, n_rate=0.0, junk_frac=0.0, a=1, w=100, o=6, e=1)
+    d.update(spec)
+    for k, v in d.items():
+        s[k] = v
+    need = int(d["read_len"]) * n
+    if arena is None:
+        arena = np.zeros(need + 64, dtype=np.uint8)
+    elif arena.size < need:
+        raise ValueError("arena too small: need %d bytes" % need)
+    pac = np.zeros((l_pac + 3) // 4, dtype=np.uint8)
+    rt = np.zeros(n, dtype=REF_TASK)
+    used = lib().bsw_synth_ref_generate(s.ctypes.data, params.ctypes.data, l_pac, pac.ctypes.data, n, rt.ctypes.data, arena.ctypes.data, arena.size)
+    if used < 0:
+        raise BswError(int(used), "bsw_synth_ref_generate")
+    return pac, rt, arena
 
 
 def make_tasks(seeds):

@@ -331,6 +331,11 @@ typedef struct bsw_synth_spec {
 /* Fills tasks[0..n) and the arena; returns bytes of arena used or <0.          */
 int64_t  bsw_synth_generate(const bsw_synth_spec *s, size_t n, bsw_task *tasks, uint8_t *arena, size_t arena_len);
 size_t   bsw_synth_arena_bound(const bsw_synth_spec *s, size_t n);
+/* Synthetic GENOME + reads for the device-resident-reference path: fills pac ((l_pac+3)/4 bytes, bwa's .pac layout)
+ * with i.i.d. bases and tasks[0..n) with forward-strand reads of read_len bases (arena: n*read_len bytes), each with
+ * one exact seed and flanks derived from the genome at the spec's error rates; rmax = bsw_chain_window of the seed. */
+int64_t  bsw_synth_ref_generate(const bsw_synth_spec *s, const bsw_params *p, int64_t l_pac, uint8_t *pac, size_t n,
+                                bsw_ref_task *tasks, uint8_t *arena, size_t arena_len);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,24 @@ int main(void)
         bsw_result_to_alnreg(&s, &r, &a);
         if (a.qb != 0 || a.qe != 150 || a.rb != s.rbeg - s.qbeg || a.score != 150) return 10;
     }
+    /* synthetic genome + reads: every read extends inside its own chain window */
+    {
+        enum { LG = 20000, NR = 300 };
+        uint8_t *gp = malloc(LG / 4 + 1), *ar = malloc((size_t)NR * 150), *win = malloc(1024), sc2[4096];
+        bsw_ref_task *rt = malloc(NR * sizeof(*rt));
+        p.variant = 0;
+        if (bsw_synth_ref_generate(&sp, &p, LG, gp, NR, rt, ar, (size_t)NR * 150) < 0) return 11;
+        if (bsw_synth_ref_generate(&sp, &p, LG, gp, NR, rt, ar, 10) >= 0) return 12;                        /* arena too small */
+        for (int i = 0; i < NR; ++i) {
+            int64_t rl = bsw_pac_get_seq(LG, gp, rt[i].rmax0, rt[i].rmax1, win);
+            if (rl != rt[i].rmax1 - rt[i].rmax0) return 13;
+            bsw_task t; bsw_result r;
+            if (bsw_seed_to_task(&p, &rt[i].seed, rt[i].l_query, rt[i].query, rt[i].rmax0, rt[i].rmax1, win, sc2, sizeof(sc2), (uint32_t)i, &t)) return 14;
+            bsw_pair_ref(&p, &t, &r);
+            if (r.score < rt[i].seed.len * p.mat[0] - p.pen_clip5 - p.pen_clip3) return 15;
+        }
+        free(gp); free(ar); free(win); free(rt);
+    }
     free(arena); free(tasks); free(res); free(W); free(R); free(t2); free(sb); free(g); free(pac); free(rseq);
     puts("asan_host ok");
     return 0;

@@ -20,8 +20,7 @@ int lane_class_bits(int c) { return kLb[c]; }
 hipError_t launch_wave(int, int, const bsw_dparams &, const uint64_t *, const bsw_dtask *, const uint32_t *, uint32_t, const uint32_t *, bsw_result *, hipStream_t) { return hipSuccess; }
 hipError_t launch_lane(int, int, const bsw_dparams &, int, const uint64_t *, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, hipStream_t) { return hipSuccess; }
 hipError_t launch_finalize(const bsw_dparams &, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, uint32_t *, uint32_t *, hipStream_t) { return hipSuccess; }
-hipError_t launch_fetch(const uint8_t *, int64_t, const bsw_fetch_desc *, uint32_t, uint64_t *, hipStream_t) { return hipSuccess; }
-hipError_t launch_pack(const uint8_t *, const bsw_dtask *, const bsw_rawoff *, uint32_t, int, int, uint64_t *, hipStream_t) { return hipSuccess; }
+hipError_t launch_pack(const uint8_t *, const bsw_dtask *, const bsw_rawoff *, uint32_t, uint32_t, int, const uint8_t *, int64_t, const bsw_refx *, uint64_t *, hipStream_t) { return hipSuccess; }
 hipError_t launch_wire_pack(const uint32_t *, const bsw_dtask *, const bsw_wireoff *, uint32_t, uint64_t *, hipStream_t) { return hipSuccess; }
 hipError_t launch_bin(const bsw_binparams &, const bsw_dtask *, uint32_t, uint32_t *, uint32_t *, hipStream_t) { return hipSuccess; }
 int global_class_count() { return 5; }

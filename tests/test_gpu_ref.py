@@ -112,3 +112,25 @@ def test_streaming_submit_against_the_resident_reference(host, oracle, mode):
     finally:
         if arena:
             arena.free()
+
+
+def test_synthetic_genome_reads_through_the_streaming_path(host, oracle):
+    """bsw_synth_ref_generate (the bench's e2e_device_reference workload) with seeds anywhere in the read:
+    bsw_submit_ref on its tasks == the oracle on the host-extracted tasks (bns_get_seq + reversal on the CPU)."""
+    p = host.default_params()
+    lp, n, L = 300_000, 30_000, 150
+    arena = host.HostArena(n * L + 64)
+    try:
+        pac, rt, _ = host.synth_ref_tasks(n, lp, p, arena=arena.u8, seed=11, read_len=L, seed_len_min=19, seed_len_max=60,
+                                          seed_at_start=0, sub_rate=0.02, indel_rate=0.004, n_rate=0.002, junk_frac=0.05)
+        reads = [arena.u8[i * L:(i + 1) * L] for i in range(n)]
+        tasks, keep = host.seeds_to_tasks(p, pac, lp, reads, rt["seed"].copy())
+        want = oracle.pair_batch(p, tasks, nthreads=8)
+        with host.BswContext(device=0, chunk_tasks=8192, streams=3) as ctx:
+            ref = ctx.ref_upload(pac, lp)
+            got = ctx.submit_ref(p, ref, rt)
+            ctx.wait()
+            assert_same(got, want, tasks)
+            ctx.ref_free(ref)
+    finally:
+        arena.free()

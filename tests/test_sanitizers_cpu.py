@@ -29,6 +29,7 @@ def test_batch_manager_host_logic_under_asan_ubsan(tmp_path):
     for name, src, cc in (("api", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_api.hip"), "hip"),
                           ("plan", os.path.join(ROOT, "tests", "asan_plan.cpp"), "hip"),
                           ("synth", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_synth.c"), "c"),
+                          ("glue", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_glue.c"), "c"),
                           ("refbatch", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_refbatch.c"), "c")):
         obj = str(tmp_path / (name + ".o"))
         if cc == "hip":

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 kernel + memory-copy trace: per-op totals and the busy/idle timeline of the last pass."""
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 d = sys.argv[1]
+GAP = int(float(os.environ.get("TRACE_GAP_MS", "1")) * 1e6)      # idle time that separates two passes
+DUMP = len(sys.argv) > 2 and sys.argv[2] == "--dump"
 ev = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -15,7 +17,7 @@ if not ev:
 # split into passes by gaps > 1 ms
 passes, cur = [], [ev[0]]
 for e in ev[1:]:
-    if e[0] - max(x[1] for x in cur) > 1_000_000:
+    if e[0] - max(x[1] for x in cur) > GAP:
         passes.append(cur); cur = [e]
     else:
         cur.append(e)
@@ -23,6 +25,9 @@ passes.append(cur)
 print("passes:", len(passes), [round((max(x[1] for x in p) - p[0][0]) / 1e6, 2) for p in passes])
 last = passes[-1]
 t0 = last[0][0]; t1 = max(x[1] for x in last)
+if DUMP:
+    for s_, e_, nme in last:
+        print("  +%8.3f ms  %7.3f ms  %s" % ((s_ - t0) / 1e6, (e_ - s_) / 1e6, nme))
 tot = collections.defaultdict(lambda: [0, 0])
 for s, e, nme in last:
     tot[nme][0] += e - s; tot[nme][1] += 1
