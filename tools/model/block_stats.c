@@ -8,7 +8,7 @@
 
 typedef struct { int h, e; } eh_t;
 #define MAXROWS 1024
-typedef struct { int nrows; short beg[MAXROWS], end[MAXROWS]; int qlen; } trace_t;
+typedef struct { int nrows; short beg[MAXROWS], end[MAXROWS]; int qlen; long key; } trace_t;
 
 /* variant H ksw_extend2, recording the clamped [beg,end) of every row it iterates */
 static void extend_trace(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat,
@@ -54,7 +54,11 @@ static void extend_trace(int qlen, const uint8_t *query, int tlen, const uint8_t
     free(eh);
 }
 
-static int cmp_q(const void *a, const void *b) { return ((const trace_t *)b)->qlen - ((const trace_t *)a)->qlen; }
+static int cmp_q(const void *a, const void *b) {
+    const trace_t *x = a, *y = b;
+    if (x->qlen != y->qlen) return y->qlen - x->qlen;
+    return x->key < y->key ? -1 : x->key > y->key;
+}
 
 int main(int argc, char **argv)
 {
@@ -74,7 +78,18 @@ int main(int argc, char **argv)
     int nt = 0;
     for (int k = 0; k < n; ++k) {           /* right sides only (h0 = seed score: left score unknown here, close enough) */
         if (!tasks[k].rqlen) continue;
-        extend_trace(tasks[k].rqlen, tasks[k].rquery, tasks[k].rtlen, tasks[k].rtarget, p.mat, 6, 1, 6, 1, p.w, 5, 100, tasks[k].h0, &tr[nt++]);
+        extend_trace(tasks[k].rqlen, tasks[k].rquery, tasks[k].rtlen, tasks[k].rtarget, p.mat, 6, 1, 6, 1, p.w, 5, 100, tasks[k].h0, &tr[nt]);
+        {
+            trace_t *t = &tr[nt]; long key = 0;
+            int kmode = argc > 3 ? atoi(argv[3]) : 0;
+            if (kmode == 1) { for (int i = 0; i < t->nrows; ++i) key += t->end[i] - t->beg[i]; }          /* total cells (oracle knowledge) */
+            if (kmode == 2) { int L = tasks[k].rqlen < tasks[k].rtlen ? tasks[k].rqlen : tasks[k].rtlen; for (int i = 0; i < L; ++i) key += tasks[k].rquery[i] != tasks[k].rtarget[i]; }   /* diagonal mismatches */
+            if (kmode == 3) { key = t->nrows; }
+            if (kmode == 4) { int L = tasks[k].rqlen < tasks[k].rtlen ? tasks[k].rqlen : tasks[k].rtlen; int i; for (i = 0; i < L && tasks[k].rquery[i] == tasks[k].rtarget[i]; ++i) {} key = i; }  /* first mismatch */
+            if (kmode == 5) { int L = tasks[k].rqlen < tasks[k].rtlen ? tasks[k].rqlen : tasks[k].rtlen; int sc = tasks[k].h0, mn = 1000; for (int i = 0; i < L; ++i) { sc += tasks[k].rquery[i] == tasks[k].rtarget[i] ? 1 : -4; if (sc < mn) mn = sc; } key = mn; }
+            t->key = key;
+        }
+        ++nt;
     }
     qsort(tr, nt, sizeof(trace_t), cmp_q);
     for (S = 64; S <= 128; S += 64) {
