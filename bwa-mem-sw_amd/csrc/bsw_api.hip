@@ -1608,11 +1608,18 @@ extern "C" int bsw_refbatch_submit(bsw_ctx *ctx, const uint32_t *in_words, uint3
 }
 
 /* one run of queued batches [q0, q1) that share G0/G1 */
-static int refbatch_group(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int zdrop)
+/* queued batches [q0, q1) (same scoring header) -> one device batch on stream s, nothing waited for: headers parsed on
+ * host threads, batches DMA'd as they are, nibble streams unpacked on the GPU.  *n_out = tasks enqueued (0: nothing
+ * in flight, the result batches are already written). */
+/* wire batches per device batch and device batches in flight: measured best at 16 x 4 (profiles/r2/wire_format_rate.jsonl).
+ * 16 batches = ~13 k seeds stay below the lane kernels' minimum batch on purpose: a lane launch costs one wave's full
+ * duration (1.6 ms per side) however few seeds it holds, the wave-per-seed kernel finishes such a group sooner. */
+#define REFBATCH_GROUP 16
+#define REFBATCH_SLOTS 4
+static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int zdrop, stage_t &st, hipStream_t s, size_t *n_out)
 {
     errs &e = ctx->err;
-    stage_t &st = ctx->small;
-    hipStream_t s = ctx->stream0();
+    *n_out = 0;
     const uint32_t *W0 = ctx->ref_queue[q0].in;
     bsw_params p;
     bsw_default_params(&p);                       /* matrix a=1,b=4,N=-1 is hard-wired (sw_extend.v:1915-1940) */
@@ -1747,17 +1754,45 @@ static int refbatch_group(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int z
     HIPCHK(e, bsw::launch_bin(bp, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
     rc = enqueue_batch(e, dp, variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, pl, st.d_out.p, s, nullptr);
     if (rc) return rc;
-    HIPCHK(e, hipMemcpyAsync(st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
-    rc = sync_stream(ctx, e, s, ctx->devs[0].events[0]);
-    if (rc) return rc;
-    size_t ti = 0;
-    for (size_t q = q0; q < q1; ++q) {
-        const uint32_t nt = ctx->ref_queue[q].in[2];
-        memset(ctx->ref_queue[q].out, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
-        rc = bsw_refbatch_encode_results(st.h_out.p + ti, nt, ctx->ref_queue[q].out);
-        if (rc < 0) return fail(e, rc, "result batch encode");
-        ti += nt;
+    /* the result DMA is issued by refbatch_collect once the kernels are done: a copy queued now would sit in its DMA
+     * engine's ring until then and hold up the next group's input copies queued behind it */
+    *n_out = n;
+    return BSW_OK;
+}
+
+/* wait for an enqueued group and write its 16 KiB result batches (host threads, one batch at a time each) */
+static int refbatch_collect(bsw_ctx *ctx, size_t q0, size_t q1, size_t n, stage_t &st, hipStream_t s, hipEvent_t ev)
+{
+    errs &e = ctx->err;
+    {
+        const int rc0 = sync_stream(ctx, e, s, ev);
+        if (rc0) return rc0;
+        HIPCHK(e, hipMemcpyAsync(st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
     }
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
+    int rc = sync_stream(ctx, e, s, ev);
+    if (rc) return rc;
+    if (dbg) fprintf(stderr, "[bsw] wire:   waited %.3f ms for the GPU\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+    const size_t nb = q1 - q0;
+    std::vector<size_t> tbase(nb + 1, 0);
+    for (size_t q = q0; q < q1; ++q) tbase[q - q0 + 1] = tbase[q - q0] + ctx->ref_queue[q].in[2];
+    const size_t nth = std::max<size_t>(1, std::min<size_t>((size_t)ctx->cfg.pack_threads, nb / 4));
+    std::vector<int> trc(nth, 0);
+    auto enc = [&](size_t t) {
+        for (size_t q = q0 + t; q < q1; q += nth) {
+            const uint32_t nt = ctx->ref_queue[q].in[2];
+            memset(ctx->ref_queue[q].out, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
+            const int r = bsw_refbatch_encode_results(st.h_out.p + tbase[q - q0], nt, ctx->ref_queue[q].out);
+            if (r < 0) trc[t] = r;
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nth; ++t) th.emplace_back(enc, t);
+    enc(0);
+    for (auto &x : th) x.join();
+    for (int r : trc)
+        if (r < 0) return fail(e, r, "result batch encode");
     return BSW_OK;
 }
 
@@ -1770,12 +1805,47 @@ extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
     if (variant != BSW_VARIANT_H && variant != BSW_VARIANT_M) { ctx->ref_queue.clear(); return fail(e, BSW_E_INVAL, "bad variant"); }
     if (hipSetDevice(ctx->device0()) != hipSuccess) { ctx->ref_queue.clear(); return fail(e, BSW_E_HIP, "hipSetDevice"); }
     const size_t nq = ctx->ref_queue.size();
+    /* Runs of batches with the same scoring header become device batches of at most REFBATCH_GROUP wire batches, up to
+     * REFBATCH_SLOTS of them in flight: the host parses the next group and writes an earlier group's result batches
+     * while the others are on the GPU (the reference's manager keeps its four TBB/RBB pairs busy the same way,
+     * batch_manager.v:418,745-773). */
+    dev_state &dev = ctx->devs[0];
+    const size_t grp_env = REFBATCH_GROUP;
+    const size_t NS = std::max<size_t>(1, std::min<size_t>(REFBATCH_SLOTS, dev.slots.size()));
+    const size_t slot_of[REFBATCH_SLOTS] = {0, 1, 2, 3};
+    struct flight { bool active = false; size_t q0 = 0, q1 = 0, n = 0; } fl[REFBATCH_SLOTS];
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = tnow();
+    auto collect = [&](size_t sl) -> int {
+        if (!fl[sl].active) return BSW_OK;
+        fl[sl].active = false;
+        const double t0 = tnow();
+        const int r = refbatch_collect(ctx, fl[sl].q0, fl[sl].q1, fl[sl].n, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], dev.events[slot_of[sl]]);
+        if (dbg) fprintf(stderr, "[bsw] wire: collect slot %zu batches [%zu,%zu): +%.3f .. +%.3f ms\n", sl, fl[sl].q0, fl[sl].q1, t0 - t_start, tnow() - t_start);
+        return r;
+    };
+    auto drain = [&]() { for (size_t sl = 0; sl < NS; ++sl) if (fl[sl].active) { errs quiet; (void)sync_stream(ctx, quiet, dev.streams[slot_of[sl]], dev.events[slot_of[sl]]); fl[sl].active = false; } };
+    size_t k = 0;
     for (size_t q0 = 0; q0 < nq;) {
         size_t q1 = q0 + 1;
-        while (q1 < nq && ctx->ref_queue[q1].in[0] == ctx->ref_queue[q0].in[0] && ctx->ref_queue[q1].in[1] == ctx->ref_queue[q0].in[1]) ++q1;
-        rc = refbatch_group(ctx, q0, q1, variant, zdrop);
-        if (rc) { ctx->ref_queue.clear(); return rc; }
+        while (q1 < nq && q1 - q0 < grp_env && ctx->ref_queue[q1].in[0] == ctx->ref_queue[q0].in[0] && ctx->ref_queue[q1].in[1] == ctx->ref_queue[q0].in[1]) ++q1;
+        if (nq - q1 < grp_env / 2)                                 /* no runt group at the end of a run */
+            while (q1 < nq && ctx->ref_queue[q1].in[0] == ctx->ref_queue[q0].in[0] && ctx->ref_queue[q1].in[1] == ctx->ref_queue[q0].in[1]) ++q1;
+        const size_t sl = k++ % NS;
+        rc = collect(sl);
+        size_t n_enq = 0;
+        const double te = tnow();
+        if (!rc) rc = refbatch_enqueue(ctx, q0, q1, variant, zdrop, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], &n_enq);
+        if (dbg) fprintf(stderr, "[bsw] wire: enqueue slot %zu batches [%zu,%zu) %zu tasks: +%.3f .. +%.3f ms\n", sl, q0, q1, n_enq, te - t_start, tnow() - t_start);
+        if (rc) { drain(); ctx->ref_queue.clear(); return rc; }
+        if (n_enq) { fl[sl].active = true; fl[sl].q0 = q0; fl[sl].q1 = q1; fl[sl].n = n_enq; }
         q0 = q1;
+    }
+    for (size_t sl = 0; sl < NS; ++sl) {
+        const size_t s2 = (k + sl) % NS;                                  /* oldest first */
+        rc = collect(s2);
+        if (rc) { drain(); ctx->ref_queue.clear(); return rc; }
     }
     ctx->ref_queue.clear();
     return (int)nq;
