@@ -195,6 +195,44 @@ def test_wire_batches_in_flight(host, oracle, kernel):
         assert (o[5 * n:] == 0).all()
 
 
+def test_wire_pipeline_errors_and_header_changes(host, oracle):
+    """The wire path runs groups of 16 batches, four in flight: a malformed batch in a late group is an error that leaves
+    nothing in flight (the context keeps working), and a change of the scoring header in mid-queue starts a new group."""
+    pa, pb = host.default_params(zdrop=0), host.default_params(zdrop=0, o_del=4, o_ins=4, e_del=2, e_ins=2, w=40)
+    tasks, arena = host.synth_tasks(70 * 819, seed=61, **MIXED)
+    ins, outs, meta, lo = [], [], [], 0
+    k = 0
+    while lo < len(tasks) and len(ins) < 70:
+        p = pb if 20 <= k < 45 else pa                                   # header changes twice, not on group boundaries
+        words, n = host.refbatch_encode(p, tasks[lo:lo + 819])
+        ins.append(words); outs.append(np.zeros(host.REFBATCH_OUT_WORDS, np.uint32)); meta.append((lo, n, p))
+        lo += n; k += 1
+    with host.BswContext(device=0) as c:
+        for a, b in zip(ins, outs):
+            c.refbatch_submit(a, b)
+        assert c.refbatch_wait(0, 0) == len(ins)
+        for (l0, n, p), o in zip(meta, outs):
+            want = oracle.pair_batch(p, tasks[l0:l0 + n], nthreads=8)
+            got = host.refbatch_decode_results(o, n)
+            for f in FIELDS:
+                assert (got[f] == want[f]).all(), (l0, f)
+        bad = ins[50].copy()
+        bad[8 + 2] = 0x7fffffff                                         # first task's data position far outside the batch
+        for i, (a, b) in enumerate(zip(ins, outs)):
+            c.refbatch_submit(bad if i == 50 else a, b)
+        with pytest.raises(host.BswError):
+            c.refbatch_wait(0, 0)
+        assert c.refbatch_wait() == 0                                   # queue dropped, nothing in flight
+        for a, b in zip(ins[:5], outs[:5]):
+            b[:] = 0
+            c.refbatch_submit(a, b)
+        assert c.refbatch_wait(0, 0) == 5
+        l0, n, p = meta[2]
+        got = host.refbatch_decode_results(outs[2], n)
+        want = oracle.pair_batch(p, tasks[l0:l0 + n], nthreads=8)
+        assert (got["score"] == want["score"]).all()
+
+
 def test_scalar_abi_from_many_threads(host, oracle):
     """bwa's -t worker threads call ksw_extend2 concurrently: calls are coalesced into device batches."""
     L = host.lib()
