@@ -49,6 +49,10 @@ L2_FN uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_p
 /* an inline constant feeds only the LOW half of a packed op on gfx9 (its high 16 bits are 0): op_sel_hi:[0,1] makes the
  * high half read the low 16 bits of src0 too */
 L2_FN uint32_t pk_shr8(uint32_t a) { uint32_t d; asm("v_pk_lshrrev_b16 %0, 8, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(a)); return d; }
+L2_FN uint32_t pk_shl8(uint32_t a) { uint32_t d; asm("v_pk_lshlrev_b16 %0, 8, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(a)); return d; }
+/* {hi byte of a.lo16, hi byte of b.lo16} per half: (a & 0xff00ff00) | ((b >> 8) & 0x00ff00ff) in one v_perm_b32 */
+L2_FN uint32_t pack_hi_bytes(uint32_t a, uint32_t b) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(0x07030501u)); return d; }
+L2_FN uint32_t or_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_or_b32 %0, %2, %1" : "=v"(d) : "v"(a), "s"(sb)); return d; }
 /* variants whose constant operand sits in an SGPR (one scalar per VOP3P instruction on gfx9) */
 L2_FN uint32_t pk_subs_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "s"(sb)); return d; }
 L2_FN uint32_t pk_min_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(sb)); return d; }
@@ -70,6 +74,9 @@ L2_FN uint32_t pk_subs(uint32_t a, uint32_t b) { return mk2(lo16(a) > lo16(b) ? 
 L2_FN uint32_t pk_sub(uint32_t a, uint32_t b) { return mk2((uint32_t)(lo16(a) - lo16(b)), (uint32_t)(hi16(a) - hi16(b))); }
 L2_FN uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return mk2((uint32_t)lo16(a) * lo16(b) + lo16(c), (uint32_t)hi16(a) * hi16(b) + hi16(c)); }
 L2_FN uint32_t pk_shr8(uint32_t a) { return (a >> 8) & 0x00ff00ffu; }
+L2_FN uint32_t pk_shl8(uint32_t a) { return (a << 8) & 0xff00ff00u; }
+L2_FN uint32_t pack_hi_bytes(uint32_t a, uint32_t b) { return (a & 0xff00ff00u) | ((b >> 8) & 0x00ff00ffu); }
+L2_FN uint32_t or_vs(uint32_t a, uint32_t sb) { return a | sb; }
 L2_FN uint32_t pk_subs_vs(uint32_t a, uint32_t sb) { return pk_subs(a, sb); }
 L2_FN uint32_t pk_min_vs(uint32_t a, uint32_t sb) { return pk_min(a, sb); }
 L2_FN uint32_t pk_mad_vsv(uint32_t a, uint32_t sb, uint32_t c) { return pk_mad(a, sb, c); }
@@ -94,8 +101,18 @@ L2_FN void sfor(F &&f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
 struct consts {
     int a, pb, pn;                      /* match score, mismatch penalty (-mat[1]), N penalty (-mat[24]); pb >= pn >= 0 */
     int o_del, e_del, oe_ins, e_ins, zdrop;
-    uint32_t OE2, ED2, ONE2;            /* {oe,oe}, {e,e}, {1,1}: symmetric gaps (o_del == o_ins, e_del == e_ins) */
+    uint32_t OE2s, ED2s, ONE2;          /* {oe,oe} << 8, {e,e} << 8, {1,1}: symmetric gaps (o_del == o_ins, e_del == e_ins) */
+    uint32_t MC[8];                     /* {a+pb, a+pb} << (8 - c): match bit c of a block byte -> (a + pb) << 8 */
 };
+
+/* the packed constants from the scalar ones (o_del + e_del < 256 and a + pb < 256: lane2_params_ok) */
+L2_FN void fill_packed_consts(consts &k)
+{
+    k.OE2s = dup16((k.o_del + k.e_del) << 8);
+    k.ED2s = dup16(k.e_del << 8);
+    k.ONE2 = 0x00010001u;
+    for (int c = 0; c < 8; ++c) k.MC[c] = dup16((k.a + k.pb) << (8 - c));
+}
 
 struct seedv {                          /* the scalars of one ksw_extend2 call (K1/K9) */
     int qlen, tlen, h0, w, beg, end;
@@ -184,51 +201,55 @@ struct lane2 {
     }
 
     /* One DP cell of column J for both seeds (K5: :1797-1798,1809,1866,1863,1776).
+     * Scores live in the HIGH byte of each 16-bit half inside the row ("scaled": value << 8, low byte 0); saturating
+     * subtract and max are scale-invariant, the match bit needs no normalising shift (bit c of the block's match
+     * byte times (a+b) << (8-c) is (a+b) << 8 whatever c is), the row-max key is `h | column` and the stored pair
+     * {e', H(i,j-1)} is one byte permute.
      * EDGE: the block holds some seed's `end` -> writes, the row max and the non-zero bits are masked per half to
      *       J < end (cells) / J <= end (the eh[end] = {h1, 0} store, :1775).  NQ: some query has an N in this block.
-     * Returns nothing; state flows through h1, f, mk, nz. */
+     * State flows through h1, f (scaled), mk, nz. */
     template <int J, bool EDGE, bool NQ>
-    L2_MFN void cell(uint32_t &P, const uint32_t Wc, const uint32_t WNc, const uint32_t AB2, const uint32_t Bv2, const uint32_t D2,
+    L2_MFN void cell(uint32_t &P, const uint32_t Wc8, const uint32_t WNc, const uint32_t Bv2s, const uint32_t D2s,
                            const consts &k, const uint32_t END2, uint32_t &mi_prev, uint32_t &h1, uint32_t &f, uint32_t &mk, uint32_t &nz)
     {
         /* key and non-zero bit are relative to the 8-column block: 16 distinct SGPR constants in the whole kernel
          * (column-absolute ones would be ~80, all hoisted out of the row loop, and spill) */
-        constexpr uint32_t JJ = (uint32_t)(J & 7) * 0x00010001u;
-        constexpr uint32_t BIT = (uint32_t)(1u << (J & 7)) * 0x00010001u;
-        uint32_t t = (J & 15) ? (Wc >> (J & 15)) : Wc;
-        t &= 0x00010001u;                                    /* 1 where q_j == t_i */
-        const uint32_t hd = P & 0x00ff00ffu;                 /* eh[j].h = H(i-1,j-1) */
-        const uint32_t e = pk_shr8(P);                       /* eh[j].e */
-        uint32_t X = pk_mad(t, AB2, hd);                     /* hd + (match ? a + pb : 0) */
+        constexpr int C = J & 7;
+        constexpr uint32_t JJ = (uint32_t)C * 0x00010001u;
+        constexpr uint32_t BIT = (uint32_t)(1u << C) * 0x00010001u;
+        const uint32_t t = Wc8 & BIT;                        /* 2^C where q_j == t_i */
+        const uint32_t hd = pk_shl8(P);                      /* eh[j].h = H(i-1,j-1), scaled */
+        const uint32_t e = P & 0xff00ff00u;                  /* eh[j].e, scaled */
+        uint32_t X = pk_mad_vsv(t, k.MC[C], hd);             /* hd + (match ? a + pb : 0) */
         if (NQ) {
             uint32_t n = (J & 15) ? (WNc >> (J & 15)) : WNc;
             n &= 0x00010001u;
-            X = pk_mad(n, D2, X);                            /* a query N scores -pn whatever the target base is */
+            X = pk_mad(n, D2s, X);                           /* a query N scores -pn whatever the target base is */
         }
-        const uint32_t M = pk_subs(X, Bv2);                  /* max(hd + s, 0): variant H, e and f are >= 0 anyway */
+        const uint32_t M = pk_subs(X, Bv2s);                 /* max(hd + s, 0): variant H, e and f are >= 0 anyway */
         uint32_t h = pk_max(pk_max(M, e), f);                /* (:1798,1809) */
-        const uint32_t tD = pk_subs_vs(h, k.OE2);
-        uint32_t en = pk_max(pk_subs_vs(e, k.ED2), tD);         /* (:1866,1770-1771) */
-        f = pk_max(pk_subs_vs(f, k.ED2), tD);                   /* (:1863,1780-1781) */
+        const uint32_t tD = pk_subs_vs(h, k.OE2s);
+        uint32_t en = pk_max(pk_subs_vs(e, k.ED2s), tD);     /* (:1866,1770-1771) */
+        f = pk_max(pk_subs_vs(f, k.ED2s), tD);               /* (:1863,1780-1781) */
         if (!EDGE) {
-            const uint32_t key = key_of(h, JJ);              /* row max of this block, ties -> later j */
-            mk = (J & 7) ? pk_max(mk, key) : key;
-            const uint32_t np = (en << 8) | h1;              /* eh[j] = {e', H(i,j-1)} (:1776) */
+            const uint32_t key = or_vs(h, JJ);               /* row max of this block, ties -> later j */
+            mk = C ? pk_max(mk, key) : key;
+            const uint32_t np = pack_hi_bytes(en, h1);       /* eh[j] = {e', H(i,j-1)} (:1776) */
             const uint32_t nb = pk_min_vs(np, k.ONE2);
-            nz = (J & 7) ? pk_mad_vsv(nb, BIT, nz) : nb;
+            nz = C ? pk_mad_vsv(nb, BIT, nz) : nb;
             P = np;
             h1 = h;
         } else {
-            const uint32_t d = pk_subs_vs(END2, dup16(J & 7));   /* END2 is relative to the block here: non-zero iff J < end */
+            const uint32_t d = pk_subs_vs(END2, dup16(C));   /* END2 is relative to the block here: non-zero iff J < end */
             const uint32_t mi = pk_sub(0u, pk_min_vs(d, k.ONE2));   /* 0xffff where J < end */
             const uint32_t mw = mi | mi_prev;                /* 0xffff where J <= end */
             mi_prev = mi;
-            const uint32_t key = key_of(h & mi, JJ);
-            mk = (J & 7) ? pk_max(mk, key) : key;
+            const uint32_t key = or_vs(h & mi, JJ);
+            mk = C ? pk_max(mk, key) : key;
             en &= mi;
-            const uint32_t np = ((en << 8) | h1) & mw;
+            const uint32_t np = pack_hi_bytes(en, h1) & mw;
             const uint32_t nb = pk_min_vs(np, k.ONE2);
-            nz = (J & 7) ? pk_mad_vsv(nb, BIT, nz) : nb;
+            nz = C ? pk_mad_vsv(nb, BIT, nz) : nb;
             P = bfi(mw, np, P);
             h1 = bfi(mi, h, h1);
         }
@@ -269,13 +290,14 @@ struct lane2 {
         match_words(qp, 0, tb[0], S.s[0].beg, rmA);
         match_words(qp, 1, tb[1], S.s[1].beg, rmB);
         /* a row against a target N scores -pn everywhere (mat[4][.], :1915-1940) */
+        /* (the match multiplier stays a + pb: against a target N no match bit is set) */
         const int pbA = tb[0] < 4 ? k.pb : k.pn, pbB = tb[1] < 4 ? k.pb : k.pn;
-        const uint32_t AB2 = pack2(k.a + pbA, k.a + pbB), Bv2 = pack2(pbA, pbB), D2 = pack2(pbA - k.pn, pbB - k.pn);
+        const uint32_t Bv2 = pack2(pbA, pbB) << 8, D2 = pack2(pbA - k.pn, pbB - k.pn) << 8;
         const uint32_t END2 = pack2(S.s[0].end, S.s[1].end);
         /* K4 column 0 (:1795-1796,1835), CPU semantics: only when beg == 0 */
         const int hi0 = S.s[0].beg == 0 ? imax(S.s[0].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
         const int hi1 = S.s[1].beg == 0 ? imax(S.s[1].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
-        uint32_t h1 = pack2(hi0, hi1), f = 0;
+        uint32_t h1 = pack2(hi0, hi1) << 8, f = 0;          /* scaled, like every score inside the row */
         L2_STAMP(2);
         uint32_t mkg[NG], nzc[NC];
         sfor<NG>([&](auto gi) { mkg[decltype(gi)::value] = 0; });
@@ -288,17 +310,18 @@ struct lane2 {
             if (b < blo) return;                              /* j0 + 8 <= jlo */
             if (b > bhi) return;                              /* j0 > jhi */
             /* both seeds' match bits of this 16-column chunk: low half seed A, high half seed B */
-            const uint32_t Wc = (c & 1) ? ((rmA[wd] >> 16) | (rmB[wd] & 0xffff0000u)) : ((rmA[wd] & 0xffffu) | (rmB[wd] << 16));
+            const uint32_t Wc16 = (c & 1) ? ((rmA[wd] >> 16) | (rmB[wd] & 0xffff0000u)) : ((rmA[wd] & 0xffffu) | (rmB[wd] << 16));
+            const uint32_t Wc = (b & 1) ? (Wc16 >> 8) : Wc16;   /* this block's 8 match bits in bits 0..7 of each half */
             uint32_t mkb = 0, nz8 = 0;                        /* this block's row-max key and non-zero bits */
             /* nested scalar branches (a combined condition would be materialised as lane masks for all 17 blocks
              * before the loop and spill) */
             if (b < bem) {                                    /* j0 + 8 <= jem: inside every active seed's range */
                 uint32_t dummy = 0;
                 if (!(nblk & (1u << b))) {
-                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, AB2, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
+                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
                 } else {
                     const uint32_t WNc = wn(c);
-                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, AB2, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
+                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
                 }
             } else {
                 /* mi of column j0 - 1 */
@@ -306,10 +329,10 @@ struct lane2 {
                 uint32_t mi_prev = pk_sub(0u, pk_min_vs(d0, k.ONE2));
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
                 if (!(nblk & (1u << b))) {
-                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, AB2, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
+                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
                 } else {
                     const uint32_t WNc = wn(c);
-                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, AB2, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
+                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
                 }
             }
             /* fold the block into its 64-column group / 16-column chunk (column offsets only touch the low key bits) */
@@ -324,7 +347,7 @@ struct lane2 {
             if (!r.act[x]) return;
             seedv &s = S.s[x];
             constexpr int sh = 16 * x;
-            const int h1x = (int)((h1 >> sh) & 0xffffu);
+            const int h1x = (int)((h1 >> (sh + 8)) & 0xffu);
             int mk = 0;                                      /* (m << 8) | mj over the groups; 0 = no positive cell */
             sfor<NG>([&](auto gi) {
                 constexpr int g = decltype(gi)::value;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     l2::consts k;
     k.a = P.mat[0]; k.pb = -P.mat[1]; k.pn = -P.mat[24];
     k.o_del = P.o_del; k.e_del = P.e_del; k.oe_ins = P.o_ins + P.e_ins; k.e_ins = P.e_ins; k.zdrop = P.zdrop;
-    k.OE2 = l2::dup16(P.o_del + P.e_del); k.ED2 = l2::dup16(P.e_del); k.ONE2 = 0x00010001u;
+    l2::fill_packed_consts(k);
     L::init_row(S, k);
 
     const auto qp = [&](int x, int b, uint32_t (&rm)[NW]) {

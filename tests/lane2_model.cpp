@@ -31,7 +31,7 @@ struct wave_model {
         consts k;
         k.a = p->mat[0]; k.pb = -p->mat[1]; k.pn = -p->mat[24];
         k.o_del = p->o_del; k.e_del = p->e_del; k.oe_ins = p->o_ins + p->e_ins; k.e_ins = p->e_ins; k.zdrop = p->zdrop;
-        k.OE2 = dup16(p->o_del + p->e_del); k.ED2 = dup16(p->e_del); k.ONE2 = 0x00010001u;
+        fill_packed_consts(k);
         int mx = 0;
         for (int i = 0; i < 25; ++i) mx = mx > p->mat[i] ? mx : p->mat[i];
         std::vector<lane_t> ln(64);
