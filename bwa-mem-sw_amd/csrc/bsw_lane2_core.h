@@ -53,6 +53,12 @@ L2_FN uint32_t pk_shl8(uint32_t a) { uint32_t d; asm("v_pk_lshlrev_b16 %0, 8, %1
 /* {hi byte of a.lo16, hi byte of b.lo16} per half: (a & 0xff00ff00) | ((b >> 8) & 0x00ff00ff) in one v_perm_b32 */
 L2_FN uint32_t pack_hi_bytes(uint32_t a, uint32_t b) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(0x07030501u)); return d; }
 L2_FN uint32_t or_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_or_b32 %0, %2, %1" : "=v"(d) : "v"(a), "s"(sb)); return d; }
+/* 16-bit half X of lo in bits [15:0], half X of hi in bits [31:16] */
+template <int X>
+L2_FN uint32_t half_pair(uint32_t lo, uint32_t hi) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(hi), "v"(lo), "s"(X ? 0x07060302u : 0x05040100u)); return d; }
+/* byte k of a in bits [7:0], byte k of b in bits [23:16], zeros elsewhere (k = 0..3) */
+template <int K>
+L2_FN uint32_t byte_pair(uint32_t a, uint32_t b) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(0x0c000c00u | (uint32_t)K | ((uint32_t)(4 + K) << 16))); return d; }
 /* variants whose constant operand sits in an SGPR (one scalar per VOP3P instruction on gfx9) */
 L2_FN uint32_t pk_subs_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "s"(sb)); return d; }
 L2_FN uint32_t pk_min_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(sb)); return d; }
@@ -77,6 +83,10 @@ L2_FN uint32_t pk_shr8(uint32_t a) { return (a >> 8) & 0x00ff00ffu; }
 L2_FN uint32_t pk_shl8(uint32_t a) { return (a << 8) & 0xff00ff00u; }
 L2_FN uint32_t pack_hi_bytes(uint32_t a, uint32_t b) { return (a & 0xff00ff00u) | ((b >> 8) & 0x00ff00ffu); }
 L2_FN uint32_t or_vs(uint32_t a, uint32_t sb) { return a | sb; }
+template <int X>
+L2_FN uint32_t half_pair(uint32_t lo, uint32_t hi) { return X ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16)); }
+template <int K>
+L2_FN uint32_t byte_pair(uint32_t a, uint32_t b) { return ((a >> (8 * K)) & 0xffu) | (((b >> (8 * K)) & 0xffu) << 16); }
 L2_FN uint32_t pk_subs_vs(uint32_t a, uint32_t sb) { return pk_subs(a, sb); }
 L2_FN uint32_t pk_min_vs(uint32_t a, uint32_t sb) { return pk_min(a, sb); }
 L2_FN uint32_t pk_mad_vsv(uint32_t a, uint32_t sb, uint32_t c) { return pk_mad(a, sb, c); }
@@ -310,8 +320,7 @@ struct lane2 {
             if (b < blo) return;                              /* j0 + 8 <= jlo */
             if (b > bhi) return;                              /* j0 > jhi */
             /* both seeds' match bits of this 16-column chunk: low half seed A, high half seed B */
-            const uint32_t Wc16 = (c & 1) ? ((rmA[wd] >> 16) | (rmB[wd] & 0xffff0000u)) : ((rmA[wd] & 0xffffu) | (rmB[wd] << 16));
-            const uint32_t Wc = (b & 1) ? (Wc16 >> 8) : Wc16;   /* this block's 8 match bits in bits 0..7 of each half */
+            const uint32_t Wc = byte_pair<b & 3>(rmA[wd], rmB[wd]);   /* this block's 8 match bits of seed A / B in bits 0..7 of the low / high half */
             uint32_t mkb = 0, nz8 = 0;                        /* this block's row-max key and non-zero bits */
             /* nested scalar branches (a combined condition would be materialised as lane masks for all 17 blocks
              * before the loop and spill) */
@@ -376,7 +385,7 @@ struct lane2 {
                 if (32 * wd + 32 <= u.jlo || 32 * wd > u.jhi) return;
                 constexpr int chi = 2 * wd + 1 < NC ? 2 * wd + 1 : 2 * wd;
                 const uint32_t lo = nzc[2 * wd], hic = 2 * wd + 1 < NC ? nzc[chi] : 0u;
-                const uint32_t word = x ? ((lo >> 16) | (hic & 0xffff0000u)) : ((lo & 0xffffu) | (hic << 16));
+                const uint32_t word = half_pair<x>(lo, hic);
                 if (word) {
                     fnz = ffs_lo(word) + 32 * wd;
                     lnz = imax(lnz, fls_hi(word) + 32 * wd);
