@@ -66,8 +66,9 @@ L2_FN uint32_t pk_mad_vsv(uint32_t a, uint32_t sb, uint32_t c) { uint32_t d; asm
 L2_FN uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { uint32_t d; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b)); return d; }   /* (m & a) | (~m & b) */
 /* (h << 8) | jj with the column constant in an SGPR: no VGPR and no VALU op spent on it */
 L2_FN uint32_t key_of(uint32_t h, uint32_t jj) { uint32_t d; asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(d) : "v"(h), "s"(jj)); return d; }
-L2_FN int ffs_lo(uint32_t x) { return (int)__builtin_ctz(x); }
-L2_FN int fls_hi(uint32_t x) { return 31 - (int)__builtin_clz(x); }
+/* index of the lowest / highest set bit; 0xffffffff for x == 0 (what the hardware returns) */
+L2_FN uint32_t ffbl(uint32_t x) { uint32_t d; asm("v_ffbl_b32 %0, %1" : "=v"(d) : "v"(x)); return d; }
+L2_FN uint32_t ffbh(uint32_t x) { uint32_t d; asm("v_ffbh_u32 %0, %1" : "=v"(d) : "v"(x)); return d; }   /* counted from the MSB */
 /* a wave-uniform value the compiler must re-read here: keeps tests on it from being hoisted out of the row loop */
 L2_FN uint32_t opaque_s(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
 #else
@@ -92,8 +93,8 @@ L2_FN uint32_t pk_min_vs(uint32_t a, uint32_t sb) { return pk_min(a, sb); }
 L2_FN uint32_t pk_mad_vsv(uint32_t a, uint32_t sb, uint32_t c) { return pk_mad(a, sb, c); }
 L2_FN uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
 L2_FN uint32_t key_of(uint32_t h, uint32_t jj) { return (h << 8) | jj; }
-L2_FN int ffs_lo(uint32_t x) { return __builtin_ctz(x); }
-L2_FN int fls_hi(uint32_t x) { return 31 - __builtin_clz(x); }
+L2_FN uint32_t ffbl(uint32_t x) { return x ? (uint32_t)__builtin_ctz(x) : 0xffffffffu; }
+L2_FN uint32_t ffbh(uint32_t x) { return x ? (uint32_t)__builtin_clz(x) : 0xffffffffu; }
 L2_FN uint32_t opaque_s(uint32_t x) { return x; }
 #endif
 
@@ -350,6 +351,13 @@ struct lane2 {
         });
 
         L2_STAMP(3);
+        /* row max over the groups, both seeds at once: the low byte of a group's key is the column inside the group
+         * (< 64), so adding 64 g makes it absolute without touching the score byte */
+        uint32_t mk2 = mkg[0];
+        sfor<NG - 1>([&](auto gi) {
+            constexpr int g = decltype(gi)::value + 1;
+            mk2 = pk_max(mk2, mkg[g] + (uint32_t)(64 * g) * 0x00010001u);
+        });
         /* ---- row tail per seed (K7, K8) ---- */
         sfor<2>([&](auto xi) {
             constexpr int x = decltype(xi)::value;
@@ -357,12 +365,7 @@ struct lane2 {
             seedv &s = S.s[x];
             constexpr int sh = 16 * x;
             const int h1x = (int)((h1 >> (sh + 8)) & 0xffu);
-            int mk = 0;                                      /* (m << 8) | mj over the groups; 0 = no positive cell */
-            sfor<NG>([&](auto gi) {
-                constexpr int g = decltype(gi)::value;
-                const int key = (int)((mkg[g] >> sh) & 0xffffu);
-                mk = imax(mk, ((key >> 8) << 8) | ((key & 63) + 64 * g));
-            });
+            const int mk = (int)((mk2 >> sh) & 0xffffu);     /* (m << 8) | mj; m == 0: no positive cell */
             if (imax(s.beg, s.end) == s.qlen) {              /* ties -> later i (:1829-1833) */
                 s.max_ie = s.gscore > h1x ? s.max_ie : i;
                 s.gscore = imax(s.gscore, h1x);
@@ -379,19 +382,23 @@ struct lane2 {
                 stop = stop || (s.mx - m - pen > k.zdrop);
             }
             /* K8 next-row range (CPU semantics): first / last non-zero eh entry in [beg, end] from the bit masks */
-            int fnz = 1 << 20, lnz = -1;
+            /* an empty word gives 0xffffffff from both bit searches: never the unsigned minimum, and negative after
+             * `^ 31 | 32 wd`, never the signed maximum — no compare, no select */
+            uint32_t fnzu = 0xffffffffu;
+            int lnz = -1;
             sfor<NW>([&](auto wi) {
-                constexpr int wd = NW - 1 - decltype(wi)::value;      /* high to low: the lowest word wins fnz */
+                constexpr int wd = decltype(wi)::value;
                 if (32 * wd + 32 <= u.jlo || 32 * wd > u.jhi) return;
                 constexpr int chi = 2 * wd + 1 < NC ? 2 * wd + 1 : 2 * wd;
                 const uint32_t lo = nzc[2 * wd], hic = 2 * wd + 1 < NC ? nzc[chi] : 0u;
                 const uint32_t word = half_pair<x>(lo, hic);
-                if (word) {
-                    fnz = ffs_lo(word) + 32 * wd;
-                    lnz = imax(lnz, fls_hi(word) + 32 * wd);
-                }
+                const uint32_t cf = ffbl(word) | (uint32_t)(32 * wd);
+                const int cl = (int)((ffbh(word) ^ 31u) | (uint32_t)(32 * wd));
+                fnzu = cf < fnzu ? cf : fnzu;
+                lnz = imax(lnz, cl);
             });
-            const int nbeg = fnz < s.end ? fnz : s.end;
+            const int fnz = fnzu < (uint32_t)s.end ? (int)fnzu : s.end;
+            const int nbeg = fnz;
             const int last = lnz >= nbeg ? lnz : nbeg - 1;
             s.beg = nbeg;
             s.end = imin(last + 2, s.qlen);
