@@ -538,6 +538,7 @@ static int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams 
 {
     memset(&bp, 0, sizeof(bp));
     bp.a = p->mat[0];
+    bp.b = p->mat[1] < 0 ? -p->mat[1] : 0;
     bp.n_wave = bsw::wave_class_count();
     bp.n_lane = bsw::lane_class_count();
     if (bp.n_wave > BSW_MAX_WAVE_CLASSES || bp.n_lane > BSW_MAX_LANE_CLASSES) return fail(e, BSW_E_LIMIT, "class table too large");

@@ -73,6 +73,8 @@ typedef struct bsw_gdtask {
 
 typedef struct bsw_binparams {
     int32_t a;                                 /* match score (score range test)            */
+    int32_t b;                                 /* mismatch penalty (>= 0): the two-seeds-per-lane kernel forms H + a + b
+                                                  in 8 bits before it subtracts b                                        */
     int32_t lane_on;                           /* 0: every seed goes to the wave-per-task classes */
     int32_t n_wave, n_lane;
     int32_t wave_cols[BSW_MAX_WAVE_CLASSES];
@@ -91,7 +93,7 @@ BSW_HD int bsw_seed_lane_bits(const bsw_binparams *bp, int lqlen, int rqlen, int
     if (!bp->lane_on) return 0;
     const int qm = lqlen > rqlen ? lqlen : rqlen;
     const int64_t top = (int64_t)h0 + (int64_t)(lqlen + rqlen) * bp->a;   /* no H can exceed this */
-    if (top <= 255 && qm + 1 <= bp->cols8) return 8;
+    if (top + bp->b <= 255 && qm + 1 <= bp->cols8) return 8;
     if (top < 65000 && qm + 1 <= bp->cols16) return 16;
     return 0;
 }

@@ -5,7 +5,8 @@
  * SURVEY.md §8a, variant H) of two seeds at once: seed A in the low and seed B in the high 16 bits of every
  * register, with packed 16-bit VALU ops (v_pk_max_u16 / v_pk_sub_u16 clamp / v_pk_mad_u16: two values per
  * 4-cycle issue slot — the best per-value rate gfx950 offers for max/add work, profiles/r2/ubench3.txt).
- *   eh[] row: one VGPR per column, each half = {e:8 | h:8} (legal when h0 + qlen*a <= 255 and qlen <= 135).
+ *   eh[] row: one VGPR per column, each half = {e:8 | h:8} (legal when h0 + qlen*a + b <= 255 and qlen <= 135:
+ *   the cell forms H + a + b in the 8 score bits before it subtracts b).
  *   Scores are unsigned with saturating subtraction: max(x - c, 0) is one op.
  *   Left edge: eh[j] == 0 for every j < beg is an invariant (zero-trimming only passes zeros; columns the band
  *   clamp drops are zeroed explicitly) and the match mask is cleared below beg, so cells left of beg compute to
@@ -53,6 +54,8 @@ L2_FN uint32_t pk_shl8(uint32_t a) { uint32_t d; asm("v_pk_lshlrev_b16 %0, 8, %1
 /* {hi byte of a.lo16, hi byte of b.lo16} per half: (a & 0xff00ff00) | ((b >> 8) & 0x00ff00ff) in one v_perm_b32 */
 L2_FN uint32_t pack_hi_bytes(uint32_t a, uint32_t b) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(0x07030501u)); return d; }
 L2_FN uint32_t or_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_or_b32 %0, %2, %1" : "=v"(d) : "v"(a), "s"(sb)); return d; }
+/* (a & m) | sc with the mask in a VGPR and the constant in an SGPR (a VOP3 reads one scalar at most on gfx9) */
+L2_FN uint32_t and_or_vvs(uint32_t a, uint32_t m, uint32_t sc) { uint32_t d; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(m), "s"(sc)); return d; }
 /* 16-bit half X of lo in bits [15:0], half X of hi in bits [31:16] */
 template <int X>
 L2_FN uint32_t half_pair(uint32_t lo, uint32_t hi) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(hi), "v"(lo), "s"(X ? 0x07060302u : 0x05040100u)); return d; }
@@ -84,6 +87,7 @@ L2_FN uint32_t pk_shr8(uint32_t a) { return (a >> 8) & 0x00ff00ffu; }
 L2_FN uint32_t pk_shl8(uint32_t a) { return (a << 8) & 0xff00ff00u; }
 L2_FN uint32_t pack_hi_bytes(uint32_t a, uint32_t b) { return (a & 0xff00ff00u) | ((b >> 8) & 0x00ff00ffu); }
 L2_FN uint32_t or_vs(uint32_t a, uint32_t sb) { return a | sb; }
+L2_FN uint32_t and_or_vvs(uint32_t a, uint32_t m, uint32_t sc) { return (a & m) | sc; }
 template <int X>
 L2_FN uint32_t half_pair(uint32_t lo, uint32_t hi) { return X ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16)); }
 template <int K>
@@ -114,6 +118,7 @@ struct consts {
     int o_del, e_del, oe_ins, e_ins, zdrop;
     uint32_t OE2s, ED2s, ONE2;          /* {oe,oe} << 8, {e,e} << 8, {1,1}: symmetric gaps (o_del == o_ins, e_del == e_ins) */
     uint32_t MC[8];                     /* {a+pb, a+pb} << (8 - c): match bit c of a block byte -> (a + pb) << 8 */
+    uint32_t HI2;                       /* 0xff00ff00: the score bytes (kept in a VGPR by the kernel) */
 };
 
 /* the packed constants from the scalar ones (o_del + e_del < 256 and a + pb < 256: lane2_params_ok) */
@@ -123,6 +128,7 @@ L2_FN void fill_packed_consts(consts &k)
     k.ED2s = dup16(k.e_del << 8);
     k.ONE2 = 0x00010001u;
     for (int c = 0; c < 8; ++c) k.MC[c] = dup16((k.a + k.pb) << (8 - c));
+    k.HI2 = 0xff00ff00u;
 }
 
 struct seedv {                          /* the scalars of one ksw_extend2 call (K1/K9) */
@@ -215,7 +221,10 @@ struct lane2 {
      * Scores live in the HIGH byte of each 16-bit half inside the row ("scaled": value << 8, low byte 0); saturating
      * subtract and max are scale-invariant, the match bit needs no normalising shift (bit c of the block's match
      * byte times (a+b) << (8-c) is (a+b) << 8 whatever c is), the row-max key is `h | column` and the stored pair
-     * {e', H(i,j-1)} is one byte permute.
+     * {e', H(i,j-1)} is one byte permute.  The LOW byte of a scaled value is don't-care: 16-bit max and saturating
+     * subtract are exact on the high byte whatever the low bytes hold (a tie in the high byte is a tie in the
+     * score), so eh[j] = {e:8 | h:8} itself serves as "e" without an extraction; only the key and the stored pair
+     * need clean bytes, and both take them by byte selection.
      * EDGE: the block holds some seed's `end` -> writes, the row max and the non-zero bits are masked per half to
      *       J < end (cells) / J <= end (the eh[end] = {h1, 0} store, :1775).  NQ: some query has an N in this block.
      * State flows through h1, f (scaled), mk, nz. */
@@ -230,7 +239,7 @@ struct lane2 {
         constexpr uint32_t BIT = (uint32_t)(1u << C) * 0x00010001u;
         const uint32_t t = Wc8 & BIT;                        /* 2^C where q_j == t_i */
         const uint32_t hd = pk_shl8(P);                      /* eh[j].h = H(i-1,j-1), scaled */
-        const uint32_t e = P & 0xff00ff00u;                  /* eh[j].e, scaled */
+        const uint32_t e = P;                                /* eh[j].e in the high byte (the low byte is don't-care) */
         uint32_t X = pk_mad_vsv(t, k.MC[C], hd);             /* hd + (match ? a + pb : 0) */
         if (NQ) {
             uint32_t n = (J & 15) ? (WNc >> (J & 15)) : WNc;
@@ -243,7 +252,7 @@ struct lane2 {
         uint32_t en = pk_max(pk_subs_vs(e, k.ED2s), tD);     /* (:1866,1770-1771) */
         f = pk_max(pk_subs_vs(f, k.ED2s), tD);               /* (:1863,1780-1781) */
         if (!EDGE) {
-            const uint32_t key = or_vs(h, JJ);               /* row max of this block, ties -> later j */
+            const uint32_t key = and_or_vvs(h, k.HI2, JJ);   /* row max of this block, ties -> later j */
             mk = C ? pk_max(mk, key) : key;
             const uint32_t np = pack_hi_bytes(en, h1);       /* eh[j] = {e', H(i,j-1)} (:1776) */
             const uint32_t nb = pk_min_vs(np, k.ONE2);
@@ -255,7 +264,7 @@ struct lane2 {
             const uint32_t mi = pk_sub(0u, pk_min_vs(d, k.ONE2));   /* 0xffff where J < end */
             const uint32_t mw = mi | mi_prev;                /* 0xffff where J <= end */
             mi_prev = mi;
-            const uint32_t key = or_vs(h & mi, JJ);
+            const uint32_t key = and_or_vvs(h & mi, k.HI2, JJ);
             mk = C ? pk_max(mk, key) : key;
             en &= mi;
             const uint32_t np = pack_hi_bytes(en, h1) & mw;

@@ -2,7 +2,7 @@
  * bsw_lane2_kernel.hip — gfx950 kernel: TWO EXTENSIONS PER LANE (inter-task SIMD with packed 16-bit math).
  *
  * The throughput path for the bins bwa's defaults produce: variant H, bwa-style matrix, symmetric gap penalties,
- * h0 + qlen*a <= 255, qlen <= 135 (150 bp reads).  A wavefront walks DP row i of 128 seeds together: lane l holds
+ * h0 + qlen*a + b <= 255, qlen <= 135 (150 bp reads).  A wavefront walks DP row i of 128 seeds together: lane l holds
  * seed A = order[128w + l] in the low and seed B = order[128w + 64 + l] in the high 16 bits of every register, and
  * every max / saturating-subtract / multiply-add of the recurrence (sw_pe_array_sw_extend.v:1797-1816,1863-1866)
  * is one v_pk_*_u16 instruction for both.  The per-lane arithmetic lives in bsw_lane2_core.h (shared with the CPU

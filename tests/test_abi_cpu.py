@@ -182,7 +182,8 @@ def test_batch_plan_bins(host):
                 q = t[qf]
                 assert (np.diff(q) <= 0).all() and (q + 1 <= ncol).all()          # longest queries first
                 tt = t["h0"].astype(np.int64) + t["lqlen"] + t["rqlen"]
-                assert ((tt <= 255) if bits == 8 else (tt > 255) | (np.maximum(t["lqlen"], t["rqlen"]) + 1 > 232)).all()
+                # 8-bit classes need h0 + qlen*a + b <= 255 (b = 4: the packed kernel forms H + a + b in 8 bits)
+                assert ((tt + 4 <= 255) if bits == 8 else (tt + 4 > 255) | (np.maximum(t["lqlen"], t["rqlen"]) + 1 > 232)).all()
         assert seg[26] - seg[25] == len(lane)                                 # redo list space
     # AUTO: small batches stay on the wave kernel, big eligible ones go to the lane bins
     order, seg, words = host.plan_batch(p, tasks[:500], kernel=host.KERNEL_AUTO)

@@ -105,6 +105,31 @@ def test_lane_class_250bp(host, oracle, lctx, qlen):
             assert_same(lctx.extend_pairs(p, tasks), oracle.pair_batch(p, tasks, nthreads=4), tasks)
 
 
+@pytest.mark.parametrize("ab", [(1, 4), (2, 3), (1, 1), (3, 7)])
+def test_top_of_the_8_bit_score_range(host, oracle, lctx, ab):
+    """Perfect matches that end exactly at, just below and just above 255 - b.  The two-seeds-per-lane kernel forms
+    H + a + b in 8 bits, so the batch manager may give it a seed only while h0 + qlen*a + b <= 255; anything above goes
+    to a wider class — and every one of them must still be exact."""
+    a, b = ab
+    rng = np.random.default_rng(a * 10 + b)
+    seeds = []
+    for k in range(2000):
+        lq = int(rng.integers(0, 60))
+        rq = int(rng.integers(1, min(135, (255 - 1) // a - lq)))
+        h0 = 255 - b - (lq + rq) * a + int(rng.integers(-2, b + 1))        # top in [255-b-2, 255]
+        if h0 < 1:
+            continue
+        qL, qR = rng.integers(0, 4, lq).astype(np.uint8), rng.integers(0, 4, rq).astype(np.uint8)
+        seeds.append(dict(lq=qL, lt=np.concatenate([qL, rng.integers(0, 4, 20).astype(np.uint8)]),
+                          rq=qR, rt=np.concatenate([qR, rng.integers(0, 4, 20).astype(np.uint8)]), h0=h0))
+    tasks, arena = host.make_tasks(seeds)
+    p = host.default_params()
+    p["mat"][0] = host.bwa_matrix(a, b, -1)
+    want = oracle.pair_batch(p, tasks, nthreads=4)
+    assert want["score"].max() == 255
+    assert_same(lctx.extend_pairs(p, tasks), want, tasks)
+
+
 def test_250bp_w500_workload(host, oracle, lctx):
     p = host.default_params(w=500)
     tasks, arena = host.synth_tasks(5000, seed=18, read_len=250, seed_len_min=19, seed_len_max=40, seed_at_start=0,

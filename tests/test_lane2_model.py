@@ -66,7 +66,7 @@ def test_random_seeds_match_the_oracle(model, host, oracle, over):
     seeds = _gen.random_seeds(rng, 700, qmin=1, qmax=135, tfac=2.2, sub=0.03, indel=0.02, junk=0.15, nrate=0.004, h0max=60)
     for s in seeds:                                       # 8-bit score range of the kernel class
         tot = len(s.get("lq", ())) + len(s.get("rq", ()))
-        s["h0"] = max(1, min(s["h0"], 255 - tot))
+        s["h0"] = max(1, min(s["h0"], 255 - 4 - tot))     # the class bound: h0 + qlen*a + b <= 255
     tasks, arena = host.make_tasks(seeds)
     p = host.default_params(**over)
     check(model, host, oracle, p, tasks)
@@ -79,7 +79,7 @@ def test_scoring_matrices(model, host, oracle, ab_n):
     seeds = _gen.random_seeds(rng, 400, qmin=1, qmax=135 // a, tfac=2.0, sub=0.05, indel=0.02, junk=0.1, nrate=0.01, h0max=40)
     for s in seeds:
         tot = len(s.get("lq", ())) + len(s.get("rq", ()))
-        s["h0"] = max(1, min(s["h0"], 255 - tot * a))
+        s["h0"] = max(1, min(s["h0"], 255 - b - tot * a))
     tasks, arena = host.make_tasks(seeds)
     p = host.default_params()
     p["mat"][0] = host.bwa_matrix(a, b, nn)
@@ -113,3 +113,36 @@ def test_ragged_and_tiny_waves(model, host, oracle):
     for n in (1, 2, 63, 64, 65, 127, 129, 200):
         tasks, arena = host.synth_tasks(n, seed=10 + n, seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.2, n_rate=0.003)
         check(model, host, oracle, p, tasks)
+
+
+@pytest.mark.parametrize("ab", [(1, 4), (2, 3), (1, 1), (3, 7)])
+def test_top_of_the_score_range(model, host, oracle, ab):
+    """Perfect matches whose final score is EXACTLY the class bound 255 - b: the scaled cell forms H + a + b in the
+    high byte of a 16-bit half before it subtracts b, so this is where an overflow would show."""
+    a, b = ab
+    rng = np.random.default_rng(a * 10 + b)
+    seeds = []
+    for k in range(300):
+        lq = int(rng.integers(0, 60))
+        rq = int(rng.integers(1, min(135, (255 - b - 1) // a - lq)))
+        h0 = 255 - b - (lq + rq) * a - int(rng.integers(0, 2))          # top = 255 - b, or one below
+        if h0 < 1:
+            continue
+        qL, qR = rng.integers(0, 4, lq).astype(np.uint8), rng.integers(0, 4, rq).astype(np.uint8)
+        tL = np.concatenate([qL, rng.integers(0, 4, 20).astype(np.uint8)])  # the query matches its target end to end
+        tR = np.concatenate([qR, rng.integers(0, 4, 20).astype(np.uint8)])
+        seeds.append(dict(lq=qL, lt=tL, rq=qR, rt=tR, h0=h0))
+    tasks, arena = host.make_tasks(seeds)
+    p = host.default_params()
+    p["mat"][0] = host.bwa_matrix(a, b, -1)
+    full = oracle.pair_batch(p, tasks, nthreads=4)
+    assert full["right"]["score"].max() == 255 - b                        # the bound is really reached
+    h0s = np.where(tasks["lqlen"] > 0, full["left"]["score"], tasks["h0"]).astype(np.int32)
+    got, idx = run_side(model, host, p, tasks, 0)
+    want = oracle_side(host, oracle, p, tasks, 0)
+    for f in EXTF:
+        assert (got[f][idx] == want[f][idx]).all(), f
+    got, idx = run_side(model, host, p, tasks, 1, h0s)
+    want = oracle_side(host, oracle, p, tasks, 1, h0s)
+    for f in EXTF:
+        assert (got[f][idx] == want[f][idx]).all(), f
