@@ -54,6 +54,9 @@ L2_FN uint32_t pk_shl8(uint32_t a) { uint32_t d; asm("v_pk_lshlrev_b16 %0, 8, %1
 /* {hi byte of a.lo16, hi byte of b.lo16} per half: (a & 0xff00ff00) | ((b >> 8) & 0x00ff00ff) in one v_perm_b32 */
 L2_FN uint32_t pack_hi_bytes(uint32_t a, uint32_t b) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(0x07030501u)); return d; }
 L2_FN uint32_t or_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_or_b32 %0, %2, %1" : "=v"(d) : "v"(a), "s"(sb)); return d; }
+/* 0xffff in every half of a that is non-zero: a * 0xffff, saturated (the inline constant -1 feeds both halves through
+ * op_sel_hi) */
+L2_FN uint32_t pk_nzmask(uint32_t a) { uint32_t d; asm("v_pk_mad_u16 %0, %1, -1, 0 op_sel_hi:[1,0,0] clamp" : "=v"(d) : "v"(a)); return d; }
 /* (a & m) | sc with the mask in a VGPR and the constant in an SGPR (a VOP3 reads one scalar at most on gfx9) */
 L2_FN uint32_t and_or_vvs(uint32_t a, uint32_t m, uint32_t sc) { uint32_t d; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(m), "s"(sc)); return d; }
 /* 16-bit half X of lo in bits [15:0], half X of hi in bits [31:16] */
@@ -88,6 +91,7 @@ L2_FN uint32_t pk_shl8(uint32_t a) { return (a << 8) & 0xff00ff00u; }
 L2_FN uint32_t pack_hi_bytes(uint32_t a, uint32_t b) { return (a & 0xff00ff00u) | ((b >> 8) & 0x00ff00ffu); }
 L2_FN uint32_t or_vs(uint32_t a, uint32_t sb) { return a | sb; }
 L2_FN uint32_t and_or_vvs(uint32_t a, uint32_t m, uint32_t sc) { return (a & m) | sc; }
+L2_FN uint32_t pk_nzmask(uint32_t a) { return ((a & 0xffffu) ? 0xffffu : 0u) | ((a >> 16) ? 0xffff0000u : 0u); }
 template <int X>
 L2_FN uint32_t half_pair(uint32_t lo, uint32_t hi) { return X ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16)); }
 template <int K>
@@ -261,7 +265,7 @@ struct lane2 {
             h1 = h;
         } else {
             const uint32_t d = pk_subs_vs(END2, dup16(C));   /* END2 is relative to the block here: non-zero iff J < end */
-            const uint32_t mi = pk_sub(0u, pk_min_vs(d, k.ONE2));   /* 0xffff where J < end */
+            const uint32_t mi = pk_nzmask(d);                /* 0xffff where J < end */
             const uint32_t mw = mi | mi_prev;                /* 0xffff where J <= end */
             mi_prev = mi;
             const uint32_t key = and_or_vvs(h & mi, k.HI2, JJ);
@@ -345,7 +349,7 @@ struct lane2 {
             } else {
                 /* mi of column j0 - 1 */
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
-                uint32_t mi_prev = pk_sub(0u, pk_min_vs(d0, k.ONE2));
+                uint32_t mi_prev = pk_nzmask(d0);
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
                 if (!(nblk & (1u << b))) {
                     sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
