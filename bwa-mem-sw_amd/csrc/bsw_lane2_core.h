@@ -266,7 +266,7 @@ struct lane2 {
         } else {
             const uint32_t d = pk_subs_vs(END2, dup16(C));   /* END2 is relative to the block here: non-zero iff J < end */
             const uint32_t mi = pk_nzmask(d);                /* 0xffff where J < end */
-            const uint32_t mw = mi | mi_prev;                /* 0xffff where J <= end */
+            const uint32_t mw = mi_prev;                     /* 0xffff where J <= end: J - 1 < end, the previous column's mask */
             mi_prev = mi;
             const uint32_t key = and_or_vvs(h & mi, k.HI2, JJ);
             mk = C ? pk_max(mk, key) : key;
