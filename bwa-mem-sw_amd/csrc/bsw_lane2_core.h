@@ -282,17 +282,26 @@ struct lane2 {
     /* match-mask words of one seed for target base tb: bit j = (q_j == t_i), neither an N, j >= beg.
      * mw(x, b, rm) loads the NW words precomputed for base b (0..3) of seed x's query: the kernel keeps the four
      * per-base masks in LDS, so a row costs two LDS reads per seed and no plane arithmetic. */
-    template <class MW>
-    L2_MFN void match_words(const MW &mw, int x, int tb, int beg, uint32_t (&rm)[NW])
+    static constexpr int KEEP_NONE = 32 * NW;         /* index of the all-zero entry of the keep table */
+
+    /* word wd of the keep-mask table entry b: bits of the columns >= b (entry KEEP_NONE: nothing) */
+    L2_MFN uint32_t keep_word(int b, int wd)
+    {
+        return b <= 32 * wd ? 0xffffffffu : (b >= 32 * wd + 32 ? 0u : 0xffffffffu << (b - 32 * wd));
+    }
+
+    /* kp(b, kw) loads the NW words of keep-table entry b (the kernel keeps the table in LDS, one per workgroup): the
+     * columns below beg lose their match bits with one AND per word; a row against a target N (no match anywhere)
+     * takes the all-zero entry. */
+    template <class MW, class KP>
+    L2_MFN void match_words(const MW &mw, const KP &kp, int x, int tb, int beg, uint32_t (&rm)[NW])
     {
         mw(x, tb & 3, rm);
-        const uint32_t tn = (uint32_t)((tb >> 2) - 1);       /* 0 when the target base is N, else ~0 */
-        const int bw = beg >> 5;                             /* words below bw are cleared, word bw partly */
-        const uint32_t km = (0xffffffffu << (beg & 31)) & tn;
+        uint32_t kw[NW];
+        kp(tb < 4 ? beg : KEEP_NONE, kw);
         sfor<NW>([&](auto wi) {
             constexpr int wd = decltype(wi)::value;
-            const uint32_t keep = wd < bw ? 0u : (wd == bw ? km : tn);   /* clear the columns below beg */
-            rm[wd] &= keep;
+            rm[wd] &= kw[wd];
         });
     }
 
@@ -303,16 +312,16 @@ struct lane2 {
     }
 
     /* One DP row for both seeds, after the wave-uniform values are known.  tb[x] = target base of seed x (0..4).
-     * qp(x, b, rm): per-base match words of seed x (see match_words); wn(c): N planes of both seeds interleaved per
+     * qp(x, b, rm): per-base match words of seed x, kp(b, kw): keep-table entry (see match_words); wn(c): N planes of both seeds interleaved per
      * 16-column chunk (low half seed A). */
-    template <class QP, class WN>
+    template <class QP, class KP, class WN>
     L2_MFN void row_body(state &S, const consts &k, const int i, const rowv &r, const uni &u, const int (&tb)[2],
-                               const QP &qp, const WN &wn)
+                               const QP &qp, const KP &kp, const WN &wn)
     {
         if (u.anybite) zero_dropped(S, r, u);
         uint32_t rmA[NW], rmB[NW];
-        match_words(qp, 0, tb[0], S.s[0].beg, rmA);
-        match_words(qp, 1, tb[1], S.s[1].beg, rmB);
+        match_words(qp, kp, 0, tb[0], S.s[0].beg, rmA);
+        match_words(qp, kp, 1, tb[1], S.s[1].beg, rmB);
         /* a row against a target N scores -pn everywhere (mat[4][.], :1915-1940) */
         /* (the match multiplier stays a + pb: against a target N no match bit is set) */
         const int pbA = tb[0] < 4 ? k.pb : k.pn, pbB = tb[1] < 4 ? k.pb : k.pn;

@@ -80,8 +80,15 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     __shared__ uint4 lds_m4[4][2][4][64];                           /* per-base match words 0..3: [wave][seed][base][lane] */
     __shared__ uint32_t lds_m1[4][2][4][64];                        /* per-base match word 4 */
     __shared__ uint32_t lds_wn[4][NC][64];                          /* N planes of both seeds, 16 columns per half */
+    __shared__ uint4 lds_k4[L::KEEP_NONE + 1];                      /* keep-mask table (match_words): words 0..3 / word 4 of entry b */
+    __shared__ uint32_t lds_k1[L::KEEP_NONE + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t w0 = (blockIdx.x * 4u + (uint32_t)wv) * 128u + (uint32_t)lane;
+    for (int b = (int)threadIdx.x; b <= L::KEEP_NONE; b += 256) {
+        lds_k4[b] = make_uint4(L::keep_word(b, 0), L::keep_word(b, 1), L::keep_word(b, 2), L::keep_word(b, 3));
+        lds_k1[b] = L::keep_word(b, 4);
+    }
+    __syncthreads();                                                /* the only barrier: the table is shared by the four waves */
 
     typename L::state S;
     uint32_t t_off[2], ti[2], nblk = 0, q2[2][NW];
@@ -146,6 +153,11 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         rm[0] = v.x; rm[1] = v.y; rm[2] = v.z; rm[3] = v.w;
         rm[4] = lds_m1[wv][x][b][lane];
     };
+    const auto kp = [&](int b, uint32_t (&kw)[NW]) {
+        const uint4 v = lds_k4[b];
+        kw[0] = v.x; kw[1] = v.y; kw[2] = v.z; kw[3] = v.w;
+        kw[4] = lds_k1[b];
+    };
     const auto wn = [&](int c) { return lds_wn[wv][c][lane]; };
     uint64_t tw[2] = {0ull, 0ull};
 
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         }
         u.nblk = nblk;
         L2_STAMP(1);
-        L::row_body(S, k, i, r, u, tb, qp, wn);
+        L::row_body(S, k, i, r, u, tb, qp, kp, wn);
         L2_STAMP(4);
     }
 

@@ -103,7 +103,10 @@ struct wave_model {
                     for (int wd = 0; wd < L::NW; ++wd) rm[wd] = L::base_match(a.qp[x][0][wd], a.qp[x][1][wd], a.qp[x][2][wd], b);
                 };
                 auto wn = [&](int c) { return a.wn[c]; };
-                L::row_body(a.S, k, i, rv[l], u, tb, qp, wn);
+                auto kp = [&](int b, uint32_t (&kw)[L::NW]) {
+                    for (int wd = 0; wd < L::NW; ++wd) kw[wd] = L::keep_word(b, wd);
+                };
+                L::row_body(a.S, k, i, rv[l], u, tb, qp, kp, wn);
             }
         }
         for (int l = 0; l < 64; ++l)
