@@ -30,13 +30,13 @@ def main():
             m = re.match(r"\s+([vs]_\S+)", l)
             if m: cur[1].append(m.group(1))
     valu = lambda ops: [o for o in ops if o.startswith("v_")]
-    # dense body = the most frequent big basic block (16 of the 17 column blocks share its size); the path through a dense
-    # block also runs the operand-extraction block in front of the variants (8 shifts of the match word: its signature) and
+    # dense body = the smallest of the frequent big basic blocks (16 of the 17 column blocks share its size); the path through a dense
+    # block also runs the operand-extraction block in front of the variants (the 8 match-bit extractions: its signature) and
     # the register-merge block behind them
     cnt = collections.Counter(len(valu(b[1])) for b in blocks if len(valu(b[1])) > 80)
-    nd = cnt.most_common(1)[0][0]
+    nd = min(sz for sz, c in cnt.items() if c >= 8)                      # four body variants per column block: the dense one is the smallest
     di = [k for k, b in enumerate(blocks) if len(valu(b[1])) == nd][3]
-    ext = max(k for k in range(di) if blocks[k][1].count("v_lshrrev_b32_e32") >= 7 and len(valu(blocks[k][1])) < 60)
+    ext = max(k for k in range(di) if (blocks[k][1].count("v_lshrrev_b32_e32") >= 7 or blocks[k][1].count("v_and_b32_e32") >= 7) and len(valu(blocks[k][1])) < 60)
     mrg = di + 1
     ops = blocks[ext][1] + blocks[di][1] + blocks[mrg][1]
     hist = collections.Counter(ops)

@@ -5,14 +5,17 @@ correction: FETCH_SIZE (KiB) x 2 + WRITE_SIZE (KiB), summed over the DP kernels 
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = sys.argv[1]
-workload, seeds, cells = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-allk = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), d, "bsw"]))
+workload, seeds, cells = sys.argv[2], int(sys.argv[3]), int(float(sys.argv[4]))
+if d.endswith(".json"):                  # a kept tools/pmc_summary.py output instead of the raw rocprofv3 directories
+    allk = json.load(open(d))
+else:
+    allk = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), d, "bsw"]))
 step = {k: v for k, v in allk.items() if any(x in k for x in ("lane2_kernel", "lane_kernel", "pair_finalize", "wave_kernel"))}
 fetch = sum(v.get("FETCH_SIZE", 0) for v in step.values())
 write = sum(v.get("WRITE_SIZE", 0) for v in step.values())
 main = max(step.items(), key=lambda kv: kv[1].get("avg_ns", 0))
 isa = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_histogram.py")]))
-out = {"workload": workload, "seeds_per_gpu": seeds, "source": os.path.basename(d.rstrip("/")),
+out = {"workload": workload, "seeds_per_gpu": seeds, "source": os.path.basename(os.path.dirname(d) if d.endswith(".json") else d.rstrip("/")),
        "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
        "traffic_kernels": {k[:40]: int((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) for k, v in step.items()},
        "dominant_kernel": main[0][:60], "dominant_kernel_avg_ms": round(main[1]["avg_ns"] / 1e6, 4),
