@@ -1235,7 +1235,7 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
     const size_t S = dev.slots.size();
     stage_t &st = dev.slots[s];
     hipStream_t stream = dev.streams[s];
-    struct { bool active = false; size_t n = 0; bsw_result *out = nullptr; bool direct = false; } pend;
+    struct { bool active = false; size_t n = 0; bsw_result *out = nullptr; bool direct = false, copied = false; } pend;
     auto bail = [&](int rc) {                       /* wake the slots waiting for their DMA turn; leave nothing in flight */
         abort_flag = 1;
         { std::lock_guard<std::mutex> lk(gate.mu); }
@@ -1248,7 +1248,14 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
     auto finish = [&]() -> int {                    /* the slot's chunk in flight: wait (watchdog), hand the results over */
         if (!pend.active) return BSW_OK;
         pend.active = false;
-        const int rc = sync_stream(ctx, e, stream, dev.events[s]);
+        int rc = BSW_OK;
+        if (!pend.copied) {                         /* kernels done -> result DMA -> done */
+            rc = wait_event(ctx, e, dev.events[s]);
+            if (rc) return rc;
+            const hipError_t ce = hipMemcpyAsync(pend.direct ? pend.out : st.h_out.p, st.d_out.p, pend.n * sizeof(bsw_result), hipMemcpyDeviceToHost, stream);
+            if (ce != hipSuccess) return fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(ce));
+        }
+        rc = sync_stream(ctx, e, stream, dev.events[s]);
         if (rc) return rc;
         if (!pend.direct) memcpy(pend.out, st.h_out.p, pend.n * sizeof(bsw_result));
         return BSW_OK;
@@ -1303,8 +1310,16 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         bsw_result *co = out + chunks[k].base;
         pend.direct = is_registered(co, n * sizeof(bsw_result));
         if (!pend.direct && (he = st.h_out.reserve(n)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
-        he = hipMemcpyAsync(pend.direct ? co : st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, stream);
+        /* A result copy queued behind its kernels sits at the head of its DMA engine's ring until they finish and holds up
+         * the copies queued to that engine after it (profiles/r2/wire_submit_timeline.txt).  With the reference on the
+         * device the input DMAs are short and that wait is what the pipeline loses (+7 % when the slot thread issues the
+         * result DMA itself once the kernels are done); with 448 B per seed of input the link is busy anyway and the
+         * extra host round trip per chunk costs more than it saves (-6 %), so there the copy is queued right away. */
+        const bool late = rtasks != nullptr;
+        if (!late) he = hipMemcpyAsync(pend.direct ? co : st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, stream);
+        else he = hipEventRecord(dev.events[s], stream);
         if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(he)));
+        pend.copied = !late;
         pend.active = true; pend.n = n; pend.out = co;
         if (dbg) { const double t4 = tnow(); t_staging += t1 - t0; t_host += t2 - t1; t_finish += t3 - t2; t_stage += t4 - t3; }
     }
