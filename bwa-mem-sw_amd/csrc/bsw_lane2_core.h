@@ -409,8 +409,7 @@ struct lane2 {
             uint32_t fnzu = 0xffffffffu;
             int lnz = -1;
             sfor<NW>([&](auto wi) {
-                constexpr int wd = decltype(wi)::value;
-                if (32 * wd + 32 <= u.jlo || 32 * wd > u.jhi) return;
+                constexpr int wd = decltype(wi)::value;           /* (every word: six straight-line ops beat a skip branch and its register joins) */
                 constexpr int chi = 2 * wd + 1 < NC ? 2 * wd + 1 : 2 * wd;
                 const uint32_t lo = nzc[2 * wd], hic = 2 * wd + 1 < NC ? nzc[chi] : 0u;
                 const uint32_t word = half_pair<x>(lo, hic);
