@@ -75,6 +75,7 @@ L2_FN uint32_t key_of(uint32_t h, uint32_t jj) { uint32_t d; asm("v_lshl_or_b32 
 /* index of the lowest / highest set bit; 0xffffffff for x == 0 (what the hardware returns) */
 L2_FN uint32_t ffbl(uint32_t x) { uint32_t d; asm("v_ffbl_b32 %0, %1" : "=v"(d) : "v"(x)); return d; }
 L2_FN uint32_t ffbh(uint32_t x) { uint32_t d; asm("v_ffbh_u32 %0, %1" : "=v"(d) : "v"(x)); return d; }   /* counted from the MSB */
+L2_FN int mul24(int a, int b) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }   /* both factors fit 24 bits: one full-rate op, not a 64-bit mad */
 /* a wave-uniform value the compiler must re-read here: keeps tests on it from being hoisted out of the row loop */
 L2_FN uint32_t opaque_s(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
 #else
@@ -103,6 +104,7 @@ L2_FN uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & 
 L2_FN uint32_t key_of(uint32_t h, uint32_t jj) { return (h << 8) | jj; }
 L2_FN uint32_t ffbl(uint32_t x) { return x ? (uint32_t)__builtin_ctz(x) : 0xffffffffu; }
 L2_FN uint32_t ffbh(uint32_t x) { return x ? (uint32_t)__builtin_clz(x) : 0xffffffffu; }
+L2_FN int mul24(int a, int b) { return a * b; }
 L2_FN uint32_t opaque_s(uint32_t x) { return x; }
 #endif
 
@@ -388,21 +390,21 @@ struct lane2 {
             constexpr int sh = 16 * x;
             const int h1x = (int)((h1 >> (sh + 8)) & 0xffu);
             const int mk = (int)((mk2 >> sh) & 0xffffu);     /* (m << 8) | mj; m == 0: no positive cell */
-            if (imax(s.beg, s.end) == s.qlen) {              /* ties -> later i (:1829-1833) */
-                s.max_ie = s.gscore > h1x ? s.max_ie : i;
-                s.gscore = imax(s.gscore, h1x);
-            }
+            /* K7, branch-free: a data-dependent if/else here costs an exec-mask region plus register copies of the seed
+             * state on both sides; selects do not.  lane2_params_ok guarantees e_del == e_ins. */
+            const bool atq = imax(s.beg, s.end) == s.qlen;   /* ties -> later i (:1829-1833) */
+            s.max_ie = (atq && h1x >= s.gscore) ? i : s.max_ie;
+            s.gscore = atq ? imax(s.gscore, h1x) : s.gscore;
             const int m = mk >> 8, mj = mk & 255;
-            bool stop = m == 0;                              /* (:1942) */
-            if (m > s.mx) {
-                s.mx = m; s.max_i = i; s.max_j = mj;
-                const int off = mj > i ? mj - i : i - mj;
-                s.max_off = imax(s.max_off, off);
-            } else if (k.zdrop > 0) {
-                const int di = i - s.max_i, dj = mj - s.max_j;
-                const int pen = di > dj ? (di - dj) * k.e_del : (dj - di) * k.e_ins;
-                stop = stop || (s.mx - m - pen > k.zdrop);
-            }
+            const bool gt = m > s.mx;
+            const int doff = mj - i, off = imax(doff, -doff);
+            const int dd = (i - s.max_i) - (mj - s.max_j), ad = imax(dd, -dd);   /* |di - dj| against the OLD maximum */
+            const bool zstop = !gt && k.zdrop > 0 && s.mx - m - mul24(ad, k.e_del) > k.zdrop;
+            const bool stop = m == 0 || zstop;               /* (:1942) */
+            s.max_off = gt ? imax(s.max_off, off) : s.max_off;
+            s.max_i = gt ? i : s.max_i;
+            s.max_j = gt ? mj : s.max_j;
+            s.mx = imax(s.mx, m);
             /* K8 next-row range (CPU semantics): first / last non-zero eh entry in [beg, end] from the bit masks */
             /* an empty word gives 0xffffffff from both bit searches: never the unsigned minimum, and negative after
              * `^ 31 | 32 wd`, never the signed maximum — no compare, no select */
