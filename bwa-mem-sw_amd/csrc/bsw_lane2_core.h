@@ -385,26 +385,28 @@ struct lane2 {
         /* ---- row tail per seed (K7, K8) ---- */
         sfor<2>([&](auto xi) {
             constexpr int x = decltype(xi)::value;
-            if (!r.act[x]) return;
+            /* computed for every seed and committed by selects on `act`: a branch around it would copy the seed state
+             * into fresh registers on one side and back on the other */
+            const bool act = r.act[x];
             seedv &s = S.s[x];
             constexpr int sh = 16 * x;
             const int h1x = (int)((h1 >> (sh + 8)) & 0xffu);
             const int mk = (int)((mk2 >> sh) & 0xffffu);     /* (m << 8) | mj; m == 0: no positive cell */
             /* K7, branch-free: a data-dependent if/else here costs an exec-mask region plus register copies of the seed
              * state on both sides; selects do not.  lane2_params_ok guarantees e_del == e_ins. */
-            const bool atq = imax(s.beg, s.end) == s.qlen;   /* ties -> later i (:1829-1833) */
-            s.max_ie = (atq && h1x >= s.gscore) ? i : s.max_ie;
+            const bool atq = act & (imax(s.beg, s.end) == s.qlen);   /* ties -> later i (:1829-1833) */
+            s.max_ie = (atq & (h1x >= s.gscore)) ? i : s.max_ie;
             s.gscore = atq ? imax(s.gscore, h1x) : s.gscore;
             const int m = mk >> 8, mj = mk & 255;
-            const bool gt = m > s.mx;
+            const bool gt = act & (m > s.mx);
             const int doff = mj - i, off = imax(doff, -doff);
             const int dd = (i - s.max_i) - (mj - s.max_j), ad = imax(dd, -dd);   /* |di - dj| against the OLD maximum */
-            const bool zstop = !gt && k.zdrop > 0 && s.mx - m - mul24(ad, k.e_del) > k.zdrop;
-            const bool stop = m == 0 || zstop;               /* (:1942) */
+            const bool zstop = (!gt) & (k.zdrop > 0) & (s.mx - m - mul24(ad, k.e_del) > k.zdrop);
+            const bool stop = (m == 0) | zstop;              /* (:1942) */
             s.max_off = gt ? imax(s.max_off, off) : s.max_off;
             s.max_i = gt ? i : s.max_i;
             s.max_j = gt ? mj : s.max_j;
-            s.mx = imax(s.mx, m);
+            s.mx = gt ? m : s.mx;
             /* K8 next-row range (CPU semantics): first / last non-zero eh entry in [beg, end] from the bit masks */
             /* an empty word gives 0xffffffff from both bit searches: never the unsigned minimum, and negative after
              * `^ 31 | 32 wd`, never the signed maximum — no compare, no select */
@@ -423,9 +425,9 @@ struct lane2 {
             const int fnz = fnzu < (uint32_t)s.end ? (int)fnzu : s.end;
             const int nbeg = fnz;
             const int last = lnz >= nbeg ? lnz : nbeg - 1;
-            s.beg = nbeg;
-            s.end = imin(last + 2, s.qlen);
-            s.alive = !stop;
+            s.beg = act ? nbeg : s.beg;
+            s.end = act ? imin(last + 2, s.qlen) : s.end;
+            s.alive = act ? !stop : s.alive;
         });
     }
 };
