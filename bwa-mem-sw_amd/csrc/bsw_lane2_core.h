@@ -349,22 +349,27 @@ struct lane2 {
             uint32_t mkb = 0, nz8 = 0;                        /* this block's row-max key and non-zero bits */
             /* nested scalar branches (a combined condition would be materialised as lane masks for all 17 blocks
              * before the loop and spill) */
-            if (b < bem) {                                    /* j0 + 8 <= jem: inside every active seed's range */
-                uint32_t dummy = 0;
-                if (!(nblk & (1u << b))) {
-                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
-                } else {
-                    const uint32_t WNc = wn(c);
-                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
-                }
-            } else {
+            /* four mutually exclusive bodies as four consecutive `if`s, not an if/else tree: a body that is simply run or
+             * skipped updates eh[j] in place, an if/else joins differently allocated versions with a v_mov per column */
+            const bool dense = b < bem;                       /* j0 + 8 <= jem: inside every active seed's range */
+            const bool nq = (nblk & (1u << b)) != 0;
+            uint32_t dummy = 0;
+            if (dense && !nq) {
+                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
+            }
+            if (dense && nq) {
+                const uint32_t WNc = wn(c);
+                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
+            }
+            if (!dense) {
                 /* mi of column j0 - 1 */
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
                 uint32_t mi_prev = pk_nzmask(d0);
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
-                if (!(nblk & (1u << b))) {
+                if (!nq) {
                     sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
-                } else {
+                }
+                if (nq) {
                     const uint32_t WNc = wn(c);
                     sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
                 }
