@@ -361,18 +361,18 @@ struct lane2 {
                 const uint32_t WNc = wn(c);
                 sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
             }
-            if (!dense) {
-                /* mi of column j0 - 1 */
-                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
+            if (!dense && !nq) {
+                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));     /* mi of column j0 - 1 */
                 uint32_t mi_prev = pk_nzmask(d0);
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
-                if (!nq) {
-                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
-                }
-                if (nq) {
-                    const uint32_t WNc = wn(c);
-                    sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
-                }
+                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
+            }
+            if (!dense && nq) {
+                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
+                uint32_t mi_prev = pk_nzmask(d0);
+                const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));
+                const uint32_t WNc = wn(c);
+                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
             }
             /* fold the block into its 64-column group / 16-column chunk (column offsets only touch the low key bits) */
             mkg[g] = pk_max(mkg[g], mkb + (uint32_t)(j0 & 63) * 0x00010001u);
