@@ -37,15 +37,16 @@ def main():
     nd = min(sz for sz, c in cnt.items() if c >= 8)                      # four body variants per column block: the dense one is the smallest
     di = [k for k, b in enumerate(blocks) if len(valu(b[1])) == nd][3]
     ext = max(k for k in range(di) if (blocks[k][1].count("v_lshrrev_b32_e32") >= 7 or blocks[k][1].count("v_and_b32_e32") >= 7) and len(valu(blocks[k][1])) < 60)
-    mrg = di + 1
-    ops = blocks[ext][1] + blocks[di][1] + blocks[mrg][1]
+    mrg = di + 1                                                        # a register-merge block behind the variants, if the compiler made one
+    has_mrg = blocks[mrg][1].count("v_mov_b32_e32") >= 5 and len(valu(blocks[mrg][1])) < 30
+    ops = blocks[ext][1] + blocks[di][1] + (blocks[mrg][1] if has_mrg else [])
     hist = collections.Counter(ops)
     v = valu(ops)
     cyc = sum(2 if o in FAST else 4 for o in v)
     pair_cells = 8
     cells_per_cycle_per_simd = 2 * 64 * pair_cells / cyc                 # two seeds per lane
     peak_gcups = cells_per_cycle_per_simd * 1024 * 2.4
-    res = {"kernel": "bsw_lane2_kernel<17,2>", "dense_path_valu_insts": len(v), "of_which_extraction_block": len(valu(blocks[ext][1])), "of_which_merge_block": len(valu(blocks[mrg][1])), "valu_insts_per_pair_cell": round(len(v) / pair_cells, 2),
+    res = {"kernel": "bsw_lane2_kernel<17,2>", "dense_path_valu_insts": len(v), "of_which_extraction_block": len(valu(blocks[ext][1])), "of_which_merge_block": len(valu(blocks[mrg][1])) if has_mrg else 0, "valu_insts_per_pair_cell": round(len(v) / pair_cells, 2),
            "full_rate_insts": sum(1 for o in v if o in FAST), "half_rate_insts": sum(1 for o in v if o not in FAST),
            "s_nop": hist.get("s_nop", 0), "salu_other": sum(c for o, c in hist.items() if o.startswith("s_") and o != "s_nop"),
            "nominal_cycles_per_block": cyc, "peak_gcups_dense_body_back_to_back": round(peak_gcups, 1),
