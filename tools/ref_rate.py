@@ -29,3 +29,24 @@ for streams, chunk in ((4, 131072), (4, 65536), (3, 131072), (6, 131072), (4, 26
         dt = float(np.median(runs))
         ctx.ref_free(ref)
     print(json.dumps(dict(streams=streams, chunk_tasks=chunk, seconds=round(dt, 5), seeds_per_s=round(n / dt), gcups=round(cells_of(obuf) / dt / 1e9, 1))), flush=True)
+
+# steady state: a stream of 1M-seed batches, two in flight through two contexts (each with its own copy of the reference)
+ho2 = host.HostArena(n * host.RESULT.itemsize)
+obuf2 = ho2.view(host.RESULT, n)
+for streams, chunk in ((2, 131072), (2, 262144), (3, 131072), (4, 131072)):
+    a = host.BswContext(device=0, streams=streams, chunk_tasks=chunk)
+    b = host.BswContext(device=0, streams=streams, chunk_tasks=chunk)
+    ra, rb = a.ref_upload(pac, lp), b.ref_upload(pac, lp)
+    a.submit_ref(p, ra, rt, out=obuf); a.wait(); b.submit_ref(p, rb, rt, out=obuf2); b.wait()
+    reps = 8
+    t0 = time.perf_counter()
+    a.submit_ref(p, ra, rt, out=obuf); b.submit_ref(p, rb, rt, out=obuf2)
+    for _ in range(reps - 1):
+        a.wait(); a.submit_ref(p, ra, rt, out=obuf)
+        b.wait(); b.submit_ref(p, rb, rt, out=obuf2)
+    a.wait(); b.wait()
+    dt = (time.perf_counter() - t0) / (2 * reps)
+    print(json.dumps(dict(mode="stream of submits, two in flight", streams_per_ctx=streams, slot_threads=2 * streams, chunk_tasks=chunk,
+                          seconds_per_batch=round(dt, 5), seeds_per_s=round(n / dt), gcups=round(cells_of(obuf) / dt / 1e9, 1),
+                          identical=bool(obuf.tobytes() == obuf2.tobytes()))), flush=True)
+    a.ref_free(ra); b.ref_free(rb); a.close(); b.close()
