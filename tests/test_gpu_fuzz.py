@@ -32,3 +32,30 @@ def test_fuzz_parameters_and_shapes(host, oracle, block):
             want = oracle.pair_batch(p, tasks, nthreads=8)
             assert_same(lctx.extend_pairs(p, tasks), want, tasks)
             assert_same(wctx.extend_pairs(p, tasks), want, tasks)
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_fuzz_two_seeds_per_lane_kernel(host, oracle, block):
+    """The packed kernel's own parameter space (variant H, symmetric gaps, 0 >= N score >= -b): random scoring, band,
+    z-drop, clip penalties and seed shapes on both sides of its 8-bit score bound, forced lane bins."""
+    rng = np.random.default_rng(12000 + block)
+    with host.BswContext(device=0, kernel=host.KERNEL_LANE) as lctx:
+        for it in range(5):
+            a = int(rng.integers(1, 5))
+            b = int(rng.integers(0, 9))
+            nsc = -int(rng.integers(0, b + 1))
+            o, e = int(rng.integers(0, 16)), int(rng.integers(1, 7))
+            over = dict(o_del=o, e_del=e, o_ins=o, e_ins=e, w=int(rng.choice([1, 2, 7, 20, 100, 300])),
+                        zdrop=int(rng.choice([0, 1, 10, 50, 100, 1000])), pen_clip5=int(rng.integers(0, 15)),
+                        pen_clip3=int(rng.integers(0, 15)), max_band_try=int(rng.integers(1, 4)), variant=0)
+            p = host.default_params(**over)
+            p["mat"][0] = host.bwa_matrix(a=a, b=b, n=nsc)
+            seeds = _gen.random_seeds(rng, 1500, qmin=1, qmax=int(rng.choice([12, 60, 134])), tfac=float(rng.choice([1.0, 1.6, 2.4])),
+                                      sub=float(rng.choice([0.0, 0.02, 0.08])), indel=float(rng.choice([0.0, 0.01, 0.05])),
+                                      junk=float(rng.choice([0.0, 0.2])), nrate=float(rng.choice([0.0, 0.002, 0.04])), h0max=60)
+            for s in seeds:                                  # scores up to, at and beyond the class bound h0 + qlen*a + b = 255
+                tot = (len(s.get("lq", ())) + len(s.get("rq", ()))) * a
+                s["h0"] = max(1, min(s["h0"] + int(rng.integers(0, 200)), 255 - b - tot + int(rng.integers(-3, 4))))
+            tasks, arena = host.make_tasks(seeds)
+            want = oracle.pair_batch(p, tasks, nthreads=8)
+            assert_same(lctx.extend_pairs(p, tasks), want, tasks)
