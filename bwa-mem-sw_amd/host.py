@@ -35,6 +35,9 @@ ALNREG = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), (
                    ("w", "<i4"), ("_pad", "<i4")])
 GTASK = np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("_pad", "<i4")])
 GRESULT = np.dtype([("score", "<i4"), ("n_cigar", "<i4")])
+ATASK = np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("xtra", "<i4"), ("_pad", "<i4")])
+KSWR = np.dtype([("score", "<i4"), ("te", "<i4"), ("qe", "<i4"), ("score2", "<i4"), ("te2", "<i4"), ("tb", "<i4"), ("qb", "<i4")])
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
 REF_TASK = np.dtype([("query", "<u8"), ("l_query", "<i4"), ("init_score", "<i4"), ("seed", SEED),
                      ("rmax0", "<i8"), ("rmax1", "<i8"), ("tag", "<u4"), ("_pad", "<u4")])
 MAX_DEVICES = 16

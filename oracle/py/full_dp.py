@@ -92,3 +92,37 @@ def _M(H, E, F, i, j, mat, t, q):
     if i == 0 or j == 0:
         return NEG          # a border cell ends with a gap, not with a match
     return H[i - 1][j - 1] + mat[t[i - 1]][q[j - 1]]
+
+
+def local_dp(query, target, mat, o_del, e_del, o_ins, e_ins, m=5):
+    """Textbook Gotoh LOCAL alignment (second opinion for ksw_align): whole matrices, row-vectorised in numpy.
+    E (gap along the target, "deletion") and F (gap along the query, "insertion") may follow each other freely —
+    bwa's striped code forbids an insertion directly followed by a deletion, so its score is <= this one and equal
+    whenever no optimal alignment needs that.  Returns dict(score, ends=set of (te, qe) reaching the score)."""
+    q = np.asarray(query, dtype=np.int64)
+    t = np.asarray(target, dtype=np.int64)
+    mat = np.asarray(mat, dtype=np.int64).reshape(m, m)
+    ql, tl = len(q), len(t)
+    oe_del, oe_ins = o_del + e_del, o_ins + e_ins
+    Hp = np.zeros(ql + 1, dtype=np.int64)
+    E = np.zeros(ql + 1, dtype=np.int64)
+    best, ends = 0, set()
+    for i in range(tl):
+        s = mat[t[i]][q] if ql else np.zeros(0, dtype=np.int64)
+        M = np.maximum(Hp[:-1] + s, 0)
+        M = np.maximum(M, E[1:])
+        H = np.zeros(ql + 1, dtype=np.int64)
+        f = 0
+        for j in range(ql):                                  # F runs along the query inside the row
+            h = max(M[j], f)
+            H[j + 1] = h
+            f = max(f - e_ins, h - oe_ins, 0)
+        E[1:] = np.maximum(np.maximum(E[1:] - e_del, H[1:] - oe_del), 0)
+        mrow = int(H.max()) if ql else 0
+        if mrow > best:
+            best, ends = mrow, set()
+        if mrow == best and best > 0:
+            for j in np.nonzero(H[1:] == best)[0]:
+                ends.add((i, int(j)))
+        Hp = H
+    return dict(score=int(best), ends=ends)

@@ -45,6 +45,12 @@ def lib():
         L.ksw_global2_ref.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, I32P, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint64)]
         L.ksw_global2_ref.restype = C.c_int
+        L.ksw_align2_ref.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.ksw_align2_ref.restype = None
+        L.ksw_align2_batch_ref.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.ksw_align2_batch_ref.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -106,3 +112,36 @@ def global2(query, target, mat, o_del, e_del, o_ins, e_ins, w, want_cigar=True, 
     if want_cigar and cig:
         _libc.free(cig)
     return dict(score=score, cigar=ops, cells=cells.value)
+
+
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
+ALIGN_FIELDS = ("score", "te", "qe", "score2", "te2", "tb", "qb")
+
+
+def align2(query, target, mat, o_del, e_del, o_ins, e_ins, xtra, m=5):
+    """bwa ksw_align2 on the oracle (literal emulation of the striped SSE2 code).  Returns dict(score, te, qe, score2,
+    te2, tb, qb, cells)."""
+    q, qp = _u8(query)
+    t, tp = _u8(target)
+    mt = np.ascontiguousarray(mat, dtype=np.int8)
+    out = np.zeros(7, dtype=np.int32)
+    cells = C.c_uint64(0)
+    lib().ksw_align2_ref(len(q), qp, len(t), tp, m, mt.ctypes.data, o_del, e_del, o_ins, e_ins, xtra, out.ctypes.data, C.byref(cells))
+    d = {k: int(v) for k, v in zip(ALIGN_FIELDS, out)}
+    d["cells"] = cells.value
+    return d
+
+
+def align2_batch(mat, o_del, e_del, o_ins, e_ins, atasks, nthreads=1):
+    """atasks: structured array with query/target pointers, qlen, tlen, xtra (host.ATASK).  Returns (int32[n][7], cells)."""
+    mt = np.ascontiguousarray(mat, dtype=np.int8)
+    n = len(atasks)
+    out = np.zeros((n, 7), dtype=np.int32)
+    qptr = np.ascontiguousarray(atasks["query"], dtype=np.uint64)
+    tptr = np.ascontiguousarray(atasks["target"], dtype=np.uint64)
+    ql = np.ascontiguousarray(atasks["qlen"], dtype=np.int32)
+    tl = np.ascontiguousarray(atasks["tlen"], dtype=np.int32)
+    xt = np.ascontiguousarray(atasks["xtra"], dtype=np.int32)
+    cells = lib().ksw_align2_batch_ref(mt.ctypes.data, o_del, e_del, o_ins, e_ins, qptr.ctypes.data, tptr.ctypes.data, ql.ctypes.data,
+                                       tl.ctypes.data, xt.ctypes.data, n, out.ctypes.data, nthreads)
+    return out, int(cells)
