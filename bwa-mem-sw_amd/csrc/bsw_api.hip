@@ -190,6 +190,9 @@ struct bsw_ctx {
     dbuf<uint8_t> g_z;
     dbuf<uint32_t> g_cig, g_order;
     dbuf<bsw_gresult> g_res;
+    dbuf<bsw_adtask> a_tasks;         /* local alignment (bsw_align_batch) */
+    dbuf<unsigned long long> a_bl;
+    dbuf<bsw_kswr> a_res;
     std::vector<refbatch_req> ref_queue;
     int device0() const { return devs[0].device; }
     hipStream_t stream0() const { return devs[0].streams[0]; }
@@ -357,6 +360,7 @@ static void ctx_release(bsw_ctx *ctx)
         for (auto &pr : ctx->hist) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         ctx->small.release();
         ctx->g_tasks.release(); ctx->g_z.release(); ctx->g_cig.release(); ctx->g_order.release(); ctx->g_res.release();
+        ctx->a_tasks.release(); ctx->a_bl.release(); ctx->a_res.release();
     }
     delete ctx;
 }
@@ -2055,4 +2059,174 @@ extern "C" int ksw_global(int qlen, const uint8_t *query, int tlen, const uint8_
                           int gapo, int gape, int w, int *n_cigar_, uint32_t **cigar_)
 {
     return ksw_global2(qlen, query, tlen, target, m, mat, gapo, gape, gapo, gape, w, n_cigar_, cigar_);
+}
+
+/* ---- local alignment with start / second-best search (bwa ksw_align2, mate rescue) -----------
+ * Host side as for the global alignment: the byte-per-base sequences travel and are packed like extension tasks
+ * (registered arenas DMA'd as they are), every alignment gets its slice of the sub-optimal list scratch, tasks are
+ * sorted by kernel class (mode x vectors per lane), bsw_align_kernel runs per class. */
+static int align_chunk(bsw_ctx *ctx, errs &e, const bsw_dparams &dp, const bsw_atask *tasks, size_t n, bsw_kswr *out)
+{
+    stage_t &st = ctx->small;
+    hipStream_t s = ctx->stream0();
+    hipError_t he;
+    if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess)
+        return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    std::vector<bsw_adtask> at(n);
+    const int ncls = bsw::align_class_count();
+    std::vector<uint32_t> order(n), cnt((size_t)ncls + 1, 0), cls(n);
+    uint64_t acc = 0, accb = 0, bacc = 0;
+    const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_atask &t = tasks[i];
+        bsw_dtask &d = st.h_tasks.p[i];
+        bsw_rawoff &r = st.h_roff.p[i];
+        memset(&d, 0, sizeof(d));
+        memset(&r, 0, sizeof(r));
+        d.rq_off = (uint32_t)acc; acc += nwords(t.qlen);
+        d.rt_off = (uint32_t)acc; acc += nwords(t.tlen);
+        d.rqlen = (uint16_t)t.qlen; d.rtlen = (uint16_t)t.tlen;
+        r.rq = (uint32_t)accb; accb += (uint64_t)t.qlen;
+        r.rt = (uint32_t)accb; accb += (uint64_t)t.tlen;
+        if (t.qlen) { if (t.query < lo) lo = t.query; if (t.query + t.qlen > hi) hi = t.query + t.qlen; }
+        if (t.tlen) { if (t.target < lo) lo = t.target; if (t.target + t.tlen > hi) hi = t.target + t.tlen; }
+        bsw_adtask &a = at[i];
+        a.q_off = d.rq_off; a.t_off = d.rt_off; a.qlen = t.qlen; a.tlen = t.tlen; a.xtra = t.xtra; a.pad = 0; a.b_off = bacc;
+        if (t.xtra & KSW_XSUBO) bacc += (uint64_t)t.tlen;
+        const int c = bsw::align_class_of(t.qlen, (t.xtra & KSW_XBYTE) != 0);
+        cls[i] = (uint32_t)c;
+        ++cnt[(size_t)c + 1];
+    }
+    for (int c = 0; c < ncls; ++c) cnt[(size_t)c + 1] += cnt[(size_t)c];
+    {
+        std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
+        for (size_t i = 0; i < n; ++i) order[pos[cls[i]]++] = (uint32_t)i;
+    }
+    const size_t spanb = hi ? (size_t)(hi - lo) : 0;
+    const bool direct = spanb > 0 && spanb < (1ull << 32) - RAW_SLACK && spanb <= 2 * accb + (1u << 20) && is_registered(lo, spanb);
+    if (direct) {
+        for (size_t i = 0; i < n; ++i) {
+            bsw_rawoff &r = st.h_roff.p[i];
+            r.rq = tasks[i].qlen ? (uint32_t)(tasks[i].query - lo) : 0;
+            r.rt = tasks[i].tlen ? (uint32_t)(tasks[i].target - lo) : 0;
+        }
+    } else {
+        if ((he = st.h_raw.reserve((size_t)accb + RAW_SLACK)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+        for (size_t i = 0; i < n; ++i) {
+            if (tasks[i].qlen) memcpy(st.h_raw.p + st.h_roff.p[i].rq, tasks[i].query, (size_t)tasks[i].qlen);
+            if (tasks[i].tlen) memcpy(st.h_raw.p + st.h_roff.p[i].rt, tasks[i].target, (size_t)tasks[i].tlen);
+        }
+    }
+    const size_t rawb = direct ? spanb : (size_t)accb;
+    if ((he = st.d_raw.reserve(rawb + RAW_FRONT + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve((size_t)acc + 4)) != hipSuccess ||
+        (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_roff.reserve(n + 1)) != hipSuccess ||
+        (he = ctx->a_tasks.reserve(n + 1)) != hipSuccess || (he = ctx->g_order.reserve(n + 1)) != hipSuccess ||
+        (he = ctx->a_res.reserve(n + 1)) != hipSuccess || (he = ctx->a_bl.reserve((size_t)bacc + 64)) != hipSuccess)
+        return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    if (rawb) HIPCHK(e, hipMemcpyAsync(st.d_raw.p + RAW_FRONT, direct ? lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(ctx->a_tasks.p, at.data(), n * sizeof(bsw_adtask), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(ctx->g_order.p, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, 0u, (uint32_t)n, 0, nullptr, 0, nullptr, st.d_seq.p, s));
+    for (int c = 0; c < ncls; ++c) {
+        const uint32_t k = cnt[(size_t)c + 1] - cnt[(size_t)c];
+        if (!k) continue;
+        HIPCHK(e, bsw::launch_align(c, dp, st.d_seq.p, ctx->a_tasks.p, ctx->g_order.p + cnt[(size_t)c], k, ctx->a_bl.p, ctx->a_res.p, s));
+    }
+    int rc = sync_stream(ctx, e, s, ctx->devs[0].events[0]);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpy(out, ctx->a_res.p, n * sizeof(bsw_kswr), hipMemcpyDeviceToHost));
+    return BSW_OK;
+}
+
+extern "C" int bsw_align_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_atask *tasks, size_t n, bsw_kswr *out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!p || (!tasks && n) || (!out && n)) return fail(e, BSW_E_INVAL, "bsw_align_batch: NULL argument");
+    int rc = busy_check(ctx, "bsw_align_batch");
+    if (rc) return rc;
+    bsw_params pp = *p;
+    pp.w = 0; pp.variant = BSW_VARIANT_H;
+    bsw_dparams dp;
+    rc = check_params(e, &pp, &dp);
+    if (rc) return rc;
+    int mxs = 0;
+    for (int i = 0; i < 25; ++i) mxs = std::max(mxs, (int)p->mat[i]);
+    if (mxs <= 0) return fail(e, BSW_E_INVAL, "bsw_align_batch: the scoring matrix has no positive score");
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_atask &t = tasks[i];
+        if (t.qlen < 0 || t.tlen < 0) return fail(e, BSW_E_INVAL, "align task %zu: negative length", i);
+        if (t.qlen > BSW_ALIGN_MAX_QLEN || t.tlen > BSW_MAX_TLEN) return fail(e, BSW_E_LIMIT, "align task %zu: beyond BSW_ALIGN_MAX_QLEN/BSW_MAX_TLEN", i);
+        if ((t.qlen && !t.query) || (t.tlen && !t.target)) return fail(e, BSW_E_INVAL, "align task %zu: NULL sequence pointer", i);
+        if (t.xtra & ~(0xffff | KSW_XBYTE | KSW_XSTOP | KSW_XSUBO | KSW_XSTART)) return fail(e, BSW_E_INVAL, "align task %zu: unknown xtra flag", i);
+    }
+    HIPCHK(e, hipSetDevice(ctx->device0()));
+    for (size_t a = 0; a < n;) {                      /* sub-batches: bounded sequence arena and sub-optimal list scratch */
+        size_t b = a;
+        uint64_t sb = 0, bb = 0;
+        while (b < n && b - a < (1u << 20)) {
+            const bsw_atask &t = tasks[b];
+            if (b > a && (sb + (uint64_t)(t.qlen + t.tlen) > (1ull << 31) || bb + (uint64_t)t.tlen > (1ull << 28))) break;
+            sb += (uint64_t)(t.qlen + t.tlen);
+            bb += (t.xtra & KSW_XSUBO) ? (uint64_t)t.tlen : 0;
+            ++b;
+        }
+        rc = align_chunk(ctx, e, dp, tasks + a, b - a, out + a);
+        if (rc) return rc;
+        a = b;
+    }
+    return BSW_OK;
+}
+
+static kswr_t align_scalar(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                           int o_del, int e_del, int o_ins, int e_ins, int xtra)
+{
+    kswr_t r = {0, -1, -1, -1, -1, -1, -1};
+    if (m != 5 || !mat || (qlen > 0 && !query) || (tlen > 0 && !target) || qlen < 0 || tlen < 0) {
+        fprintf(stderr, "ksw_align2(libbwasw_mi355): unsupported arguments (m must be 5)\n");
+        r.score = -1;
+        return r;
+    }
+    std::unique_lock<std::mutex> lk(g_mu);
+    while (g_leader) g_cv.wait(lk);                   /* share the scalar context with the ksw_extend2 round trips */
+    g_leader = true;
+    lk.unlock();
+    r.score = -1;
+    {
+        std::vector<scalar_req *> none;
+        if (!g_ctx && !g_ctx_rc) scalar_round_trip(none);          /* creates the context */
+        if (g_ctx) {
+            bsw_params p;
+            bsw_default_params(&p);
+            memcpy(p.mat, mat, 25);
+            p.o_del = o_del; p.e_del = e_del; p.o_ins = o_ins; p.e_ins = e_ins;
+            bsw_atask t;
+            memset(&t, 0, sizeof(t));
+            t.query = query; t.target = target; t.qlen = qlen; t.tlen = tlen; t.xtra = xtra;
+            bsw_kswr o;
+            const int rc = bsw_align_batch(g_ctx, &p, &t, 1, &o);
+            if (rc) fprintf(stderr, "ksw_align2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
+            else { r.score = o.score; r.te = o.te; r.qe = o.qe; r.score2 = o.score2; r.te2 = o.te2; r.tb = o.tb; r.qb = o.qb; }
+        }
+    }
+    lk.lock();
+    g_leader = false;
+    g_cv.notify_all();
+    return r;
+}
+
+extern "C" kswr_t ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat,
+                             int o_del, int e_del, int o_ins, int e_ins, int xtra, void **qry)
+{
+    (void)qry;
+    return align_scalar(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, xtra);
+}
+
+extern "C" kswr_t ksw_align(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat,
+                            int gapo, int gape, int xtra, void **qry)
+{
+    (void)qry;
+    return align_scalar(qlen, query, tlen, target, m, mat, gapo, gape, gapo, gape, xtra);
 }

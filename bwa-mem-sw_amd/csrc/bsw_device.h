@@ -62,6 +62,14 @@ typedef struct bsw_gdtask {
     uint64_t z_off;           /* byte offset of this alignment's backtrack matrix */
 } bsw_gdtask;
 
+/* one local alignment (bsw_align_kernel.hip; SURVEY.md §8f F4: bwa ksw_align2) */
+typedef struct bsw_adtask {
+    uint32_t q_off, t_off;    /* word offsets into seq */
+    int32_t  qlen, tlen, xtra;
+    uint32_t pad;
+    uint64_t b_off;           /* first entry of this alignment's slice of the sub-optimal list scratch */
+} bsw_adtask;
+
 #define BSW_KEY_BITS 10                        /* column index bits in the arg-max key */
 
 /* ---- binning: which kernel class a seed goes to.  The host counts seeds per class with these

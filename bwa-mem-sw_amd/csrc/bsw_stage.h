@@ -38,6 +38,10 @@ int global_class_count();
 int global_class_cols(int cls);
 hipError_t launch_global(int cls, const bsw_dparams &P, const uint64_t *seq, const bsw_gdtask *tasks, const uint32_t *order, uint32_t n,
                          uint8_t *z, uint32_t *cigars, int max_cigar, bsw_gresult *out, hipStream_t s);
+int align_class_count();
+int align_class_of(int qlen, int byte_mode);                 /* -1: query too long for the mode */
+hipError_t launch_align(int cls, const bsw_dparams &P, const uint64_t *seq, const bsw_adtask *tasks, const uint32_t *order, uint32_t n,
+                        unsigned long long *blist, bsw_kswr *out, hipStream_t s);
 hipError_t launch_bin(const bsw_binparams &bp, const bsw_dtask *tasks, uint32_t n, uint32_t *bins, uint32_t *order, hipStream_t s);
 }  // namespace bsw
 

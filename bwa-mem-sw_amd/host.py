@@ -45,6 +45,7 @@ CONFIG = np.dtype([("device", "<i4"), ("kernel", "<i4"), ("streams", "<i4"), ("p
                    ("chunk_tasks", "<u8"), ("n_devices", "<i4"), ("devices", "<i4", (MAX_DEVICES,)),
                    ("timeout_ms", "<i4")])
 assert PARAMS.itemsize == 68 and TASK.itemsize == 72 and EXT.itemsize == 32 and RESULT.itemsize == 96
+assert ATASK.itemsize == 32 and KSWR.itemsize == 28
 assert EXT_TASK.itemsize == 40 and SYNTH.itemsize == 72 and CONFIG.itemsize == 96 and REF_TASK.itemsize == 56
 
 REFBATCH_IN_WORDS, REFBATCH_OUT_WORDS, REFBATCH_MAX_TASKS = 65536, 4096, 819
@@ -111,6 +112,7 @@ def lib():
             "bsw_batch_order": (C.c_int, [vp, vp, vp, vp]),
             "bsw_scalar_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
             "bsw_global_batch": (C.c_int, [vp, vp, vp, sz, C.c_int, vp, vp]),
+            "bsw_align_batch": (C.c_int, [vp, vp, vp, sz, vp]),
             "ksw_global2": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp] + [C.c_int] * 5 + [vp, vp]),
             "ksw_global": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp] + [C.c_int] * 3 + [vp, vp]),
             "bsw_ref_upload": (C.c_int, [vp, vp, C.c_int64, C.POINTER(vp)]),
@@ -140,7 +142,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["ksw_global2", "ksw_global", "bsw_global_batch", "ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_scalar_stats", "bsw_host_alloc", "bsw_host_free",
+EXPORTS = ["ksw_global2", "ksw_global", "bsw_global_batch", "bsw_align_batch", "ksw_align2", "ksw_align", "ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_scalar_stats", "bsw_host_alloc", "bsw_host_free",
            "bsw_host_register", "bsw_host_unregister", "bsw_batch_order", "bsw_refbatch_submit", "bsw_refbatch_wait", "bsw_default_params", "bsw_default_config",
            "bsw_device_count", "bsw_create", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
@@ -355,6 +357,12 @@ class BswContext:
         self._chk(lib().bsw_global_batch(self.handle, params.ctypes.data, gtasks.ctypes.data, len(gtasks), max_cigar,
                                          res.ctypes.data, cig.ctypes.data if want_cigar else None), "bsw_global_batch")
         return res, cig
+
+    def align_batch(self, params, atasks):
+        """Batched ksw_align2 (bwa's local alignment of mate rescue).  Returns a KSWR array."""
+        res = np.zeros(len(atasks), dtype=KSWR)
+        self._chk(lib().bsw_align_batch(self.handle, params.ctypes.data, atasks.ctypes.data, len(atasks), res.ctypes.data), "bsw_align_batch")
+        return res
 
     def batch_order(self, batch):
         """Launch order the device-side binning produced (order, seg) — same layout as plan_batch."""

@@ -205,6 +205,38 @@ int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 int ksw_global(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
                int gapo, int gape, int w, int *n_cigar, uint32_t **cigar);
 
+/* ---- local alignment with start / second-best search (second half: bwa ksw.h ksw_align2, the
+ * Smith-Waterman of mate rescue, mem_matesw) -------------------------------------------------------------
+ * Results are those of bwa's striped SSE2 code (ksw_u8 when KSW_XBYTE is set, else ksw_i16), bit for bit: score
+ * (255 = the 8-bit run saturated, call again without KSW_XBYTE), te/qe (end on target / query, inclusive),
+ * score2/te2 (best end at least ceil(score/max) rows away, needs KSW_XSUBO | threshold), tb/qb (start, needs
+ * KSW_XSTART; -1 when the start pass did not run or disagrees).  xtra = flags | 16-bit threshold, as in bwa. */
+#define KSW_XBYTE  0x10000
+#define KSW_XSTOP  0x20000
+#define KSW_XSUBO  0x40000
+#define KSW_XSTART 0x80000
+#define BSW_ALIGN_MAX_QLEN 256
+typedef struct bsw_kswr {            /* = bwa's kswr_t */
+    int32_t score, te, qe, score2, te2, tb, qb;
+} bsw_kswr;
+typedef struct bsw_atask {
+    const uint8_t *query, *target;   /* codes 0..4, one per byte */
+    int32_t qlen, tlen;              /* qlen <= BSW_ALIGN_MAX_QLEN */
+    int32_t xtra;
+    int32_t _pad;
+} bsw_atask;
+/* Batched ksw_align2 on the GPU (m = 5; p supplies mat and the four gap penalties). */
+int      bsw_align_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_atask *tasks, size_t n, bsw_kswr *out);
+/* drop-in scalar ABI (bwa ksw.h).  qry (bwa's query-profile cache) is not used: pass NULL, or a pointer whose target
+ * stays NULL. */
+#ifndef __AC_KSW_H
+typedef struct { int score; int te, qe; int score2, te2; int tb, qb; } kswr_t;
+#endif
+kswr_t ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat,
+                  int o_del, int e_del, int o_ins, int e_ins, int xtra, void **qry);
+kswr_t ksw_align(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat,
+                 int gapo, int gape, int xtra, void **qry);
+
 /* ---- device-resident batches (inputs in HBM before the timed region) ------- */
 int      bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out);
 int      bsw_run(bsw_ctx *ctx, bsw_dev_batch *b);          /* enqueue kernels only        */
