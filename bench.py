@@ -48,6 +48,55 @@ PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # rocprofv3 --pmc summary of this same command
 
 
+def side_paths(host, device):
+    """The paths either side of the extension kernels, one short measurement each, outside the timed
+    region: wall time of the whole library call (host layout + H2D + kernels + D2H), inputs in registered host memory."""
+    rng = np.random.default_rng(5)
+    p = host.default_params()
+    res = {}
+    n, L = 100_000, 150
+    ref = rng.integers(0, 4, 2_000_000).astype(np.uint8)
+    starts = rng.integers(1000, len(ref) - 2000, n)
+    reads = ref[starts[:, None] + np.arange(L)]
+    reads = np.where(rng.random(reads.shape) < 0.02, (reads + rng.integers(1, 4, reads.shape)) % 4, reads).astype(np.uint8)
+    arena = host.HostArena(len(ref) + n * 152 + 4096)
+    arena.u8[:len(ref)] = ref
+    arena.u8[len(ref):len(ref) + n * 152].reshape(n, 152)[:, :L] = reads
+    base = arena.u8.ctypes.data
+    with host.BswContext(device=device) as c:
+        # F4: bwa ksw_align2, mate-rescue shapes (150 bp mate in a 600 bp window that holds it, bwa's flags, 8-bit mode)
+        at = np.zeros(n, dtype=host.ATASK)
+        at["query"], at["qlen"] = base + len(ref) + 152 * np.arange(n), L
+        at["target"], at["tlen"] = base + starts - 200, 600
+        at["xtra"] = host.KSW_XBYTE | host.KSW_XSUBO | host.KSW_XSTART | 19
+        c.align_batch(p, at[:2000])
+        t0 = time.perf_counter(); r = c.align_batch(p, at); dt = time.perf_counter() - t0
+        res["ksw_align2"] = {"alignments_per_s": round(n / dt), "first_pass_gcups": round(n * L * 600 / dt / 1e9, 1), "mean_score": round(float(r["score"].mean()), 1)}
+        # F4: bwa ksw_global2 with CIGAR, w = 25
+        gt = np.zeros(n, dtype=host.GTASK)
+        gt["query"], gt["qlen"] = at["query"], L
+        gt["target"], gt["tlen"], gt["w"] = base + starts, L, 25
+        c.global_batch(p, gt[:2000], max_cigar=32)
+        t0 = time.perf_counter(); g, _ = c.global_batch(p, gt, max_cigar=32); dt = time.perf_counter() - t0
+        res["ksw_global2"] = {"alignments_per_s": round(n / dt), "band_w": 25, "mean_score": round(float(g["score"].mean()), 1)}
+        # F1: the reference's 256 KiB task batches, 128 queued per wait
+        pz = host.default_params(zdrop=0)
+        wt, _ = host.synth_tasks(128 * 819, seed=51, seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.05)
+        ins, outs, lo = [], [], 0
+        while lo < len(wt) and len(ins) < 128:
+            w, k = host.refbatch_encode(pz, wt[lo:lo + 819]); ins.append(w); outs.append(np.zeros(host.REFBATCH_OUT_WORDS, np.uint32)); lo += k
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for a, b in zip(ins, outs):
+                c.refbatch_submit(a, b)
+            c.refbatch_wait(0, 0)
+            best = min(best, time.perf_counter() - t0)
+        res["wire_format"] = {"seeds_per_s": round(lo / best), "batches_in_flight": len(ins)}
+    arena.free()
+    return res
+
+
 def pmc_summary(workload, tasks):
     """Counters of the committed rocprofv3 PMC passes of this same command (profiles/pmc_latest.json), or {}."""
     try:
@@ -374,6 +423,7 @@ def main():
             extra[wl] = {"gcups": round(cells_of(r2) / (ms * 1e-3) / 1e9, 1), "ms_per_step": round(ms, 3), "seeds": args.tasks}
             b2.free()
         out["other_workloads"] = extra
+        out["other_paths"] = side_paths(host, local_rank)
         if not args.no_e2e:
             # the same submit path when the caller's memory is NOT registered: host threads gather into pinned staging
             t3, a3 = host.synth_tasks(args.tasks, seed=1000, **spec)
