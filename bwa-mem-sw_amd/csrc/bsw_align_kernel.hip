@@ -35,19 +35,21 @@ __device__ __forceinline__ int adpp(int old, int src)
 {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, 0xf, false);
 }
-/* max over the 16 lanes of a DPP row, in every lane: mirror, half mirror, two quad permutes */
+/* max over the GW (16 or 8) lanes of a group, in every lane: (mirror,) half mirror, two quad permutes */
+template <int GW>
 __device__ __forceinline__ int row_max16(int v)
 {
-    v = max(v, adpp<0x140>(INT_MIN, v));            /* row_mirror      */
+    if (GW == 16) v = max(v, adpp<0x140>(INT_MIN, v));   /* row_mirror      */
     v = max(v, adpp<0x141>(INT_MIN, v));            /* row_half_mirror */
     v = max(v, adpp<0x4e>(INT_MIN, v));             /* quad_perm [2,3,0,1] */
     v = max(v, adpp<0xb1>(INT_MIN, v));             /* quad_perm [1,0,3,2] */
     return v;
 }
+template <int GW>
 __device__ __forceinline__ unsigned long long row_max16_u64(unsigned long long v)
 {
     /* two 32-bit butterflies would not keep (hi, lo) together: compare as 64 bits after moving both halves */
-    for (int s = 0; s < 4; ++s) {
+    for (int s = GW == 16 ? 0 : 1; s < 4; ++s) {
         int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32), lo2, hi2;
         switch (s) {
         case 0: lo2 = adpp<0x140>(0, lo); hi2 = adpp<0x140>(0, hi); break;
@@ -76,9 +78,10 @@ __device__ __forceinline__ akswr align_pass(const bool on, const int qlen, const
                                             const int xtra, const bsw_dparams &P, const int shift, const int mx,
                                             int8_t (*prof)[SLEN][256], unsigned long long *__restrict__ bl)
 {
-    constexpr int NP = BYTE ? 16 : 8;
-    const int tid = threadIdx.x, l = tid & 15;
-    const bool lane_on = l < NP;
+    constexpr int NP = BYTE ? 16 : 8;                /* lanes of the SSE vector = lanes of the group: a 16-lane DPP row holds one
+                                                         8-bit alignment or two 16-bit ones */
+    const int tid = threadIdx.x, l = tid & (NP - 1);
+    constexpr bool lane_on = true;
     const int slen = (qlen + NP - 1) / NP;
     const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
     const int hcap = BYTE ? 255 - shift : 32767;
@@ -137,13 +140,13 @@ __device__ __forceinline__ akswr align_pass(const bool on, const int qlen, const
                 const int fn = max(f - e_ins, 0);
                 f = go ? fn : f;
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(go && lane_on && fn > hh);
-                const bool any = ((m >> (tid & 48)) & 0xffffull) != 0;
+                const bool any = ((m >> (tid & (64 - NP))) & (NP == 16 ? 0xffffull : 0xffull)) != 0;
                 lz = go ? any : lz;                                        /* (rows past their slen keep lz and skip on their own) */
             }
         }
 #pragma unroll
         for (int j = 0; j < SLEN; ++j) hl = (ra && j == slen - 1) ? H[j] : hl;
-        const int imax = row_max16(lane_on ? mxv : 0);
+        const int imax = row_max16<NP>(mxv);
         if (ra && imax >= minsc) {                                         /* the b array of sub-optimal ends */
             if (n_b == 0 || last_i + 1 != i) {
                 if (l == 0) bl[n_b] = ((unsigned long long)(uint32_t)imax << 32) | (uint32_t)i;
@@ -169,7 +172,7 @@ __device__ __forceinline__ akswr align_pass(const bool on, const int qlen, const
 #pragma unroll
         for (int j = 0; j < SLEN; ++j)
             if (lane_on && j < slen) key = max(key, (Hmax[j] << 16) | (0xffff - (j * NP + l)));
-        key = row_max16(key);
+        key = row_max16<NP>(key);
         if (slen > 0) {
             const int mi = 0xffff - (key & 0xffff);
             r.qe = mi / NP + (mi % NP) * slen;
@@ -178,7 +181,7 @@ __device__ __forceinline__ akswr align_pass(const bool on, const int qlen, const
             __threadfence_block();
             const int d = (r.score + mx - 1) / mx, low = te - d, high = te + d;
             unsigned long long best = 0;                                   /* (score + 1) << 32 | ~index : 0 = none */
-            for (int x = l; x < n_b; x += 16) {
+            for (int x = l; x < n_b; x += NP) {
                 const unsigned long long ent = bl[x];
                 const int e = (int)(uint32_t)ent, sc = (int)(ent >> 32);
                 if (e < low || e > high) {
@@ -186,7 +189,7 @@ __device__ __forceinline__ akswr align_pass(const bool on, const int qlen, const
                     best = kk > best ? kk : best;
                 }
             }
-            best = row_max16_u64(best);
+            best = row_max16_u64<NP>(best);
             if (best != 0) {
                 const int x = 0x7fffffff - (int)(uint32_t)best;
                 const int sc = (int)(best >> 32) - 1;
@@ -206,8 +209,9 @@ __global__ __launch_bounds__(256) void bsw_align_kernel(const bsw_dparams P, con
                                                         const uint32_t n, unsigned long long *__restrict__ blist, bsw_kswr *__restrict__ out)
 {
     __shared__ int8_t prof[5][SLEN][256];
-    const int tid = threadIdx.x, l = tid & 15;
-    const uint32_t slot = blockIdx.x * 16u + (uint32_t)(tid >> 4);
+    constexpr int GW = BYTE ? 16 : 8, APB = 256 / GW;               /* lanes per alignment, alignments per workgroup */
+    const int tid = threadIdx.x, l = tid & (GW - 1);
+    const uint32_t slot = blockIdx.x * (uint32_t)APB + (uint32_t)(tid / GW);
     const bool valid = slot < n;
     const uint32_t ai = order[valid ? slot : 0];
     const bsw_adtask T = tasks[ai];
@@ -245,7 +249,9 @@ hipError_t launch_align(int cls, const bsw_dparams &P, const uint64_t *seq, cons
                         unsigned long long *blist, bsw_kswr *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    const dim3 grid((n + 15u) / 16u), block(256);
+    const bool byte = kAlignClasses[cls].byte != 0;
+    const uint32_t apb = byte ? 16u : 32u;
+    const dim3 grid((n + apb - 1u) / apb), block(256);
     switch (cls) {
     case 0: hipLaunchKernelGGL((bsw_align_kernel<8, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
     case 1: hipLaunchKernelGGL((bsw_align_kernel<16, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
