@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256) void bsw_align_kernel(const bsw_dparams P, con
 }
 
 /* classes: (mode, vectors per lane) -> query length up to lanes * vectors */
-static const struct { int byte, slen; } kAlignClasses[] = {{1, 8}, {1, 16}, {0, 16}, {0, 32}};
+/* (10 / 20 vectors: 150 bp reads, the common case, without the predicated tail of the 16 / 32 vector kernels) */
+static const struct { int byte, slen; } kAlignClasses[] = {{1, 8}, {1, 10}, {1, 16}, {0, 16}, {0, 20}, {0, 32}};
 int align_class_count() { return (int)(sizeof(kAlignClasses) / sizeof(kAlignClasses[0])); }
 int align_class_of(int qlen, int byte_mode)
 {
@@ -254,9 +255,11 @@ hipError_t launch_align(int cls, const bsw_dparams &P, const uint64_t *seq, cons
     const dim3 grid((n + apb - 1u) / apb), block(256);
     switch (cls) {
     case 0: hipLaunchKernelGGL((bsw_align_kernel<8, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
-    case 1: hipLaunchKernelGGL((bsw_align_kernel<16, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
-    case 2: hipLaunchKernelGGL((bsw_align_kernel<16, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
-    case 3: hipLaunchKernelGGL((bsw_align_kernel<32, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 1: hipLaunchKernelGGL((bsw_align_kernel<10, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 2: hipLaunchKernelGGL((bsw_align_kernel<16, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 3: hipLaunchKernelGGL((bsw_align_kernel<16, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 4: hipLaunchKernelGGL((bsw_align_kernel<20, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 5: hipLaunchKernelGGL((bsw_align_kernel<32, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
