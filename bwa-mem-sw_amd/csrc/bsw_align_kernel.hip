@@ -5,10 +5,11 @@
  * The outputs of the SSE2 code depend on its striping (which query position shares a vector with which, where the
  * lazy-F loop stops, that E is taken from H before the lazy-F correction, the memory order of the qe search — see
  * oracle/ksw_align_ref.c), so the kernel keeps the striping: ONE 16-LANE DPP ROW PLAYS ONE __m128i.  Lane l of the
- * row is byte lane l (8-bit mode) or word lane l < 8 (16-bit mode; lanes 8..15 idle); the slen vectors of H, E and
- * Hmax are slen registers per lane, statically addressed; _mm_slli_si128 is one `row_shr:1`; the horizontal max and
- * the "all lanes done" test of the lazy-F loop are 4-step DPP butterflies / a ballot.  Four alignments per wavefront,
- * sixteen per workgroup; the per-lane score profile lives in LDS.  The sub-optimal list b[] goes to HBM (8 bytes per
+ * row is byte lane l (8-bit mode: one alignment per row), or the row holds two alignments of 8 word lanes each
+ * (16-bit mode); the slen vectors of H, E and Hmax are slen registers per lane, statically addressed (H is updated in
+ * place: the old value is the next column's diagonal); _mm_slli_si128 is one `row_shr:1` with the group's lane 0
+ * forced to zero; the horizontal max and the "all lanes done" test of the lazy-F loop are DPP butterflies / a ballot.
+ * Four (eight) alignments per wavefront; the per-lane score profile lives in LDS, one column per thread.  The sub-optimal list b[] goes to HBM (8 bytes per
  * qualifying row) and is scanned by the row's 16 lanes afterwards.  The start-point pass (KSW_XSTART) runs in the same
  * kernel on the mirrored prefixes by index arithmetic, no sequence is reversed in memory.
  * Integer max/add work, ~14 VALU + 1 LDS read per cell and lane: VALU-issue-bound like the extension kernels, but at
