@@ -206,7 +206,8 @@ int ksw_global(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
                int gapo, int gape, int w, int *n_cigar, uint32_t **cigar);
 
 /* ---- local alignment with start / second-best search (second half: bwa ksw.h ksw_align2, the
- * Smith-Waterman of mate rescue, mem_matesw) -------------------------------------------------------------
+ * Smith-Waterman of mate rescue, mem_matesw; like ksw_global2 it lives in the reference's host software, the
+ * bwa-0.7.8 tree named at /root/reference/README.md:7-18, not in the RTL) ---------------------------------
  * Results are those of bwa's striped SSE2 code (ksw_u8 when KSW_XBYTE is set, else ksw_i16), bit for bit: score
  * (255 = the 8-bit run saturated, call again without KSW_XBYTE), te/qe (end on target / query, inclusive),
  * score2/te2 (best end at least ceil(score/max) rows away, needs KSW_XSUBO | threshold), tb/qb (start, needs
