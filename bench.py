@@ -97,15 +97,76 @@ def side_paths(host, device):
     return res
 
 
+PRESETS = {
+    # BASELINE.json configs[3]: 100M 150 bp PE reads, per-read task shard over the ranks, one pool (strong scaling)
+    "configs3": dict(workload="150bp_w100_mixed_bins", scaling="strong", pool=100_000_000),
+    # BASELINE.json configs[4]: 250 bp PE reads at ~5 % error, w=500 (weak: every rank owns a batch)
+    "configs4": dict(workload="250bp_w500", scaling="weak"),
+}
+
+
+def self_launch(n):
+    """One fresh child process per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set as torchrun would), rank 0's stdout relayed.
+    The parent never initialises the GPU and never execs: the reference's one manager feeding several PE arrays
+    (batch_manager.v:343-348) becomes one launcher feeding N per-GPU ranks.  Exit code: non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = []
+    deadline = time.time() + 600
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print("bench.py: ranks failed (rank, exit code): %s" % bad, file=sys.stderr)
+        return 1
+    return 0
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the kernel and batch-manager sources the library is built from: identifies the code a
+    counter file was collected on (tools/make_pmc_latest.py stores it, pmc_summary() compares it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "bwa-mem-sw_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.c"))):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_summary(workload, tasks):
-    """Counters of the committed rocprofv3 PMC passes of this same command (profiles/pmc_latest.json), or {}."""
+    """(counters, source) of the committed rocprofv3 PMC passes of this same command (profiles/pmc_latest.json).  The counters
+    come from an EARLIER run of this command under rocprofv3 --pmc, not from the run that prints them: they are quoted only
+    when the file was collected on the same workload AND the same kernel sources as this tree; otherwise ({}, why)."""
+    src = {"file": "profiles/pmc_latest.json", "collected": "earlier rocprofv3 --pmc passes of this command (tools/profile.sh), not this run"}
     try:
         j = json.load(open(PMC_FILE))
-        if j.get("workload") != workload or j.get("seeds_per_gpu") != tasks:
-            return {}
-        return j
     except Exception:
-        return {}
+        return {}, dict(src, status="absent")
+    src["source_hash"] = j.get("source_hash")
+    src["tree_hash"] = kernel_source_hash()
+    if j.get("workload") != workload or j.get("seeds_per_gpu") != tasks:
+        return {}, dict(src, status="other workload: counters omitted")
+    if j.get("source_hash") != src["tree_hash"]:
+        return {}, dict(src, status="stale (kernel sources changed since the counters were collected): counters omitted")
+    return j, dict(src, status="matches this tree")
 
 
 def cells_of(res):
@@ -119,7 +180,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tasks", type=int, default=1_000_000, help="seeds per GPU per step (weak scaling)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--pool", type=int, default=8_000_000, help="--scaling strong: seeds in the one pool all ranks share")
+    ap.add_argument("--pool", type=int, default=8_000_000, help="--scaling strong: seeds in the one pool all ranks share (BASELINE configs[3]: 100000000)")
+    ap.add_argument("--resident-chunks", type=int, default=32, help="--scaling strong: 128Ki-seed chunks per resident batch")
     ap.add_argument("--workload", default="150bp_w100_single_bin", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--zdrop", type=int, default=100)
@@ -136,13 +198,40 @@ def main():
                     help="torch.distributed backend for the barrier / timing reduction (nccl = RCCL; gloo only to rehearse N>1 on a 1-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses device 0 (needs --backend gloo)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto (batch manager picks per bin), 1 wave-per-task only, 2 force lane bins")
+    ap.add_argument("--dry-run", action="store_true", help="launcher check without a GPU: the ranks rendezvous over gloo, count themselves and rank 0 prints the count")
+    ap.add_argument("--preset", default=None, choices=sorted(PRESETS),
+                    help="BASELINE.json configs[3] / configs[4] as one flag (sets --workload/--scaling/--pool; explicit flags still win)")
     args = ap.parse_args()
+    if args.preset:
+        given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+        for key, val in PRESETS[args.preset].items():
+            if "--" + key not in given:
+                setattr(args, key, val)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without torchrun: start N fresh per-GPU ranks BEFORE anything here touches the GPU
+        sys.exit(self_launch(args.gpus))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if args.dry_run:
+        seen = 1
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo")
+            v = torch.ones(1, dtype=torch.float64)
+            dist.all_reduce(v)
+            seen = int(v.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "gpus_flag": args.gpus,
+                              "scaling": args.scaling, "workload": args.workload, "pool": args.pool}), flush=True)
+        return
     if args.share_gpu:
         local_rank = 0
     if world > 1:
@@ -167,33 +256,45 @@ def main():
 
     # ---- this rank's seeds, generated straight into pinned (DMA-able) host memory ----
     chunk = 131072
+    ctx = host.BswContext(device=local_rank, kernel=args.kernel)
     if args.scaling == "strong":
+        # one pool, chunk c -> rank c mod N; a rank's chunks become resident batches of <= --resident-chunks chunks (a resident
+        # batch holds < 4 GiB of bases), generated, uploaded and dropped on the host one group at a time
         nchunks = (args.pool + chunk - 1) // chunk
-        mine = [c for c in range(nchunks) if c % world == rank]             # chunk c -> rank c mod N
-        sizes = [min(chunk, args.pool - c * chunk) for c in mine]
-        n_local = int(sum(sizes))
+        mine = [c for c in range(nchunks) if c % world == rank]
+        groups = [mine[i:i + args.resident_chunks] for i in range(0, len(mine), args.resident_chunks)]
+        gb = args.resident_chunks * host.synth_arena_bound(chunk, **spec) + 4096
+        harena = host.HostArena(gb)
+        batches, n_local, gstats = [], 0, []
+        for grp in groups:
+            sizes = [min(chunk, args.pool - c * chunk) for c in grp]
+            tg = np.zeros(int(sum(sizes)), dtype=host.TASK)
+            off = k = 0
+            for c, sz in zip(grp, sizes):                                   # every chunk has its own generator seed
+                t, _ = host.synth_tasks(sz, arena=harena.u8[off:], seed=5000 + c, **spec)
+                t["tag"] = np.arange(c * chunk, c * chunk + sz, dtype=np.uint32)
+                tg[k:k + sz] = t
+                k += sz
+                off += host.synth_arena_bound(sz, **spec)
+            batches.append(ctx.upload(params, tg))                          # inputs resident in HBM before the timed region
+            n_local += len(tg)
+            gstats.append((int((tg["lqlen"] > 0).sum() + (tg["rqlen"] > 0).sum()),
+                           int((tg["lqlen"].astype(np.int64) * tg["ltlen"]).sum() + (tg["rqlen"].astype(np.int64) * tg["rtlen"]).sum())))
+            if rank == 0 and len(groups) > 1:
+                print("bench.py: rank 0 resident batch %d/%d (%d seeds)" % (len(batches), len(groups), len(tg)), file=sys.stderr, flush=True)
+        tasks = tg if len(groups) == 1 else None                            # e2e legs only when the rank's share is one batch
+        hout = host.HostArena(max(n_local if tasks is not None else 1, 1) * host.RESULT.itemsize)
     else:
-        mine, sizes, n_local = None, None, args.tasks
-    bound = (sum(host.synth_arena_bound(sz, **spec) for sz in sizes) if sizes else host.synth_arena_bound(max(n_local, 1), **spec)) + 4096
-    harena = host.HostArena(bound)
-    hout = host.HostArena(max(n_local, 1) * host.RESULT.itemsize)
-    if args.scaling == "strong":
-        tasks = np.zeros(n_local, dtype=host.TASK)
-        off = k = 0
-        for c, sz in zip(mine, sizes):                                      # every chunk has its own generator seed
-            t, _ = host.synth_tasks(sz, arena=harena.u8[off:], seed=5000 + c, **spec)
-            t["tag"] = np.arange(c * chunk, c * chunk + sz, dtype=np.uint32)
-            tasks[k:k + sz] = t
-            k += sz
-            off += host.synth_arena_bound(sz, **spec)
-    else:
+        n_local = args.tasks
+        harena = host.HostArena(host.synth_arena_bound(max(n_local, 1), **spec) + 4096)
+        hout = host.HostArena(max(n_local, 1) * host.RESULT.itemsize)
         tasks, _ = host.synth_tasks(n_local, arena=harena.u8, seed=1000 + rank, **spec)
-    out_buf = hout.view(host.RESULT, max(n_local, 1))[:n_local]
+        batches = [ctx.upload(params, tasks)]        # inputs resident in HBM before the timed region
+    if tasks is None:
+        args.no_e2e = True
+    out_buf = hout.view(host.RESULT, max(n_local, 1))[:n_local] if tasks is not None else None
     hout2 = host.HostArena(max(n_local, 1) * host.RESULT.itemsize) if (world == 1 and not args.no_e2e) else None
     out_buf2 = hout2.view(host.RESULT, max(n_local, 1))[:n_local] if hout2 is not None else None
-
-    ctx = host.BswContext(device=local_rank, kernel=args.kernel)
-    batch = ctx.upload(params, tasks)            # inputs resident in HBM before the timed region
 
     def barrier():
         torch.cuda.synchronize()
@@ -202,25 +303,41 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        ctx.run(batch)
+        for b in batches:
+            ctx.run(b)
     ctx.sync()
     ctx.run_history()                            # reset per-run event history
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.run(batch)
+        for b in batches:
+            ctx.run(b)
     ctx.sync()
     barrier()
     dt = time.perf_counter() - t0
-    kern_ms = ctx.run_history()                  # HIP events on the library's own stream, one pair per step
+    kern_ms = ctx.run_history()                  # HIP events on the library's own stream, one pair per bsw_run
 
-    res = ctx.download(batch)
-    info = batch.info()
-    batch.free()
-    cells = cells_of(res)
-    ext_calls = int((tasks["lqlen"] > 0).sum() + (tasks["rqlen"] > 0).sum()
-                    + (res["left"]["aw"] > spec["w"]).sum() + (res["right"]["aw"] > spec["w"]).sum())
-    nominal = int((tasks["lqlen"].astype(np.int64) * tasks["ltlen"]).sum() + (tasks["rqlen"].astype(np.int64) * tasks["rtlen"]).sum())
+    info = {"in_bytes": 0, "out_bytes": 0, "launches": 0}
+    cells = ext_calls = nominal = 0
+    res = None
+    for gi, b in enumerate(batches):
+        r = ctx.download(b)
+        bi = b.info()
+        for key in info:
+            info[key] += bi[key]
+        b.free()
+        cells += cells_of(r)
+        retry = int((r["left"]["aw"] > spec["w"]).sum() + (r["right"]["aw"] > spec["w"]).sum())
+        if tasks is not None:
+            res = r
+            ext_calls += int((tasks["lqlen"] > 0).sum() + (tasks["rqlen"] > 0).sum()) + retry
+            nominal += int((tasks["lqlen"].astype(np.int64) * tasks["ltlen"]).sum() + (tasks["rqlen"].astype(np.int64) * tasks["rtlen"]).sum())
+        else:
+            ext_calls += gstats[gi][0] + retry
+            nominal += gstats[gi][1]
+    n_tasks_local = n_local
+    if len(batches) > 1:                         # kernel time per step = the step's bsw_run calls together
+        kern_ms = [float(sum(kern_ms[i:i + len(batches)])) for i in range(0, len(kern_ms), len(batches))]
 
     def stream_two_in_flight(make_ctx, submit, reps=8):
         """A stream of batches, two in flight: two contexts of two slots each (4 slot threads in all), submit k+2 issued as
@@ -298,7 +415,7 @@ def main():
         hreads.free()
 
     if dist is not None:
-        v = torch.tensor([dt, float(cells), float(ext_calls), float(len(tasks)), float(nominal), e2e_dt or 0.0],
+        v = torch.tensor([dt, float(cells), float(ext_calls), float(n_tasks_local), float(nominal), e2e_dt or 0.0],
                          dtype=torch.float64, device=red_dev)
         tmax = v[[0, 5]].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -307,19 +424,21 @@ def main():
         cells_all, ext_all, tasks_all, nominal_all = (float(x) for x in v[1:5].tolist())
     else:
         dt_all, e2e_all = dt, e2e_dt or 0.0
-        cells_all, ext_all, tasks_all, nominal_all = float(cells), float(ext_calls), float(len(tasks)), float(nominal)
+        cells_all, ext_all, tasks_all, nominal_all = float(cells), float(ext_calls), float(n_tasks_local), float(nominal)
 
     out = None
     if rank == 0:
         gcups = cells_all * args.steps / dt_all / 1e9
         kavg_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
         alg_bytes = info["in_bytes"] + info["out_bytes"]          # per launch: packed seq + task records + order + results
-        pmc = pmc_summary(args.workload, n_local)
+        pmc, pmc_src = pmc_summary(args.workload, n_local)
         traffic = int((2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in pmc else None
         tops = cells * VALU_OPS_PER_CELL / (kavg_ms * 1e-3) / 1e12
         out = {
             "metric": "GCUPS (seed-extension DP cells/s, 150 bp PE)", "value": round(gcups, 3), "unit": "GCUPS",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "world_size": (dist.get_world_size() if dist is not None else 1),
+            "collective_backend": (("rccl" if args.backend == "nccl" else args.backend) if dist is not None else None),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_all / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32 ALU on host-range-checked u8 rows (16-bit rows / int32 for wider scores)",
             "data": "synthetic",
@@ -327,7 +446,7 @@ def main():
                        "pool_seeds": args.pool if args.scaling == "strong" else None, "read_len": spec["read_len"],
                        "band_w": spec["w"], "zdrop": args.zdrop, "variant": "H" if args.variant == 0 else "M",
                        "sharding": "per-read task shard (chunk c -> rank c mod N), no collective" if world > 1 else "single GPU",
-                       "kernel_launches_per_step": info["launches"]},
+                       "kernel_launches_per_step": info["launches"], "resident_batches_per_rank": len(batches), "preset": args.preset},
             "extensions_per_s": round(ext_all * args.steps / dt_all, 1),
             "seeds_per_s": round(tasks_all * args.steps / dt_all, 1),
             "cells_per_step": cells_all,
@@ -339,6 +458,7 @@ def main():
                 "peak_opcode_weighted": pmc.get("peak_opcode_weighted_tops"),
                 "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"), "valu_issue_busy": pmc.get("valu_issue_busy"),
                 "traffic": traffic, "traffic_kernels": pmc.get("traffic_kernels"),
+                "counters_source": pmc_src,
                 "kernel_ms_avg": round(kavg_ms, 4),
                 "note": "integer max/add DP at ~0.02 B/cell: VALU issue binds, not HBM and not MFMA; see roofline_hbm",
             },
@@ -379,7 +499,7 @@ def main():
                     "seeds_per_s": round(n_local / ref_stream[0], 1), "gcups": round(rcells / ref_stream[0] / 1e9, 1),
                     "ratio_to_hbm_resident": round((n_local / ref_stream[0]) / (tasks_all * args.steps / dt_all), 3),
                     "host_threads": "4 slot threads (2 contexts x 2 slots)", "batches_timed": 16, "bit_exact_vs_single_submit": ref_stream[1]}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and tasks is not None:
             orc = graft.load_oracle()
             ncpu = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)
             ns = min(args.cpu_sample, len(tasks))

@@ -1240,11 +1240,15 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
     stage_t &st = dev.slots[s];
     hipStream_t stream = dev.streams[s];
     struct { bool active = false; size_t n = 0; bsw_result *out = nullptr; bool direct = false, copied = false; } pend;
+    bool queued = false;                            /* some async op of the current chunk may be on the stream (set before the first one) */
     auto bail = [&](int rc) {                       /* wake the slots waiting for their DMA turn; leave nothing in flight */
         abort_flag = 1;
         { std::lock_guard<std::mutex> lk(gate.mu); }
         gate.cv.notify_all();
-        if (pend.active) { errs quiet; (void)sync_stream(ctx, quiet, stream, dev.events[s]); pend.active = false; }
+        /* a failure after stage_device queued its first copy leaves DMAs out of the caller's registered arena and kernels
+         * in flight although pend.active is still false: drain the stream (with the watchdog) before the error is reported,
+         * so the caller may free or reuse that memory as soon as bsw_wait returns */
+        if (pend.active || queued) { errs quiet; (void)sync_stream(ctx, quiet, stream, dev.events[s]); pend.active = false; queued = false; }
         return rc;
     };
     hipError_t he = hipSetDevice(dev.device);
@@ -1308,6 +1312,7 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         const double t3 = dbg ? tnow() : 0;
         gate_turn turn;
         turn.gate = &gate; turn.seq = k; turn.ev = dev.h2d_done[s]; turn.abort_flag = &abort_flag;
+        queued = true;
         rc = stage_device(e, st, stream, ci, n, rtasks != nullptr, ref, nullptr, &turn, d);
         if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr);
         if (rc) return bail(rc);
@@ -1325,6 +1330,7 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(he)));
         pend.copied = !late;
         pend.active = true; pend.n = n; pend.out = co;
+        queued = false;                             /* from here on finish() / bail() drain through pend */
         if (dbg) { const double t4 = tnow(); t_staging += t1 - t0; t_host += t2 - t1; t_finish += t3 - t2; t_stage += t4 - t3; }
     }
     const double t5 = dbg ? tnow() : 0;
@@ -1715,11 +1721,13 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
                 if (lq) { d.lq_off = (uint32_t)a2; a2 += nwords(lq); d.lt_off = (uint32_t)a2; a2 += nwords(lt); }
                 if (rq) { d.rq_off = (uint32_t)a2; a2 += nwords(rq); d.rt_off = (uint32_t)a2; a2 += nwords(rt); }
                 d.lqlen = (uint16_t)lq; d.rqlen = (uint16_t)rq; d.ltlen = (uint16_t)lt; d.rtlen = (uint16_t)rt;
-                /* H5/H6 = {max_del[31:16], max_ins[15:0]}: the band limit the RTL applies (proc_element.v:925,933) */
+                /* H5/H6 = {max_del[31:16], max_ins[15:0]}: the band limit the RTL applies (proc_element.v:925,933).  A
+                 * non-positive limit (never written by bwa: both are >= 1) reads as 1, exactly as bsw_refbatch_decode maps it,
+                 * so a malformed header gives the same band through either entry point */
                 auto lim = [](uint32_t h) {
                     const int mi = (int)(int16_t)(h & 0xffff), md = (int)(int16_t)(h >> 16);
                     const int l = mi < md ? mi : md;
-                    return (uint16_t)(l < 0 ? 0 : l);
+                    return (uint16_t)(l < 1 ? 1 : l);
                 };
                 d.wlim_l = lim(H[5]); d.wlim_r = lim(H[6]);
                 d.h0 = h0; d.init_score = (int)(int16_t)(H[3] & 0xffff); d.qbeg = (int)(H[3] >> 16); d.tag = H[7];
@@ -1858,7 +1866,12 @@ extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
         const double te = tnow();
         if (!rc) rc = refbatch_enqueue(ctx, q0, q1, variant, zdrop, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], &n_enq);
         if (dbg) fprintf(stderr, "[bsw] wire: enqueue slot %zu batches [%zu,%zu) %zu tasks: +%.3f .. +%.3f ms\n", sl, q0, q1, n_enq, te - t_start, tnow() - t_start);
-        if (rc) { drain(); ctx->ref_queue.clear(); return rc; }
+        if (rc) {
+            /* a failure half-way through refbatch_enqueue leaves copies out of the queued batches / kernels on this slot's
+             * stream with fl[sl].active still false: drain that stream too before the caller gets its buffers back */
+            { errs quiet; (void)sync_stream(ctx, quiet, dev.streams[slot_of[sl]], dev.events[slot_of[sl]]); }
+            drain(); ctx->ref_queue.clear(); return rc;
+        }
         if (n_enq) { fl[sl].active = true; fl[sl].q0 = q0; fl[sl].q1 = q1; fl[sl].n = n_enq; }
         q0 = q1;
     }

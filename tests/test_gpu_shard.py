@@ -62,3 +62,29 @@ def test_two_ranks_share_the_task_pool_on_gpu():
         assert pr.exitcode == 0
     assert same
     assert int(agg[0]) == ref_cells and int(agg[1]) == n
+
+
+def _bench(*args, timeout=600):
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")})
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stderr[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_gpus_2_without_torchrun_runs_two_ranks():
+    """The driver's command shape: `python bench.py --gpus 2 ...` with no launcher in front.  Two ranks share the one GPU of
+    this box (gloo for the barrier); the line must say n_gpus 2 and carry both ranks' seeds."""
+    common = ["--share-gpu", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-extra"]
+    weak = _bench("--gpus", "2", "--tasks", "60000", *common)
+    assert weak["n_gpus"] == 2 and weak["world_size"] == 2 and weak["scaling"] == "weak"
+    assert round(weak["seeds_per_s"] * weak["ms_per_step"] / 1e3) == 120000
+    # configs[3] shape at a small pool: one pool, chunk c -> rank c mod 2, several resident batches per rank
+    strong = _bench("--gpus", "2", "--preset", "configs3", "--pool", "700000", "--resident-chunks", "2", *common)
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["config"]["pool_seeds"] == 700000
+    assert strong["config"]["resident_batches_per_rank"] == 2
+    assert round(strong["seeds_per_s"] * strong["ms_per_step"] / 1e3) == 700000
+    one = _bench("--gpus", "1", "--preset", "configs3", "--pool", "700000", "--resident-chunks", "2", *common[2:])
+    assert one["n_gpus"] == 1 and one["cells_per_step"] == strong["cells_per_step"]      # same pool, same cells, however it is sharded

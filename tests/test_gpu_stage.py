@@ -164,6 +164,30 @@ def test_wire_format_carries_h5_h6(host, oracle, ctx):
         assert (got[f] == want[f]).all(), f
 
 
+def test_wire_format_nonpositive_h5_h6_reads_as_one(host, oracle, ctx):
+    """A malformed header (max_ins/max_del <= 0, never written by bwa) must give the SAME band through bsw_refbatch_run as
+    through bsw_refbatch_decode + bsw_submit: both read it as 1 (the wire path used to apply band 0)."""
+    tasks, arena = host.synth_tasks(300, seed=53, **dict(MIXED, indel_rate=0.03, n_rate=0.0))
+    tasks["wlim_l"] = 3
+    tasks["wlim_r"] = 5
+    p = host.default_params(zdrop=0)
+    words, n = host.refbatch_encode(p, tasks)
+    assert n == len(tasks)
+    for i in range(n):                               # H5 / H6 of every other task: zero, or a negative max_ins
+        if i % 2 == 0:
+            words[8 + 8 * i + 5] = 0
+            words[8 + 8 * i + 6] = np.uint32(0x0004fffd)      # max_del 4, max_ins -3
+    p2, t2, seqbuf = host.refbatch_decode(words)
+    assert (t2["wlim_l"][0::2] == 1).all() and (t2["wlim_r"][0::2] == 1).all() and (t2["wlim_l"][1::2] == 3).all()
+    out, nres = ctx.refbatch_run(words, variant=0, zdrop=0)
+    got = host.refbatch_decode_results(out, n)
+    want = oracle.pair_batch(p2, t2)
+    via_submit = ctx.extend_pairs(p2, t2)
+    assert via_submit.tobytes() == want.tobytes()
+    for f in FIELDS:
+        assert (got[f] == want[f]).all(), f
+
+
 @pytest.mark.parametrize("kernel", [0, 2])
 def test_wire_batches_in_flight(host, oracle, kernel):
     """bsw_refbatch_submit/wait: many 256 KiB task batches queued, unpacked on the GPU, run as one device batch."""

@@ -66,3 +66,33 @@ def test_shard_indices_partition(host):
         assert len(seen) == n and (np.sort(seen) == np.arange(n)).all()
     # contiguous per-read chunks, round-robin over ranks
     assert (host.shard_indices(300, 2, 1, 100) == np.arange(100, 200)).all()
+
+
+def _bench(*args, timeout=300):
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")})
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_flag_starts_one_rank_per_gpu():
+    """`python bench.py --gpus N` without torchrun must start N ranks itself (it used to measure one GPU):
+    the launcher path, rendezvous and relay of rank 0's line, checked without a GPU through --dry-run."""
+    rc, line, err = _bench("--gpus", "2", "--dry-run", "--preset", "configs3")
+    assert rc == 0, err
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["scaling"] == "strong" and line["pool"] == 100_000_000 and line["workload"] == "150bp_w100_mixed_bins"
+    rc, line, err = _bench("--gpus", "3", "--dry-run", "--preset", "configs4", "--pool", "5")
+    assert rc == 0 and line["n_gpus"] == 3 and line["workload"] == "250bp_w500" and line["scaling"] == "weak" and line["pool"] == 5
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """no GPU here: every rank fails its `needs a GPU` assertion and the launcher must exit non-zero, not print a line"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU")
+    rc, line, err = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert rc != 0 and line is None and "ranks failed" in err

@@ -15,7 +15,9 @@ fetch = sum(v.get("FETCH_SIZE", 0) for v in step.values())
 write = sum(v.get("WRITE_SIZE", 0) for v in step.values())
 main = max(step.items(), key=lambda kv: kv[1].get("avg_ns", 0))
 isa = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_histogram.py")]))
-out = {"workload": workload, "seeds_per_gpu": seeds, "source": os.path.basename(os.path.dirname(d) if d.endswith(".json") else d.rstrip("/")),
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_hash: the code these counters belong to)
+out = {"workload": workload, "seeds_per_gpu": seeds, "source_hash": bench.kernel_source_hash(), "source": os.path.basename(os.path.dirname(d) if d.endswith(".json") else d.rstrip("/")),
        "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
        "traffic_kernels": {k[:40]: int((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) for k, v in step.items()},
        "dominant_kernel": main[0][:60], "dominant_kernel_avg_ms": round(main[1]["avg_ns"] / 1e6, 4),
