@@ -122,16 +122,18 @@ L2_FN void sfor(F &&f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
 struct consts {
     int a, pb, pn;                      /* match score, mismatch penalty (-mat[1]), N penalty (-mat[24]); pb >= pn >= 0 */
     int o_del, e_del, oe_ins, e_ins, zdrop;
-    uint32_t OE2s, ED2s, ONE2;          /* {oe,oe} << 8, {e,e} << 8, {1,1}: symmetric gaps (o_del == o_ins, e_del == e_ins) */
+    uint32_t OED2s, ED2s, OEI2s, EI2s, ONE2;   /* {oe_del,oe_del} << 8, {e_del,e_del} << 8, the same for insertions, {1,1} */
     uint32_t MC[8];                     /* {a+pb, a+pb} << (8 - c): match bit c of a block byte -> (a + pb) << 8 */
     uint32_t HI2;                       /* 0xff00ff00: the score bytes (kept in a VGPR by the kernel) */
 };
 
-/* the packed constants from the scalar ones (o_del + e_del < 256 and a + pb < 256: lane2_params_ok) */
+/* the packed constants from the scalar ones (o_del + e_del < 256, o_ins + e_ins < 256 and a + pb < 256: lane2_params_ok) */
 L2_FN void fill_packed_consts(consts &k)
 {
-    k.OE2s = dup16((k.o_del + k.e_del) << 8);
+    k.OED2s = dup16((k.o_del + k.e_del) << 8);
     k.ED2s = dup16(k.e_del << 8);
+    k.OEI2s = dup16(k.oe_ins << 8);
+    k.EI2s = dup16(k.e_ins << 8);
     k.ONE2 = 0x00010001u;
     for (int c = 0; c < 8; ++c) k.MC[c] = dup16((k.a + k.pb) << (8 - c));
     k.HI2 = 0xff00ff00u;
@@ -160,7 +162,10 @@ struct uni {                            /* wave-uniform values of the current ro
     uint32_t nblk;                      /* bit b: some query of the wave has an N in columns [8b, 8b+8) */
 };
 
-template <int QB>
+/* VM: variant M (bwa >= 0.7.9: M = H(i-1,j-1) ? H(i-1,j-1) + s : 0, gaps open from M) instead of variant H (the RTL's,
+ * sw_pe_array_sw_extend.v:1797-1798,1863,1866: gaps open from h).  SYM: o_del == o_ins and e_del == e_ins (one shared
+ * gap-open term per cell); the RTL's datapath takes the four penalties separately (sw_pe_array_proc_element.v:816-819). */
+template <int QB, bool VM = false, bool SYM = true>
 struct lane2 {
     static constexpr int QMAX = QB * 8;
     static constexpr int NW = (QMAX + 31) / 32;     /* 32-column match-mask words per seed */
@@ -252,11 +257,14 @@ struct lane2 {
             n &= 0x00010001u;
             X = pk_mad(n, D2s, X);                           /* a query N scores -pn whatever the target base is */
         }
-        const uint32_t M = pk_subs(X, Bv2s);                 /* max(hd + s, 0): variant H, e and f are >= 0 anyway */
+        uint32_t M = pk_subs(X, Bv2s);                       /* max(hd + s, 0): e and f are >= 0 anyway */
+        if (VM) M &= pk_nzmask(hd);                          /* variant M: a zero H(i-1,j-1) stays zero (only a match could lift it) */
         uint32_t h = pk_max(pk_max(M, e), f);                /* (:1798,1809) */
-        const uint32_t tD = pk_subs_vs(h, k.OE2s);
+        const uint32_t g = VM ? M : h;                       /* what a gap opens from: h in variant H (:1863,1866), M in variant M */
+        const uint32_t tD = pk_subs_vs(g, k.OED2s);
+        const uint32_t tI = SYM ? tD : pk_subs_vs(g, k.OEI2s);
         uint32_t en = pk_max(pk_subs_vs(e, k.ED2s), tD);     /* (:1866,1770-1771) */
-        f = pk_max(pk_subs_vs(f, k.ED2s), tD);               /* (:1863,1780-1781) */
+        f = pk_max(pk_subs_vs(f, SYM ? k.ED2s : k.EI2s), tI);   /* (:1863,1780-1781) */
         if (!EDGE) {
             const uint32_t key = and_or_vvs(h, k.HI2, JJ);   /* row max of this block, ties -> later j */
             mk = C ? pk_max(mk, key) : key;
@@ -398,7 +406,7 @@ struct lane2 {
             const int h1x = (int)((h1 >> (sh + 8)) & 0xffu);
             const int mk = (int)((mk2 >> sh) & 0xffffu);     /* (m << 8) | mj; m == 0: no positive cell */
             /* K7, branch-free: a data-dependent if/else here costs an exec-mask region plus register copies of the seed
-             * state on both sides; selects do not.  lane2_params_ok guarantees e_del == e_ins. */
+             * state on both sides; selects do not. */
             const bool atq = act & (imax(s.beg, s.end) == s.qlen);   /* ties -> later i (:1829-1833) */
             s.max_ie = (atq & (h1x >= s.gscore)) ? i : s.max_ie;
             s.gscore = atq ? imax(s.gscore, h1x) : s.gscore;
@@ -406,7 +414,9 @@ struct lane2 {
             const bool gt = act & (m > s.mx);
             const int doff = mj - i, off = imax(doff, -doff);
             const int dd = (i - s.max_i) - (mj - s.max_j), ad = imax(dd, -dd);   /* |di - dj| against the OLD maximum */
-            const bool zstop = (!gt) & (k.zdrop > 0) & (s.mx - m - mul24(ad, k.e_del) > k.zdrop);
+            /* rows ahead of the maximum by more than columns: a deletion's extension penalty, else an insertion's */
+            const int eg = SYM ? k.e_del : (dd > 0 ? k.e_del : k.e_ins);
+            const bool zstop = (!gt) & (k.zdrop > 0) & (s.mx - m - mul24(ad, eg) > k.zdrop);
             const bool stop = (m == 0) | zstop;              /* (:1942) */
             s.max_off = gt ? imax(s.max_off, off) : s.max_off;
             s.max_i = gt ? i : s.max_i;

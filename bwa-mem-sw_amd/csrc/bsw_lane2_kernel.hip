@@ -65,14 +65,14 @@ __device__ __forceinline__ uint32_t nib_plane(uint64_t w, int b)
 
 #define BSW_L2_TCHUNK 4         /* target words staged per seed in LDS = 64 DP rows */
 
-template <int QB, int WPS>
+template <int QB, int WPS, bool VM, bool SYM>
 __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P, const int side,
                                                              const uint64_t *__restrict__ seq,
                                                              const bsw_dtask *__restrict__ tasks,
                                                              const uint32_t *__restrict__ order, const uint32_t n,
                                                              bsw_result *__restrict__ out)
 {
-    using L = l2::lane2<QB>;
+    using L = l2::lane2<QB, VM, SYM>;
     constexpr int QMAX = L::QMAX, NW = L::NW, NC = L::NC;
     static_assert(QMAX <= BSW_LANE_QBINS && QMAX <= 256, "row-max key and binning assume at most 256 eh[] columns");
     __shared__ uint64_t lds_t[4][2][BSW_L2_TCHUNK][64];             /* [wave][seed][word][lane] */
@@ -226,21 +226,27 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     });
 }
 
-/* what the packed formulation needs from the scoring parameters (everything else takes bsw_lane_kernel) */
+/* what the packed formulation needs from the scoring parameters (everything else takes bsw_lane_kernel): a bwa-style
+ * matrix and penalties that fit the 8 score bits.  Both recurrence variants and separate deletion / insertion penalties
+ * (the RTL's four-penalty datapath, sw_pe_array_proc_element.v:816-819) run here. */
 bool lane2_params_ok(const bsw_dparams &P, int variant)
 {
     static const bool off = getenv("BSW_NO_LANE2") != nullptr;
-    if (off || variant != BSW_VARIANT_H) return false;
-    if (P.o_del != P.o_ins || P.e_del != P.e_ins) return false;
+    if (off || (variant != BSW_VARIANT_H && variant != BSW_VARIANT_M)) return false;
     const int a = P.mat[0], pb = -P.mat[1], pn = -P.mat[24];
-    return a > 0 && pb >= 0 && pn >= 0 && pb >= pn && a + pb < 256 && P.o_del + P.e_del < 256;
+    return a > 0 && pb >= 0 && pn >= 0 && pb >= pn && a + pb < 256 && P.o_del + P.e_del < 256 && P.o_ins + P.e_ins < 256;
 }
 
-hipError_t launch_lane2(const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
+hipError_t launch_lane2(const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
                         uint32_t n, bsw_result *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL((bsw_lane2_kernel<17, 2>), dim3((n + 511u) / 512u), dim3(256), 0, s, P, side, seq, tasks, order, n, out);
+    const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins, vm = variant == BSW_VARIANT_M;
+    const dim3 grid((n + 511u) / 512u), block(256);
+    if (!vm && sym) hipLaunchKernelGGL((bsw_lane2_kernel<17, 2, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+    else if (!vm) hipLaunchKernelGGL((bsw_lane2_kernel<17, 2, false, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+    else if (sym) hipLaunchKernelGGL((bsw_lane2_kernel<17, 2, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+    else hipLaunchKernelGGL((bsw_lane2_kernel<17, 2, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
     return hipGetLastError();
 }
 

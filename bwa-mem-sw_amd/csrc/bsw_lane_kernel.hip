@@ -422,14 +422,14 @@ int lane_class_bits(int cls) { return kLaneClasses[cls].bits; }
 /* bsw_lane2_kernel.hip: two seeds per lane, packed 16-bit math — takes the 8-bit 136-column class whenever the
  * scoring parameters allow its formulation */
 bool lane2_params_ok(const bsw_dparams &P, int variant);
-hipError_t launch_lane2(const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
+hipError_t launch_lane2(const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
                         uint32_t n, bsw_result *out, hipStream_t s);
 
 hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
                        const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    if (cls == 0 && lane2_params_ok(P, variant)) return launch_lane2(P, side, seq, tasks, order, n, out, s);
+    if (cls == 0 && lane2_params_ok(P, variant)) return launch_lane2(P, variant, side, seq, tasks, order, n, out, s);
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins;
     switch (cls) {
     case 0: return launch_lane_c0(variant, sym, P, side, seq, tasks, order, n, out, s);

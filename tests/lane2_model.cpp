@@ -13,9 +13,9 @@
 
 using namespace bsw::l2;
 
-template <int QB>
+template <int QB, bool VM, bool SYM>
 struct wave_model {
-    using L = lane2<QB>;
+    using L = lane2<QB, VM, SYM>;
     struct lane_t {
         typename L::state S;
         uint32_t qp[2][3][L::NW];       // query bit planes
@@ -126,7 +126,14 @@ extern "C" int lane2_model_run(const bsw_params *p, const bsw_task *tasks, int s
                                const int32_t *h0s, bsw_ext *out)
 {
     if (!p || !tasks || !order || !out) return -1;
-    if (p->o_del != p->o_ins || p->e_del != p->e_ins || p->mat[1] > 0 || p->mat[24] > 0 || -p->mat[1] < -p->mat[24]) return -2;
-    for (size_t w0 = 0; w0 < n; w0 += 128) wave_model<17>::run(p, tasks, side, order, n, w0, h0s, out);
+    if (p->mat[1] > 0 || p->mat[24] > 0 || -p->mat[1] < -p->mat[24]) return -2;      /* lane2_params_ok */
+    if (p->o_del + p->e_del > 255 || p->o_ins + p->e_ins > 255 || p->mat[0] - p->mat[1] > 255) return -2;
+    const bool sym = p->o_del == p->o_ins && p->e_del == p->e_ins, vm = p->variant == BSW_VARIANT_M;
+    for (size_t w0 = 0; w0 < n; w0 += 128) {
+        if (!vm && sym) wave_model<17, false, true>::run(p, tasks, side, order, n, w0, h0s, out);
+        else if (!vm) wave_model<17, false, false>::run(p, tasks, side, order, n, w0, h0s, out);
+        else if (sym) wave_model<17, true, true>::run(p, tasks, side, order, n, w0, h0s, out);
+        else wave_model<17, true, false>::run(p, tasks, side, order, n, w0, h0s, out);
+    }
     return 0;
 }

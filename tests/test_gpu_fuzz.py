@@ -36,8 +36,9 @@ def test_fuzz_parameters_and_shapes(host, oracle, block):
 
 @pytest.mark.parametrize("block", range(8))
 def test_fuzz_two_seeds_per_lane_kernel(host, oracle, block):
-    """The packed kernel's own parameter space (variant H, symmetric gaps, 0 >= N score >= -b): random scoring, band,
-    z-drop, clip penalties and seed shapes on both sides of its 8-bit score bound, forced lane bins."""
+    """The packed kernel's own parameter space (both variants, shared or separate deletion / insertion penalties,
+    0 >= N score >= -b): random scoring, band, z-drop, clip penalties and seed shapes on both sides of its 8-bit score
+    bound, forced lane bins."""
     rng = np.random.default_rng(12000 + block)
     with host.BswContext(device=0, kernel=host.KERNEL_LANE) as lctx:
         for it in range(5):
@@ -45,9 +46,11 @@ def test_fuzz_two_seeds_per_lane_kernel(host, oracle, block):
             b = int(rng.integers(0, 9))
             nsc = -int(rng.integers(0, b + 1))
             o, e = int(rng.integers(0, 16)), int(rng.integers(1, 7))
-            over = dict(o_del=o, e_del=e, o_ins=o, e_ins=e, w=int(rng.choice([1, 2, 7, 20, 100, 300])),
+            kind = (block * 5 + it) % 4                      # H/sym, M/sym, H/asym, M/asym in turn: the four kernel instantiations
+            oi, ei = (o, e) if kind < 2 else (int(rng.integers(0, 16)), int(rng.integers(1, 7)))
+            over = dict(o_del=o, e_del=e, o_ins=oi, e_ins=ei, w=int(rng.choice([1, 2, 7, 20, 100, 300])),
                         zdrop=int(rng.choice([0, 1, 10, 50, 100, 1000])), pen_clip5=int(rng.integers(0, 15)),
-                        pen_clip3=int(rng.integers(0, 15)), max_band_try=int(rng.integers(1, 4)), variant=0)
+                        pen_clip3=int(rng.integers(0, 15)), max_band_try=int(rng.integers(1, 4)), variant=kind & 1)
             p = host.default_params(**over)
             p["mat"][0] = host.bwa_matrix(a=a, b=b, n=nsc)
             seeds = _gen.random_seeds(rng, 1500, qmin=1, qmax=int(rng.choice([12, 60, 134])), tfac=float(rng.choice([1.0, 1.6, 2.4])),

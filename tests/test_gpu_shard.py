@@ -80,11 +80,11 @@ def test_bench_gpus_2_without_torchrun_runs_two_ranks():
     common = ["--share-gpu", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-extra"]
     weak = _bench("--gpus", "2", "--tasks", "60000", *common)
     assert weak["n_gpus"] == 2 and weak["world_size"] == 2 and weak["scaling"] == "weak"
-    assert round(weak["seeds_per_s"] * weak["ms_per_step"] / 1e3) == 120000
+    assert abs(weak["seeds_per_s"] * weak["ms_per_step"] / 1e3 - 120000) < 60          # both ranks' seeds (ms_per_step is rounded)
     # configs[3] shape at a small pool: one pool, chunk c -> rank c mod 2, several resident batches per rank
     strong = _bench("--gpus", "2", "--preset", "configs3", "--pool", "700000", "--resident-chunks", "2", *common)
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["config"]["pool_seeds"] == 700000
     assert strong["config"]["resident_batches_per_rank"] == 2
-    assert round(strong["seeds_per_s"] * strong["ms_per_step"] / 1e3) == 700000
+    assert abs(strong["seeds_per_s"] * strong["ms_per_step"] / 1e3 - 700000) < 350
     one = _bench("--gpus", "1", "--preset", "configs3", "--pool", "700000", "--resident-chunks", "2", *common[2:])
     assert one["n_gpus"] == 1 and one["cells_per_step"] == strong["cells_per_step"]      # same pool, same cells, however it is sharded

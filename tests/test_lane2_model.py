@@ -60,6 +60,12 @@ def check(model, host, oracle, p, tasks):
 @pytest.mark.parametrize("over", [
     dict(), dict(zdrop=0), dict(w=5), dict(w=17, zdrop=0), dict(w=1), dict(w=40, zdrop=30),
     dict(o_del=4, e_del=2, o_ins=4, e_ins=2), dict(o_del=0, e_del=1, o_ins=0, e_ins=1), dict(o_del=11, e_del=3, o_ins=11, e_ins=3, w=25),
+    # variant M (bwa >= 0.7.9) and separate deletion / insertion penalties (the RTL's four-penalty datapath,
+    # sw_pe_array_proc_element.v:816-819), alone and together
+    dict(variant=1), dict(variant=1, zdrop=0), dict(variant=1, w=7), dict(variant=1, o_del=4, e_del=2, o_ins=4, e_ins=2, zdrop=40),
+    dict(o_del=6, e_del=1, o_ins=4, e_ins=2), dict(o_del=2, e_del=3, o_ins=9, e_ins=1, zdrop=25), dict(o_del=0, e_del=2, o_ins=5, e_ins=1, w=12),
+    dict(variant=1, o_del=6, e_del=1, o_ins=4, e_ins=2), dict(variant=1, o_del=3, e_del=2, o_ins=8, e_ins=1, zdrop=20, w=30),
+    dict(variant=1, o_del=9, e_del=1, o_ins=1, e_ins=4, zdrop=0),
 ])
 def test_random_seeds_match_the_oracle(model, host, oracle, over):
     rng = np.random.default_rng(abs(hash(str(sorted(over.items())))) % (2 ** 31))
@@ -72,8 +78,9 @@ def test_random_seeds_match_the_oracle(model, host, oracle, over):
     check(model, host, oracle, p, tasks)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("ab_n", [(1, 4, -1), (2, 3, -1), (1, 1, 0), (1, 6, -2), (3, 5, -5)])
-def test_scoring_matrices(model, host, oracle, ab_n):
+def test_scoring_matrices(model, host, oracle, ab_n, variant):
     a, b, nn = ab_n
     rng = np.random.default_rng(a * 100 + b)
     seeds = _gen.random_seeds(rng, 400, qmin=1, qmax=135 // a, tfac=2.0, sub=0.05, indel=0.02, junk=0.1, nrate=0.01, h0max=40)
@@ -81,18 +88,38 @@ def test_scoring_matrices(model, host, oracle, ab_n):
         tot = len(s.get("lq", ())) + len(s.get("rq", ()))
         s["h0"] = max(1, min(s["h0"], 255 - b - tot * a))
     tasks, arena = host.make_tasks(seeds)
-    p = host.default_params()
+    p = host.default_params(variant=variant)
+    if variant:
+        p["o_ins"], p["e_ins"] = 3, 2
     p["mat"][0] = host.bwa_matrix(a, b, nn)
     check(model, host, oracle, p, tasks)
 
 
-def test_bench_workload_shapes(model, host, oracle):
+@pytest.mark.parametrize("over", [dict(), dict(variant=1), dict(o_del=5, e_del=2, o_ins=7, e_ins=1), dict(variant=1, o_del=5, e_del=2, o_ins=7, e_ins=1)])
+def test_bench_workload_shapes(model, host, oracle, over):
     """The synthetic workloads bench.py times: single bin (qlen 131 / tlen 257) and mixed PE bins with Ns."""
-    p = host.default_params()
+    p = host.default_params(**over)
     tasks, arena = host.synth_tasks(1500, seed=3)
     check(model, host, oracle, p, tasks)
     tasks, arena = host.synth_tasks(1500, seed=4, seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.1, n_rate=0.002)
     check(model, host, oracle, p, tasks)
+
+
+def test_variants_differ_where_they_should(model, host, oracle):
+    """Variant H lifts a zero H(i-1,j-1) by a match, variant M does not: on indel-rich seeds the two must disagree
+    somewhere (or the M path is not exercised) and each must equal the oracle's own variant."""
+    rng = np.random.default_rng(77)
+    seeds = _gen.random_seeds(rng, 1500, qmin=20, qmax=135, tfac=2.2, sub=0.06, indel=0.05, junk=0.2, nrate=0.0, h0max=30)
+    for s in seeds:
+        tot = len(s.get("lq", ())) + len(s.get("rq", ()))
+        s["h0"] = max(1, min(s["h0"], 255 - 4 - tot))
+    tasks, arena = host.make_tasks(seeds)
+    pH, pM = host.default_params(zdrop=0), host.default_params(zdrop=0, variant=1)
+    gotH, idx = run_side(model, host, pH, tasks, 1)
+    gotM, _ = run_side(model, host, pM, tasks, 1)
+    assert gotH[idx].tobytes() != gotM[idx].tobytes()
+    check(model, host, oracle, pH, tasks)
+    check(model, host, oracle, pM, tasks)
 
 
 def test_right_side_starts_from_the_left_score(model, host, oracle):
