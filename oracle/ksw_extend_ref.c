@@ -145,6 +145,17 @@ int ksw_extend2_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *tar
                         qle_, tle_, gtle_, gscore_, max_off_, variant, cells_, 0);
 }
 
+/* the same with the RTL's H5/H6 band limit in place of the formula (wlim > 0), as side_ref calls it */
+int ksw_extend2_wlim_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
+                         int m, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins,
+                         int w, int end_bonus, int zdrop, int h0,
+                         int *qle_, int *tle_, int *gtle_, int *gscore_, int *max_off_,
+                         int variant, uint64_t *cells_, int wlim)
+{
+    return extend2_core(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop, h0,
+                        qle_, tle_, gtle_, gscore_, max_off_, variant, cells_, wlim);
+}
+
 int ksw_extend_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
                    int m, const int8_t *mat, int gapo, int gape,
                    int w, int end_bonus, int zdrop, int h0,

@@ -42,6 +42,15 @@ int ksw_extend_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
                    int *qle, int *tle, int *gtle, int *gscore, int *max_off,
                    int variant, uint64_t *cells);
 
+int ksw_extend2_wlim_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
+                         int m, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins,
+                         int w, int end_bonus, int zdrop, int h0,
+                         int *qle, int *tle, int *gtle, int *gscore, int *max_off,
+                         int variant, uint64_t *cells, int wlim);
+
+/* Strong CPU baseline (oracle/ksw_extend_avx2.c): the same batch, 16 seeds per AVX2 register; same bytes out. */
+void bsw_pair_batch_avx2(const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out, int nthreads);
+
 /* bwa's banded global alignment with CIGAR (oracle/ksw_global_ref.c).  *cigar_ is malloc'ed. */
 int ksw_global2_ref(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
                     int o_del, int e_del, int o_ins, int e_ins, int w, int *n_cigar_, uint32_t **cigar_, uint64_t *cells_);

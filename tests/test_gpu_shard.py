@@ -86,5 +86,5 @@ def test_bench_gpus_2_without_torchrun_runs_two_ranks():
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["config"]["pool_seeds"] == 700000
     assert strong["config"]["resident_batches_per_rank"] == 2
     assert abs(strong["seeds_per_s"] * strong["ms_per_step"] / 1e3 - 700000) < 350
-    one = _bench("--gpus", "1", "--preset", "configs3", "--pool", "700000", "--resident-chunks", "2", *common[2:])
+    one = _bench("--gpus", "1", "--preset", "configs3", "--pool", "700000", "--resident-chunks", "2", *common[3:])
     assert one["n_gpus"] == 1 and one["cells_per_step"] == strong["cells_per_step"]      # same pool, same cells, however it is sharded
