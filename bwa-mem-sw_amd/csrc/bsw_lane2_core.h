@@ -76,6 +76,13 @@ L2_FN uint32_t key_of(uint32_t h, uint32_t jj) { uint32_t d; asm("v_lshl_or_b32 
 L2_FN uint32_t ffbl(uint32_t x) { uint32_t d; asm("v_ffbl_b32 %0, %1" : "=v"(d) : "v"(x)); return d; }
 L2_FN uint32_t ffbh(uint32_t x) { uint32_t d; asm("v_ffbh_u32 %0, %1" : "=v"(d) : "v"(x)); return d; }   /* counted from the MSB */
 L2_FN int mul24(int a, int b) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }   /* both factors fit 24 bits: one full-rate op, not a 64-bit mad */
+L2_FN uint32_t pk_adds_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_pk_add_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "s"(sb)); return d; }   /* saturating */
+L2_FN uint32_t pk_sub_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(sb)); return d; }          /* wrapping */
+L2_FN uint32_t pk_neg(uint32_t a) { uint32_t d; asm("v_pk_sub_u16 %0, 0, %1" : "=v"(d) : "v"(a)); return d; }                                     /* 0 - a per half */
+/* byte k of a in bits [7:0], byte k of b in bits [23:16], zeros elsewhere, k = sel & 3 chosen at run time (selector in an SGPR) */
+L2_FN uint32_t byte_pair_dyn(uint32_t a, uint32_t b, uint32_t k) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(0x0c000c00u + k * 0x00010001u + 0x00040000u)); return d; }
+L2_FN int popc(uint32_t x) { return __builtin_popcount(x); }
+L2_FN int clz32(uint32_t x) { return __builtin_clz(x); }
 /* a wave-uniform value the compiler must re-read here: keeps tests on it from being hoisted out of the row loop */
 L2_FN uint32_t opaque_s(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
 #else
@@ -106,6 +113,12 @@ L2_FN uint32_t ffbl(uint32_t x) { return x ? (uint32_t)__builtin_ctz(x) : 0xffff
 L2_FN uint32_t ffbh(uint32_t x) { return x ? (uint32_t)__builtin_clz(x) : 0xffffffffu; }
 L2_FN int mul24(int a, int b) { return a * b; }
 L2_FN uint32_t opaque_s(uint32_t x) { return x; }
+L2_FN uint32_t pk_adds_vs(uint32_t a, uint32_t sb) { const uint32_t lo = lo16(a) + lo16(sb), hi = hi16(a) + hi16(sb); return mk2(lo > 0xffffu ? 0xffffu : lo, hi > 0xffffu ? 0xffffu : hi); }
+L2_FN uint32_t pk_sub_vs(uint32_t a, uint32_t sb) { return pk_sub(a, sb); }
+L2_FN uint32_t pk_neg(uint32_t a) { return pk_sub(0u, a); }
+L2_FN uint32_t byte_pair_dyn(uint32_t a, uint32_t b, uint32_t k) { return ((a >> (8 * k)) & 0xffu) | (((b >> (8 * k)) & 0xffu) << 16); }
+L2_FN int popc(uint32_t x) { return __builtin_popcount(x); }
+L2_FN int clz32(uint32_t x) { return __builtin_clz(x); }
 #endif
 
 L2_FN uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x00010001u; }
@@ -437,6 +450,174 @@ struct lane2 {
                 fnzu = cf < fnzu ? cf : fnzu;
                 lnz = imax(lnz, cl);
             });
+            const int fnz = fnzu < (uint32_t)s.end ? (int)fnzu : s.end;
+            const int nbeg = fnz;
+            const int last = lnz >= nbeg ? lnz : nbeg - 1;
+            s.beg = act ? nbeg : s.beg;
+            s.end = act ? imin(last + 2, s.qlen) : s.end;
+            s.alive = act ? !stop : s.alive;
+        });
+    }
+};
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * lane2l: the same two-seeds-per-lane arithmetic with the 8-column blocks walked by a RUN-TIME LOOP instead of unrolled
+ * code.  The eh[] row does not live in a C++ array but behind a `ROW` accessor: on the GPU that is the accumulator
+ * register file addressed through the VGPR index mode (s_set_gpr_idx_on: M0 offsets the AccVGPR number of
+ * v_accvgpr_read/_write — bsw_lane2l_kernel.hip), on the CPU model a plain array.  One copy of each block body serves
+ * every block, so the hot code is a few KB whatever the class width: the unrolled kernel's 232-column instantiation
+ * spends half its time in instruction-cache misses at one wave per SIMD (profiles/r3/lane2_wide_icache.json).
+ *   ROW::load8(b, T)            T[c] = eh[8b + c]
+ *   ROW::store8(b, T)           eh[8b + c] = T[c]
+ *   ROW::swap8(b, T)            eh[8b + c] = T[c], then T[c] = eh[8b + 8 + c]   (one statement: the next block's columns)
+ *   ROW::put_rm(wd, a, b)       this row's match words (32 columns each) of seed A / B, word index static
+ *   ROW::get_rm(wd, a, b)       the same, word index chosen at run time
+ * Everything that was indexed by the block number at compile time is either block-relative already (key, bit and end
+ * constants) or folded as it goes: the row max with the absolute column added per block, the first / last non-zero
+ * column as a packed running minimum / maximum (K8). */
+template <int QB, bool VM = false, bool SYM = true>
+struct lane2l {
+    using B = lane2<QB, VM, SYM>;
+    static constexpr int QMAX = B::QMAX, NW = B::NW, NC = B::NC, KEEP_NONE = B::KEEP_NONE;
+
+    struct state { seedv s[2]; };
+
+    /* K2 first row, closed form, block by block (sw_pe_array_sw_extend.v:1979,1957,1974) */
+    template <class ROW>
+    L2_MFN void init_row(const state &S, const consts &k, ROW &row)
+    {
+        for (int b = 0; b < QB; ++b) {
+            uint32_t T[8];
+            sfor<8>([&](auto ci) {
+                constexpr int c = decltype(ci)::value;
+                const int j = 8 * b + c;
+                const int v0 = j == 0 ? S.s[0].h0 : imax(S.s[0].h0 - k.oe_ins - (j - 1) * k.e_ins, 0);
+                const int v1 = j == 0 ? S.s[1].h0 : imax(S.s[1].h0 - k.oe_ins - (j - 1) * k.e_ins, 0);
+                T[c] = pack2(v0, v1);
+            });
+            row.store8(b, T);
+        }
+    }
+
+    /* the columns a band clamp dropped are zeroed (rare: only rows where the clamp moves some seed's beg) */
+    template <class ROW>
+    L2_MFN void zero_dropped(const rowv &r, const uni &u, ROW &row)
+    {
+        const int b0 = u.zl >> 3, b1 = (u.zh - 1) >> 3;
+        for (int b = b0; b <= b1 && b < QB; ++b) {
+            uint32_t T[8];
+            row.load8(b, T);
+            sfor<8>([&](auto ci) {
+                constexpr int c = decltype(ci)::value;
+                const int J = 8 * b + c;
+                uint32_t keep = 0xffffffffu;
+                if (r.bite[0] && J >= r.zlo[0] && J < r.zhi[0]) keep &= 0xffff0000u;
+                if (r.bite[1] && J >= r.zlo[1] && J < r.zhi[1]) keep &= 0x0000ffffu;
+                T[c] &= keep;
+            });
+            row.store8(b, T);
+        }
+    }
+
+    /* One DP row for both seeds (see lane2::row_body for the arithmetic; the cell is the same function). */
+    template <class QP, class KP, class WN, class ROW>
+    L2_MFN void row_body(state &S, const consts &k, const int i, const rowv &r, const uni &u, const int (&tb)[2],
+                         const QP &qp, const KP &kp, const WN &wn, ROW &row)
+    {
+        if (u.anybite) zero_dropped(r, u, row);
+        {
+            uint32_t rmA[NW], rmB[NW];
+            B::match_words(qp, kp, 0, tb[0], S.s[0].beg, rmA);
+            B::match_words(qp, kp, 1, tb[1], S.s[1].beg, rmB);
+            sfor<NW>([&](auto wi) { constexpr int wd = decltype(wi)::value; row.put_rm(wd, rmA[wd], rmB[wd]); });
+        }
+        const int pbA = tb[0] < 4 ? k.pb : k.pn, pbB = tb[1] < 4 ? k.pb : k.pn;
+        const uint32_t Bv2 = pack2(pbA, pbB) << 8, D2 = pack2(pbA - k.pn, pbB - k.pn) << 8;
+        const uint32_t END2 = pack2(S.s[0].end, S.s[1].end);
+        const int hi0 = S.s[0].beg == 0 ? imax(S.s[0].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
+        const int hi1 = S.s[1].beg == 0 ? imax(S.s[1].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
+        uint32_t h1 = pack2(hi0, hi1) << 8, f = 0;
+        L2_STAMP(2);
+        uint32_t mk2 = 0;                                   /* running row max: (m << 8) | absolute column, per half */
+        uint32_t Fnz = 0xffffffffu, Lnz = 0;                /* K8: packed first / last non-zero column trackers */
+        const int blo = u.jlo >> 3, bhi = imin(u.jhi >> 3, QB - 1), bem = u.jem >> 3;
+        const uint32_t nblk = opaque_s(u.nblk);
+        uint32_t T[8];
+        row.load8(blo, T);
+        for (int b = blo; b <= bhi; ++b) {
+            const uint32_t j0 = 8u * (uint32_t)b;
+            uint32_t wa, wb;
+            row.get_rm(b >> 2, wa, wb);
+            const uint32_t Wc = byte_pair_dyn(wa, wb, (uint32_t)b & 3u);
+            uint32_t mkb = 0, nz8 = 0, dummy = 0;
+            const bool dense = b < bem;
+            const bool nq = ((nblk >> b) & 1u) != 0;
+            const uint32_t J0d = j0 * 0x00010001u;
+            /* four mutually exclusive bodies as four consecutive `if`s, not an if/else tree: a body that is simply run or
+             * skipped updates T[] in place, an if/else joins differently allocated versions with a v_mov per column */
+            if (dense && !nq) {
+                sfor<8>([&](auto ci) { B::template cell<decltype(ci)::value, false, false>(T[decltype(ci)::value], Wc, 0u, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
+            }
+            if (dense && nq) {
+                const uint32_t WNr = wn(b >> 1);
+                const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;            /* cell() reads bit C of each half */
+                sfor<8>([&](auto ci) { B::template cell<decltype(ci)::value, false, true>(T[decltype(ci)::value], Wc, WNc, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
+            }
+            if (!dense && !nq) {
+                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, J0d);    /* mi of column j0 - 1 */
+                uint32_t mi_prev = pk_nzmask(d0);
+                const uint32_t ENDr = pk_subs_vs(END2, J0d);
+                sfor<8>([&](auto ci) { B::template cell<decltype(ci)::value, true, false>(T[decltype(ci)::value], Wc, 0u, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
+            }
+            if (!dense && nq) {
+                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, J0d);
+                uint32_t mi_prev = pk_nzmask(d0);
+                const uint32_t ENDr = pk_subs_vs(END2, J0d);
+                const uint32_t WNr = wn(b >> 1);
+                const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;
+                sfor<8>([&](auto ci) { B::template cell<decltype(ci)::value, true, true>(T[decltype(ci)::value], Wc, WNc, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
+            }
+            /* row max: the block's key carries the column inside the block; + j0 makes it absolute (< 256: low byte) */
+            mk2 = pk_max(mk2, mkb + J0d);
+            /* K8: nz8 = non-zero bits of the block's stored eh entries, seed A in [7:0], seed B in [23:16].
+             * first: lowest set bit isolated, minus one (2^k - 1; 0xffff for an empty block), plus j0 << 8, saturating:
+             *        an empty block gives 0xffff and never wins the minimum;
+             * last:  (j0 << 8) + bits for a non-empty block, 0 for an empty one: the maximum keeps the highest block.
+             * (Folding the bits per 32-column word as the unrolled kernel does, with the match words shifted along, was
+             * slower here: 1508 vs 1579 GCUPS on the 250 bp workload.) */
+            const uint32_t J0h = J0d << 8;
+            const uint32_t lb = pk_neg(nz8) & nz8;
+            Fnz = pk_min(Fnz, pk_adds_vs(pk_sub_vs(lb, k.ONE2), J0h));
+            Lnz = pk_max(Lnz, pk_mad_vsv(pk_min_vs(nz8, k.ONE2), J0h, nz8));
+            row.swap8(b, T);                                 /* eh[8b ..] <- T, T <- eh[8b + 8 ..] */
+        }
+        L2_STAMP(3);
+        sfor<2>([&](auto xi) {
+            constexpr int x = decltype(xi)::value;
+            const bool act = r.act[x];
+            seedv &s = S.s[x];
+            constexpr int sh = 16 * x;
+            const int h1x = (int)((h1 >> (sh + 8)) & 0xffu);
+            const int mk = (int)((mk2 >> sh) & 0xffffu);
+            const bool atq = act & (imax(s.beg, s.end) == s.qlen);
+            s.max_ie = (atq & (h1x >= s.gscore)) ? i : s.max_ie;
+            s.gscore = atq ? imax(s.gscore, h1x) : s.gscore;
+            const int m = mk >> 8, mj = mk & 255;
+            const bool gt = act & (m > s.mx);
+            const int doff = mj - i, off = imax(doff, -doff);
+            const int dd = (i - s.max_i) - (mj - s.max_j), ad = imax(dd, -dd);
+            const int eg = SYM ? k.e_del : (dd > 0 ? k.e_del : k.e_ins);
+            const bool zstop = (!gt) & (k.zdrop > 0) & (s.mx - m - mul24(ad, eg) > k.zdrop);
+            const bool stop = (m == 0) | zstop;
+            s.max_off = gt ? imax(s.max_off, off) : s.max_off;
+            s.max_i = gt ? i : s.max_i;
+            s.max_j = gt ? mj : s.max_j;
+            s.mx = gt ? m : s.mx;
+            /* K8 next-row range from the packed trackers */
+            const uint32_t Fx = (Fnz >> sh) & 0xffffu, Lx = (Lnz >> sh) & 0xffffu;
+            const uint32_t fnzu = Fx == 0xffffu ? 0xffffffffu : (Fx >> 8) + (uint32_t)popc(Fx & 0xffu);
+            const int lnz = Lx == 0 ? -1 : (int)(Lx >> 8) + (31 - clz32(Lx & 0xffu));
             const int fnz = fnzu < (uint32_t)s.end ? (int)fnzu : s.end;
             const int nbeg = fnz;
             const int last = lnz >= nbeg ? lnz : nbeg - 1;

@@ -76,17 +76,21 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     constexpr int QMAX = L::QMAX, NW = L::NW, NC = L::NC;
     static_assert(QMAX <= BSW_LANE_QBINS && QMAX <= 256, "row-max key and binning assume at most 256 eh[] columns");
     __shared__ uint64_t lds_t[4][2][BSW_L2_TCHUNK][64];             /* [wave][seed][word][lane] */
-    static_assert(NW == 5, "match-word staging below is laid out for 5 words (129..160 columns)");
-    __shared__ uint4 lds_m4[4][2][4][64];                           /* per-base match words 0..3: [wave][seed][base][lane] */
-    __shared__ uint32_t lds_m1[4][2][4][64];                        /* per-base match word 4 */
+    /* per-base match words of both queries: NQ4 quads of four words + NR single words per (wave, seed, base, lane) */
+    constexpr int NQ4 = NW / 4, NR = NW % 4;
+    __shared__ uint4 lds_m4[4][2][4][NQ4][64];
+    __shared__ uint32_t lds_m1[4][2][4][NR ? NR : 1][64];
     __shared__ uint32_t lds_wn[4][NC][64];                          /* N planes of both seeds, 16 columns per half */
-    __shared__ uint4 lds_k4[L::KEEP_NONE + 1];                      /* keep-mask table (match_words): words 0..3 / word 4 of entry b */
-    __shared__ uint32_t lds_k1[L::KEEP_NONE + 1];
+    __shared__ uint4 lds_k4[NQ4][L::KEEP_NONE + 1];                 /* keep-mask table (match_words), same split */
+    __shared__ uint32_t lds_k1[NR ? NR : 1][L::KEEP_NONE + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t w0 = (blockIdx.x * 4u + (uint32_t)wv) * 128u + (uint32_t)lane;
     for (int b = (int)threadIdx.x; b <= L::KEEP_NONE; b += 256) {
-        lds_k4[b] = make_uint4(L::keep_word(b, 0), L::keep_word(b, 1), L::keep_word(b, 2), L::keep_word(b, 3));
-        lds_k1[b] = L::keep_word(b, 4);
+#pragma unroll
+        for (int q4 = 0; q4 < NQ4; ++q4)
+            lds_k4[q4][b] = make_uint4(L::keep_word(b, 4 * q4), L::keep_word(b, 4 * q4 + 1), L::keep_word(b, 4 * q4 + 2), L::keep_word(b, 4 * q4 + 3));
+#pragma unroll
+        for (int r1 = 0; r1 < NR; ++r1) lds_k1[r1][b] = L::keep_word(b, 4 * NQ4 + r1);
     }
     __syncthreads();                                                /* the only barrier: the table is shared by the four waves */
 
@@ -134,8 +138,11 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            lds_m4[wv][x][b][lane] = make_uint4(mb[b][0], mb[b][1], mb[b][2], mb[b][3]);
-            lds_m1[wv][x][b][lane] = mb[b][4];
+#pragma unroll
+            for (int q4 = 0; q4 < NQ4; ++q4)
+                lds_m4[wv][x][b][q4][lane] = make_uint4(mb[b][4 * q4], mb[b][4 * q4 + 1], mb[b][4 * q4 + 2], mb[b][4 * q4 + 3]);
+#pragma unroll
+            for (int r1 = 0; r1 < NR; ++r1) lds_m1[wv][x][b][r1][lane] = mb[b][4 * NQ4 + r1];
         }
     });
 #pragma unroll
@@ -149,14 +156,22 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     L::init_row(S, k);
 
     const auto qp = [&](int x, int b, uint32_t (&rm)[NW]) {
-        const uint4 v = lds_m4[wv][x][b][lane];
-        rm[0] = v.x; rm[1] = v.y; rm[2] = v.z; rm[3] = v.w;
-        rm[4] = lds_m1[wv][x][b][lane];
+#pragma unroll
+        for (int q4 = 0; q4 < NQ4; ++q4) {
+            const uint4 v = lds_m4[wv][x][b][q4][lane];
+            rm[4 * q4] = v.x; rm[4 * q4 + 1] = v.y; rm[4 * q4 + 2] = v.z; rm[4 * q4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int r1 = 0; r1 < NR; ++r1) rm[4 * NQ4 + r1] = lds_m1[wv][x][b][r1][lane];
     };
     const auto kp = [&](int b, uint32_t (&kw)[NW]) {
-        const uint4 v = lds_k4[b];
-        kw[0] = v.x; kw[1] = v.y; kw[2] = v.z; kw[3] = v.w;
-        kw[4] = lds_k1[b];
+#pragma unroll
+        for (int q4 = 0; q4 < NQ4; ++q4) {
+            const uint4 v = lds_k4[q4][b];
+            kw[4 * q4] = v.x; kw[4 * q4 + 1] = v.y; kw[4 * q4 + 2] = v.z; kw[4 * q4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int r1 = 0; r1 < NR; ++r1) kw[4 * NQ4 + r1] = lds_k1[r1][b];
     };
     const auto wn = [&](int c) { return lds_wn[wv][c][lane]; };
     uint64_t tw[2] = {0ull, 0ull};
@@ -235,6 +250,16 @@ bool lane2_params_ok(const bsw_dparams &P, int variant)
     if (off || (variant != BSW_VARIANT_H && variant != BSW_VARIANT_M)) return false;
     const int a = P.mat[0], pb = -P.mat[1], pn = -P.mat[24];
     return a > 0 && pb >= 0 && pn >= 0 && pb >= pn && a + pb < 256 && P.o_del + P.e_del < 256 && P.o_ins + P.e_ins < 256;
+}
+
+/* the 232-column class (250 bp reads): the same kernel at one wave per SIMD (232 row registers + working set > 256) */
+hipError_t launch_lane2_wide(const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
+                             uint32_t n, bsw_result *out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const dim3 grid((n + 511u) / 512u), block(256);
+    hipLaunchKernelGGL((bsw_lane2_kernel<29, 1, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_lane2(const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,

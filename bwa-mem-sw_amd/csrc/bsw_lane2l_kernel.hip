@@ -1,0 +1,328 @@
+/*
+ * bsw_lane2l_kernel.hip — gfx950 kernel: two extensions per lane (as bsw_lane2_kernel.hip), 8-column blocks walked by a
+ * RUN-TIME LOOP, eh[] row in the ACCUMULATOR register file.
+ *
+ * Why: the unrolled kernel's code grows with the class width (356 KB for 232 columns) and at one wave per SIMD — all a
+ * 232-register row leaves room for — half of its time is instruction-cache misses (profiles/r3/lane2_wide_*).  gfx950
+ * still has the VGPR index mode of gfx9: between s_set_gpr_idx_on and _off, M0[7:0] is added to the register number of
+ * the operand slots the mode names, and that includes the AccVGPR operand of v_accvgpr_read / v_accvgpr_write
+ * (tools/ubench/gpr_idx.hip).  So the row lives in a[0 .. QMAX+7], this row's match words in the AccVGPRs behind it, and
+ * ONE copy of each block body (dense / edge / with query Ns) serves every block: per block eight v_accvgpr_write (the
+ * columns just computed), eight v_accvgpr_read (the next block's), two more reads for the match words.  The compiler
+ * never allocates AccVGPRs here (the kernel needs < 256 VGPRs; audited in the build: no compiler v_accvgpr_*, no
+ * scratch), the reservation statement below makes the kernel descriptor allocate them.
+ * The per-lane arithmetic is lane2l in bsw_lane2_core.h (shared with the CPU model of the tests; the DP cell itself is
+ * the unrolled kernel's function).  The reference's PE handles qlen <= 255 in one datapath (sw_pe_array_sw_extend.v:101-102).
+ */
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "bsw_device.h"
+#define L2_STAMP(k) ((void)0)
+#include "bsw_lane2_core.h"
+
+namespace bsw {
+
+namespace {
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp2l(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ int wave_max2l(int x)
+{
+    x = max(x, dpp2l<0x111>(INT_MIN, x));
+    x = max(x, dpp2l<0x112>(INT_MIN, x));
+    x = max(x, dpp2l<0x114>(INT_MIN, x));
+    x = max(x, dpp2l<0x118>(INT_MIN, x));
+    x = max(x, dpp2l<0x142, 0xa>(INT_MIN, x));
+    x = max(x, dpp2l<0x143, 0xc>(INT_MIN, x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+/* every 4th bit of a 64-bit word (bit `b` of each nibble) gathered into 16 contiguous bits */
+__device__ __forceinline__ uint32_t nib_plane_l(uint64_t w, int b)
+{
+    uint64_t x = (w >> b) & 0x1111111111111111ull;
+    x = (x | (x >> 3)) & 0x0303030303030303ull;
+    x = (x | (x >> 6)) & 0x000F000F000F000Full;
+    x = (x | (x >> 12)) & 0x000000FF000000FFull;
+    x = (x | (x >> 24)) & 0xFFFFull;
+    return (uint32_t)x;
+}
+
+/* The eh[] row in AccVGPRs a[0 .. QMAX+7] (the last eight are slack: swap8 of the last block reads past the row), the
+ * match words of the current row in a[RM .. RM+2NW).  Register numbers in the strings are RELATIVE: the index mode adds
+ * M0[7:0] (= 8b, or the word number) to the slot it is enabled for — 0x1 = SRC0 (the AccVGPR of a read), 0x8 = VDST (the
+ * AccVGPR of a write); the VGPR side of each instruction sits in the other slot and is not offset. */
+template <int QMAX, int NW>
+struct acc_row {
+    static constexpr int RM = QMAX + 8;
+    __device__ __forceinline__ void load8(int b, uint32_t (&T)[8]) const
+    {
+        asm volatile("s_set_gpr_idx_on %8, 0x1\n\ts_nop 0\n\t"
+                     "v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\t"
+                     "v_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\t"
+                     "s_set_gpr_idx_off"
+                     : "=v"(T[0]), "=v"(T[1]), "=v"(T[2]), "=v"(T[3]), "=v"(T[4]), "=v"(T[5]), "=v"(T[6]), "=v"(T[7])
+                     : "s"(8 * b));
+    }
+    __device__ __forceinline__ void store8(int b, const uint32_t (&T)[8])
+    {
+        asm volatile("s_set_gpr_idx_on %8, 0x8\n\ts_nop 0\n\t"
+                     "v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %1\n\tv_accvgpr_write_b32 a2, %2\n\tv_accvgpr_write_b32 a3, %3\n\t"
+                     "v_accvgpr_write_b32 a4, %4\n\tv_accvgpr_write_b32 a5, %5\n\tv_accvgpr_write_b32 a6, %6\n\tv_accvgpr_write_b32 a7, %7\n\t"
+                     "s_set_gpr_idx_off"
+                     :
+                     : "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]), "v"(T[5]), "v"(T[6]), "v"(T[7]), "s"(8 * b));
+    }
+    /* block b's columns out, block b+1's in: one index value serves both (the reads name a8..a15) */
+    __device__ __forceinline__ void swap8(int b, uint32_t (&T)[8])
+    {
+        asm volatile("s_set_gpr_idx_on %8, 0x8\n\ts_nop 0\n\t"
+                     "v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %1\n\tv_accvgpr_write_b32 a2, %2\n\tv_accvgpr_write_b32 a3, %3\n\t"
+                     "v_accvgpr_write_b32 a4, %4\n\tv_accvgpr_write_b32 a5, %5\n\tv_accvgpr_write_b32 a6, %6\n\tv_accvgpr_write_b32 a7, %7\n\t"
+                     "s_set_gpr_idx_mode 0x1\n\ts_nop 0\n\t"
+                     "v_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9\n\tv_accvgpr_read_b32 %2, a10\n\tv_accvgpr_read_b32 %3, a11\n\t"
+                     "v_accvgpr_read_b32 %4, a12\n\tv_accvgpr_read_b32 %5, a13\n\tv_accvgpr_read_b32 %6, a14\n\tv_accvgpr_read_b32 %7, a15\n\t"
+                     "s_set_gpr_idx_off"
+                     : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7])
+                     : "s"(8 * b));
+    }
+    template <int WD>
+    __device__ __forceinline__ void put_rm_s(uint32_t a, uint32_t b)
+    {
+        asm volatile("v_accvgpr_write_b32 a[%c2], %0\n\tv_accvgpr_write_b32 a[%c3], %1" : : "v"(a), "v"(b), "i"(RM + WD), "i"(RM + NW + WD));
+    }
+    __device__ __forceinline__ void put_rm(int wd, uint32_t a, uint32_t b)
+    {
+        /* wd is a compile-time constant at every call site (sfor): dispatch to the literal register numbers */
+        l2::sfor<NW>([&](auto wi) { if (decltype(wi)::value == wd) put_rm_s<decltype(wi)::value>(a, b); });
+    }
+    __device__ __forceinline__ void get_rm(int wd, uint32_t &a, uint32_t &b) const
+    {
+        asm volatile("s_set_gpr_idx_on %2, 0x1\n\ts_nop 0\n\t"
+                     "v_accvgpr_read_b32 %0, a[%c3]\n\tv_accvgpr_read_b32 %1, a[%c4]\n\t"
+                     "s_set_gpr_idx_off"
+                     : "=v"(a), "=v"(b)
+                     : "s"(wd), "i"(RM), "i"(RM + NW));
+    }
+};
+
+}  // namespace
+
+#define BSW_L2_TCHUNK 4         /* target words staged per seed in LDS = 64 DP rows */
+
+template <int QB, int WPS, bool VM, bool SYM>
+__global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams P, const int side,
+                                                              const uint64_t *__restrict__ seq,
+                                                              const bsw_dtask *__restrict__ tasks,
+                                                              const uint32_t *__restrict__ order, const uint32_t n,
+                                                              bsw_result *__restrict__ out)
+{
+    using L = l2::lane2l<QB, VM, SYM>;
+    using LB = typename L::B;
+    constexpr int QMAX = L::QMAX, NW = L::NW, NC = L::NC;
+    static_assert(QMAX <= BSW_LANE_QBINS && QMAX <= 232, "row + slack + match words must fit the 256 AccVGPRs");
+    /* the accumulator registers this kernel owns (listing them makes the kernel descriptor allocate them) */
+    if constexpr (QMAX + 8 + 2 * NW <= 160) asm volatile("; AccVGPRs a0..a159: eh[] row + match words" : : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
+    else asm volatile("; AccVGPRs a0..a255: eh[] row + match words" : : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+    __shared__ uint64_t lds_t[4][2][BSW_L2_TCHUNK][64];             /* [wave][seed][word][lane] */
+    constexpr int NQ4 = NW / 4, NR = NW % 4;
+    __shared__ uint4 lds_m4[4][2][4][NQ4][64];
+    __shared__ uint32_t lds_m1[4][2][4][NR ? NR : 1][64];
+    __shared__ uint32_t lds_wn[4][NC][64];                          /* N planes of both seeds, 16 columns per half */
+    __shared__ uint4 lds_k4[NQ4][L::KEEP_NONE + 1];                 /* keep-mask table (match_words) */
+    __shared__ uint32_t lds_k1[NR ? NR : 1][L::KEEP_NONE + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t w0 = (blockIdx.x * 4u + (uint32_t)wv) * 128u + (uint32_t)lane;
+    for (int b = (int)threadIdx.x; b <= L::KEEP_NONE; b += 256) {
+#pragma unroll
+        for (int q4 = 0; q4 < NQ4; ++q4)
+            lds_k4[q4][b] = make_uint4(LB::keep_word(b, 4 * q4), LB::keep_word(b, 4 * q4 + 1), LB::keep_word(b, 4 * q4 + 2), LB::keep_word(b, 4 * q4 + 3));
+#pragma unroll
+        for (int r1 = 0; r1 < NR; ++r1) lds_k1[r1][b] = LB::keep_word(b, 4 * NQ4 + r1);
+    }
+    __syncthreads();                                                /* the only barrier: the table is shared by the four waves */
+
+    typename L::state S;
+    acc_row<QMAX, NW> row;
+    uint32_t t_off[2], ti[2], nblk = 0, q2[2][NW];
+    int ntw[2];
+    bool valid[2];
+    l2::sfor<2>([&](auto xi) {
+        constexpr int x = decltype(xi)::value;
+        const uint32_t slot = w0 + 64u * x;
+        valid[x] = slot < n;
+        ti[x] = valid[x] ? order[slot] : order[0];
+        const bsw_dtask T = tasks[ti[x]];
+        int qlen, tlen, wlim, h0;
+        uint32_t q_off;
+        if (side == 0) {
+            qlen = T.lqlen; tlen = T.ltlen; wlim = T.wlim_l; q_off = T.lq_off; t_off[x] = T.lt_off; h0 = T.h0;
+        } else {
+            qlen = T.rqlen; tlen = T.rtlen; wlim = T.wlim_r; q_off = T.rq_off; t_off[x] = T.rt_off;
+            h0 = T.lqlen > 0 ? out[ti[x]].left.score : T.h0;          /* h0 = score after the left ext (:1671) */
+        }
+        if (!valid[x]) tlen = 0;
+        ntw[x] = (tlen + 15) >> 4;
+        LB::init_seed(S.s[x], qlen, tlen, h0, min(P.w, wlim));
+        uint32_t mb[4][NW];
+        /* all query words are requested before the first is waited for (at one wave per SIMD nothing else hides a round
+         * trip to HBM per word); the index is clamped, words past the query are zeroed afterwards */
+        constexpr int NV = (QMAX + 15) / 16;
+        uint64_t qwv[NV];
+        const int lastq = max((qlen + 15) / 16 - 1, 0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) qwv[v] = seq[q_off + (uint32_t)min(v, lastq)];
+#pragma unroll
+        for (int wd = 0; wd < NW; ++wd) {
+            uint32_t p0 = 0, p1 = 0, p2 = 0;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int v = wd * 2 + hlf;
+                if (v < NV) {
+                    const uint64_t qw = (valid[x] && v * 16 < qlen) ? qwv[v] : 0ull;
+                    p0 |= nib_plane_l(qw, 0) << (hlf * 16);
+                    p1 |= nib_plane_l(qw, 1) << (hlf * 16);
+                    p2 |= nib_plane_l(qw, 2) << (hlf * 16);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mb[b][wd] = LB::base_match(p0, p1, p2, b);
+            q2[x][wd] = p2;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (wd * 4 + b < QB && __builtin_amdgcn_ballot_w64(((p2 >> (8 * b)) & 0xffu) != 0) != 0) nblk |= 1u << (wd * 4 + b);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int q4 = 0; q4 < NQ4; ++q4)
+                lds_m4[wv][x][b][q4][lane] = make_uint4(mb[b][4 * q4], mb[b][4 * q4 + 1], mb[b][4 * q4 + 2], mb[b][4 * q4 + 3]);
+#pragma unroll
+            for (int r1 = 0; r1 < NR; ++r1) lds_m1[wv][x][b][r1][lane] = mb[b][4 * NQ4 + r1];
+        }
+    });
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        lds_wn[wv][c][lane] = ((q2[0][c >> 1] >> (16 * (c & 1))) & 0xffffu) | ((q2[1][c >> 1] >> (16 * (c & 1))) << 16);
+
+    l2::consts k;
+    k.a = P.mat[0]; k.pb = -P.mat[1]; k.pn = -P.mat[24];
+    k.o_del = P.o_del; k.e_del = P.e_del; k.oe_ins = P.o_ins + P.e_ins; k.e_ins = P.e_ins; k.zdrop = P.zdrop;
+    l2::fill_packed_consts(k);
+    L::init_row(S, k, row);
+
+    const auto qp = [&](int x, int b, uint32_t (&rm)[NW]) {
+#pragma unroll
+        for (int q4 = 0; q4 < NQ4; ++q4) {
+            const uint4 v = lds_m4[wv][x][b][q4][lane];
+            rm[4 * q4] = v.x; rm[4 * q4 + 1] = v.y; rm[4 * q4 + 2] = v.z; rm[4 * q4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int r1 = 0; r1 < NR; ++r1) rm[4 * NQ4 + r1] = lds_m1[wv][x][b][r1][lane];
+    };
+    const auto kp = [&](int b, uint32_t (&kw)[NW]) {
+#pragma unroll
+        for (int q4 = 0; q4 < NQ4; ++q4) {
+            const uint4 v = lds_k4[q4][b];
+            kw[4 * q4] = v.x; kw[4 * q4 + 1] = v.y; kw[4 * q4 + 2] = v.z; kw[4 * q4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int r1 = 0; r1 < NR; ++r1) kw[4 * NQ4 + r1] = lds_k1[r1][b];
+    };
+    const auto wn = [&](int c) { return lds_wn[wv][c][lane]; };
+    uint64_t tw[2] = {0ull, 0ull};
+
+    for (int i = 0;; ++i) {
+        l2::rowv r;
+        {
+            typename LB::state tmp;                               /* row_begin works on the seed scalars only */
+            (void)tmp;
+        }
+        l2::sfor<2>([&](auto xi) {                                /* K3 band clamp: lane2::row_begin on the seed scalars */
+            constexpr int x = decltype(xi)::value;
+            l2::seedv &s = S.s[x];
+            r.act[x] = s.alive && i < s.tlen;
+            const int nb = l2::imax(s.beg, i - s.w), ne = l2::imin(l2::imin(s.end, i + s.w + 1), s.qlen);
+            r.bite[x] = r.act[x] && nb > s.beg;
+            r.zlo[x] = s.beg; r.zhi[x] = nb;
+            s.beg = r.act[x] ? nb : s.beg;
+            s.end = r.act[x] ? ne : s.end;
+            r.len[x] = l2::imax(s.end - s.beg, 0);
+            s.cells += r.act[x] ? (unsigned)r.len[x] : 0u;
+        });
+        if (__builtin_amdgcn_ballot_w64(r.act[0] || r.act[1]) == 0) break;
+        if ((i & (BSW_L2_TCHUNK * 16 - 1)) == 0) {                    /* stage the next 128 target bases of every seed */
+            const int wbase = i >> 4;
+            uint64_t tv[2][BSW_L2_TCHUNK];
+            l2::sfor<2>([&](auto xi) {
+                constexpr int x = decltype(xi)::value;
+                const int last = max(ntw[x] - 1, 0);
+#pragma unroll
+                for (int q = 0; q < BSW_L2_TCHUNK; ++q) tv[x][q] = seq[t_off[x] + (uint32_t)min(wbase + q, last)];
+            });
+            l2::sfor<2>([&](auto xi) {
+                constexpr int x = decltype(xi)::value;
+#pragma unroll
+                for (int q = 0; q < BSW_L2_TCHUNK; ++q) lds_t[wv][x][q][lane] = tv[x][q];
+            });
+        }
+        if ((i & 15) == 0) {
+            tw[0] = lds_t[wv][0][(i >> 4) & (BSW_L2_TCHUNK - 1)][lane];
+            tw[1] = lds_t[wv][1][(i >> 4) & (BSW_L2_TCHUNK - 1)][lane];
+        }
+        const int tb[2] = {(int)((tw[0] >> ((i & 15) * 4)) & 7), (int)((tw[1] >> ((i & 15) * 4)) & 7)};
+
+        l2::uni u;
+        const int b0 = S.s[0].beg, b1 = S.s[1].beg, e0 = S.s[0].end, e1 = S.s[1].end;
+        u.jlo = -wave_max2l(max(r.act[0] ? -b0 : INT_MIN, r.act[1] ? -b1 : INT_MIN));
+        u.jhi = wave_max2l(max(r.act[0] ? e0 : INT_MIN, r.act[1] ? e1 : INT_MIN));
+        u.jem = -wave_max2l(max(r.act[0] ? -e0 : INT_MIN, r.act[1] ? -e1 : INT_MIN));
+        u.anybite = __builtin_amdgcn_ballot_w64(r.bite[0] || r.bite[1]) != 0;
+        u.zl = 0; u.zh = 0;
+        if (u.anybite) {
+            u.zl = -wave_max2l(max(r.bite[0] ? -r.zlo[0] : INT_MIN, r.bite[1] ? -r.zlo[1] : INT_MIN));
+            u.zh = wave_max2l(max(r.bite[0] ? r.zhi[0] : INT_MIN, r.bite[1] ? r.zhi[1] : INT_MIN));
+        }
+        u.nblk = nblk;
+        L::row_body(S, k, i, r, u, tb, qp, kp, wn, row);
+    }
+
+    l2::sfor<2>([&](auto xi) {
+        constexpr int x = decltype(xi)::value;
+        if (!valid[x]) return;
+        const l2::seedv &s = S.s[x];
+        bsw_ext e;
+        e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
+        e.gscore = s.gscore; e.max_off = s.max_off; e.aw = P.w; e.cells = s.cells;
+        if (side == 0) out[ti[x]].left = e; else out[ti[x]].right = e;
+    });
+}
+
+/* the 232-column class (250 bp reads) at one wave per SIMD; BSW_LANE2L_NARROW=1 also routes the 136-column class here
+ * (experiments: the unrolled kernel is faster there) */
+hipError_t launch_lane2l(int cls, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
+                         const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins, vm = variant == BSW_VARIANT_M;
+    const dim3 grid((n + 511u) / 512u), block(256);
+#define BSW_L2L_GO(QB, WPS)                                                                                                     \
+    do {                                                                                                                        \
+        if (!vm && sym) hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);   \
+        else if (!vm) hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, false, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);    \
+        else if (sym) hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);      \
+        else hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);              \
+    } while (0)
+    if (cls == 0) BSW_L2L_GO(17, 1);
+    else BSW_L2L_GO(29, 1);
+#undef BSW_L2L_GO
+    return hipGetLastError();
+}
+
+}  // namespace bsw

@@ -13,11 +13,27 @@
 
 using namespace bsw::l2;
 
-template <int QB, bool VM, bool SYM>
+// row storage of the looped kernel (lane2l): a plain array here, the accumulator register file on the GPU
+template <int QMAX, int NW>
+struct array_row {
+    uint32_t eh[QMAX + 16];
+    uint32_t rm[2][NW];
+    void load8(int b, uint32_t (&T)[8]) const { for (int c = 0; c < 8; ++c) T[c] = eh[8 * b + c]; }
+    void store8(int b, const uint32_t (&T)[8]) { for (int c = 0; c < 8; ++c) eh[8 * b + c] = T[c]; }
+    void swap8(int b, uint32_t (&T)[8]) { store8(b, T); for (int c = 0; c < 8; ++c) T[c] = eh[8 * b + 8 + c]; }
+    void put_rm(int wd, uint32_t a, uint32_t b) { rm[0][wd] = a; rm[1][wd] = b; }
+    void get_rm(int wd, uint32_t &a, uint32_t &b) const { a = rm[0][wd]; b = rm[1][wd]; }
+};
+
+template <int QB, bool VM, bool SYM, bool LOOP>
 struct wave_model {
-    using L = lane2<QB, VM, SYM>;
+    using LU = lane2<QB, VM, SYM>;
+    using LL = lane2l<QB, VM, SYM>;
+    using L = LU;
     struct lane_t {
-        typename L::state S;
+        typename LU::state S;
+        typename LL::state SL;
+        array_row<LU::QMAX, LU::NW> row;
         uint32_t qp[2][3][L::NW];       // query bit planes
         uint32_t wn[L::NC];             // N planes, interleaved per 16 columns
         const uint8_t *t[2];
@@ -58,6 +74,7 @@ struct wave_model {
                 }
                 if (!a.valid[x]) tlen = 0;
                 L::init_seed(a.S.s[x], qlen, tlen, h0s ? h0s[a.ti[x]] : T.h0, p->w < wl ? p->w : wl);
+                a.SL.s[x] = a.S.s[x];
                 for (int j = 0; j < qlen; ++j) {
                     const int c = q[j] > 4 ? 4 : q[j];
                     if (c & 1) a.qp[x][0][j >> 5] |= 1u << (j & 31);
@@ -69,18 +86,20 @@ struct wave_model {
                 const uint32_t wa = (a.qp[0][2][c >> 1] >> (16 * (c & 1))) & 0xffffu, wb = (a.qp[1][2][c >> 1] >> (16 * (c & 1))) & 0xffffu;
                 a.wn[c] = wa | (wb << 16);
             }
-            L::init_row(a.S, k);
+            if constexpr (LOOP) { memset(&a.row, 0xa5, sizeof(a.row)); LL::init_row(a.SL, k, a.row); }
+            else L::init_row(a.S, k);
         }
         std::vector<rowv> rv(64);
         for (int i = 0;; ++i) {
             bool any = false;
             u.jlo = 1 << 20; u.jhi = -1; u.jem = 1 << 20; u.anybite = false; u.zl = 1 << 20; u.zh = -1;
             for (int l = 0; l < 64; ++l) {
-                L::row_begin(ln[l].S, i, rv[l]);
+                if constexpr (LOOP) { typename LU::state tmp; tmp.s[0] = ln[l].SL.s[0]; tmp.s[1] = ln[l].SL.s[1]; L::row_begin(tmp, i, rv[l]); ln[l].SL.s[0] = tmp.s[0]; ln[l].SL.s[1] = tmp.s[1]; }
+                else L::row_begin(ln[l].S, i, rv[l]);
                 for (int x = 0; x < 2; ++x) {
                     if (!rv[l].act[x]) continue;
                     any = true;
-                    const seedv &s = ln[l].S.s[x];
+                    const seedv &s = LOOP ? ln[l].SL.s[x] : ln[l].S.s[x];
                     if (s.beg < u.jlo) u.jlo = s.beg;
                     if (s.end > u.jhi) u.jhi = s.end;
                     if (s.end < u.jem) u.jem = s.end;
@@ -106,13 +125,14 @@ struct wave_model {
                 auto kp = [&](int b, uint32_t (&kw)[L::NW]) {
                     for (int wd = 0; wd < L::NW; ++wd) kw[wd] = L::keep_word(b, wd);
                 };
-                L::row_body(a.S, k, i, rv[l], u, tb, qp, kp, wn);
+                if constexpr (LOOP) LL::row_body(a.SL, k, i, rv[l], u, tb, qp, kp, wn, a.row);
+                else L::row_body(a.S, k, i, rv[l], u, tb, qp, kp, wn);
             }
         }
         for (int l = 0; l < 64; ++l)
             for (int x = 0; x < 2; ++x) {
                 if (!ln[l].valid[x]) continue;
-                const seedv &s = ln[l].S.s[x];
+                const seedv &s = LOOP ? ln[l].SL.s[x] : ln[l].S.s[x];
                 bsw_ext &e = out[ln[l].ti[x]];
                 e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
                 e.gscore = s.gscore; e.max_off = s.max_off; e.aw = p->w; e.cells = s.cells;
@@ -130,10 +150,30 @@ extern "C" int lane2_model_run(const bsw_params *p, const bsw_task *tasks, int s
     if (p->o_del + p->e_del > 255 || p->o_ins + p->e_ins > 255 || p->mat[0] - p->mat[1] > 255) return -2;
     const bool sym = p->o_del == p->o_ins && p->e_del == p->e_ins, vm = p->variant == BSW_VARIANT_M;
     for (size_t w0 = 0; w0 < n; w0 += 128) {
-        if (!vm && sym) wave_model<17, false, true>::run(p, tasks, side, order, n, w0, h0s, out);
-        else if (!vm) wave_model<17, false, false>::run(p, tasks, side, order, n, w0, h0s, out);
-        else if (sym) wave_model<17, true, true>::run(p, tasks, side, order, n, w0, h0s, out);
-        else wave_model<17, true, false>::run(p, tasks, side, order, n, w0, h0s, out);
+        if (!vm && sym) wave_model<17, false, true, false>::run(p, tasks, side, order, n, w0, h0s, out);
+        else if (!vm) wave_model<17, false, false, false>::run(p, tasks, side, order, n, w0, h0s, out);
+        else if (sym) wave_model<17, true, true, false>::run(p, tasks, side, order, n, w0, h0s, out);
+        else wave_model<17, true, false, false>::run(p, tasks, side, order, n, w0, h0s, out);
+    }
+    return 0;
+}
+
+// The looped kernel (bsw_lane2l_kernel<QB>: blocks walked by a run-time loop, row behind an accessor), qb = 17 or 29.
+extern "C" int lane2l_model_run(const bsw_params *p, const bsw_task *tasks, int side, const uint32_t *order, size_t n,
+                                const int32_t *h0s, bsw_ext *out, int qb)
+{
+    if (!p || !tasks || !order || !out) return -1;
+    if (p->mat[1] > 0 || p->mat[24] > 0 || -p->mat[1] < -p->mat[24]) return -2;
+    if (p->o_del + p->e_del > 255 || p->o_ins + p->e_ins > 255 || p->mat[0] - p->mat[1] > 255) return -2;
+    const bool sym = p->o_del == p->o_ins && p->e_del == p->e_ins, vm = p->variant == BSW_VARIANT_M;
+    for (size_t w0 = 0; w0 < n; w0 += 128) {
+#define RUNL(QB) do { \
+        if (!vm && sym) wave_model<QB, false, true, true>::run(p, tasks, side, order, n, w0, h0s, out); \
+        else if (!vm) wave_model<QB, false, false, true>::run(p, tasks, side, order, n, w0, h0s, out); \
+        else if (sym) wave_model<QB, true, true, true>::run(p, tasks, side, order, n, w0, h0s, out); \
+        else wave_model<QB, true, false, true>::run(p, tasks, side, order, n, w0, h0s, out); } while (0)
+        if (qb == 17) RUNL(17); else if (qb == 29) RUNL(29); else return -3;
+#undef RUNL
     }
     return 0;
 }

@@ -15,14 +15,34 @@ EXTF = ["score", "qle", "tle", "gtle", "gscore", "max_off", "aw", "cells"]
 
 
 @pytest.fixture(scope="module")
-def model(tmp_path_factory):
+def model_lib(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("l2") / "lane2_model.so")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "include"),
                            "-o", so, os.path.join(ROOT, "tests", "lane2_model.cpp")])
     L = C.CDLL(so)
     L.lane2_model_run.restype = C.c_int
     L.lane2_model_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.lane2l_model_run.restype = C.c_int
+    L.lane2l_model_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     return L
+
+
+class Model:
+    """unrolled: bsw_lane2_kernel<17> (blocks unrolled, row in VGPRs); loop17 / loop29: bsw_lane2l_kernel (blocks walked by a
+    run-time loop, row behind an accessor) for the 136- and the 232-column class"""
+    def __init__(self, lib, kind):
+        self.lib, self.kind = lib, kind
+        self.qcap = 231 if kind == "loop29" else 135
+
+    def lane2_model_run(self, *a):
+        if self.kind == "unrolled":
+            return self.lib.lane2_model_run(*a)
+        return self.lib.lane2l_model_run(*a, 29 if self.kind == "loop29" else 17)
+
+
+@pytest.fixture(scope="module", params=["unrolled", "loop17", "loop29"])
+def model(model_lib, request):
+    return Model(model_lib, request.param)
 
 
 def run_side(model, host, p, tasks, side, h0s=None):
@@ -69,7 +89,7 @@ def check(model, host, oracle, p, tasks):
 ])
 def test_random_seeds_match_the_oracle(model, host, oracle, over):
     rng = np.random.default_rng(abs(hash(str(sorted(over.items())))) % (2 ** 31))
-    seeds = _gen.random_seeds(rng, 700, qmin=1, qmax=135, tfac=2.2, sub=0.03, indel=0.02, junk=0.15, nrate=0.004, h0max=60)
+    seeds = _gen.random_seeds(rng, 700, qmin=1, qmax=model.qcap, tfac=2.2, sub=0.03, indel=0.02, junk=0.15, nrate=0.004, h0max=60)
     for s in seeds:                                       # 8-bit score range of the kernel class
         tot = len(s.get("lq", ())) + len(s.get("rq", ()))
         s["h0"] = max(1, min(s["h0"], 255 - 4 - tot))     # the class bound: h0 + qlen*a + b <= 255
@@ -83,7 +103,7 @@ def test_random_seeds_match_the_oracle(model, host, oracle, over):
 def test_scoring_matrices(model, host, oracle, ab_n, variant):
     a, b, nn = ab_n
     rng = np.random.default_rng(a * 100 + b)
-    seeds = _gen.random_seeds(rng, 400, qmin=1, qmax=135 // a, tfac=2.0, sub=0.05, indel=0.02, junk=0.1, nrate=0.01, h0max=40)
+    seeds = _gen.random_seeds(rng, 400, qmin=1, qmax=model.qcap // a, tfac=2.0, sub=0.05, indel=0.02, junk=0.1, nrate=0.01, h0max=40)
     for s in seeds:
         tot = len(s.get("lq", ())) + len(s.get("rq", ()))
         s["h0"] = max(1, min(s["h0"], 255 - b - tot * a))
@@ -109,7 +129,7 @@ def test_variants_differ_where_they_should(model, host, oracle):
     """Variant H lifts a zero H(i-1,j-1) by a match, variant M does not: on indel-rich seeds the two must disagree
     somewhere (or the M path is not exercised) and each must equal the oracle's own variant."""
     rng = np.random.default_rng(77)
-    seeds = _gen.random_seeds(rng, 1500, qmin=20, qmax=135, tfac=2.2, sub=0.06, indel=0.05, junk=0.2, nrate=0.0, h0max=30)
+    seeds = _gen.random_seeds(rng, 1500, qmin=20, qmax=model.qcap, tfac=2.2, sub=0.06, indel=0.05, junk=0.2, nrate=0.0, h0max=30)
     for s in seeds:
         tot = len(s.get("lq", ())) + len(s.get("rq", ()))
         s["h0"] = max(1, min(s["h0"], 255 - 4 - tot))
@@ -151,7 +171,7 @@ def test_top_of_the_score_range(model, host, oracle, ab):
     seeds = []
     for k in range(300):
         lq = int(rng.integers(0, 60))
-        rq = int(rng.integers(1, min(135, (255 - b - 1) // a - lq)))
+        rq = int(rng.integers(1, min(model.qcap, (255 - b - 1) // a - lq)))
         h0 = 255 - b - (lq + rq) * a - int(rng.integers(0, 2))          # top = 255 - b, or one below
         if h0 < 1:
             continue

@@ -97,5 +97,8 @@ int main()
     run<72, 4, 0>("pair dense body, 72 columns, 4 waves/SIMD", d_out, d_in, cus, ghz);
     run<72, 2, 0>("pair dense body, 72 columns, 2 waves/SIMD", d_out, d_in, cus, ghz);
     run<104, 3, 0>("pair dense body, 104 columns, 3 waves/SIMD", d_out, d_in, cus, ghz);
+    run<232, 1, 0>("pair dense body, 232 columns, 1 wave/SIMD", d_out, d_in, cus, ghz);
+    run<232, 1, 1>("pair dense body, 232 columns, 1 wave/SIMD, lshl_or key", d_out, d_in, cus, ghz);
+    run<200, 1, 0>("pair dense body, 200 columns, 1 wave/SIMD", d_out, d_in, cus, ghz);
     return 0;
 }
