@@ -380,6 +380,33 @@ def main():
             e2e_stream = (d2, same2 and bool(out_buf.tobytes() == res.tobytes()))
             ca.close(); cb.close()
 
+    # ---- the same seeds handed over 4-BIT PACKED (the device layout; bsw_submit_packed): no pack kernel, ~0.6x the PCIe bytes ----
+    packed_leg = None
+    if not args.no_e2e and world == 1:
+        need = int(host.lib().bsw_pack_tasks_bound(tasks.ctypes.data, len(tasks)))
+        parena = host.HostArena(need + 64)
+        ptasks, _w = host.pack_tasks(tasks, parena.view(np.uint64, need // 8 + 1))
+        # 96 Ki chunks: with half the bytes per seed the input DMAs are short and smaller chunks start the GPU sooner
+        # (sweep: profiles/r3/e2e_packed_sweep.txt)
+        pctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=4, pack_threads=4, chunk_tasks=98304)
+        pctx.extend_pairs_packed(params, ptasks, out=out_buf)
+        runs = []
+        for _ in range(args.e2e_reps):
+            barrier()
+            t1 = time.perf_counter()
+            gotp = pctx.extend_pairs_packed(params, ptasks, out=out_buf)
+            barrier()
+            runs.append(time.perf_counter() - t1)
+        psame = bool(gotp.tobytes() == res.tobytes())
+        pctx.close()
+        d2, same2, (ca, cb) = stream_two_in_flight(
+            lambda: host.BswContext(device=local_rank, kernel=args.kernel, streams=2, pack_threads=2, chunk_tasks=2 * chunk),
+            lambda c, o: (lambda: c.submit_packed(params, ptasks, o)))
+        pstream = (d2, same2 and bool(out_buf.tobytes() == res.tobytes()))
+        ca.close(); cb.close()
+        packed_leg = (float(np.median(runs)), psame, need, pstream)
+        parena.free()
+
     # ---- same shape of work, seeds against a DEVICE-RESIDENT reference: only the reads cross PCIe ----
     ref_leg = None
     if not args.no_e2e and args.ref_mbp > 0 and args.scaling == "weak":
@@ -485,6 +512,19 @@ def main():
                     "seeds_per_s": round(len(tasks) / e2e_stream[0], 1), "gcups": round(cells / e2e_stream[0] / 1e9, 1),
                     "ratio_to_hbm_resident": round((cells / e2e_stream[0] / 1e9) / gcups, 3), "host_threads": "4 slot threads (2 contexts x 2 slots)",
                     "batches_timed": 16, "bit_exact_vs_resident_run": e2e_stream[1]}
+        if packed_leg is not None:
+            pdt, psame, pbytes, pstream = packed_leg
+            out["e2e_packed_input"] = {
+                "seeds_per_s": round(len(tasks) / pdt, 1), "gcups": round(cells / pdt / 1e9, 1),
+                "ratio_to_hbm_resident": round((cells / pdt / 1e9) / gcups, 3), "host_threads": "4 slot threads", "reps_median_of": args.e2e_reps,
+                "path": "bsw_submit_packed: sequences 4-bit packed by the caller (16 bases per uint64, the device layout) in a registered arena, "
+                        "DMA'd straight into the sequence buffer, no pack kernel; packing itself is not timed (the caller keeps its reads packed)",
+                "bytes_per_seed_h2d": round((pbytes + len(tasks) * 44) / max(len(tasks), 1), 1),
+                "bit_exact_vs_resident_run": psame,
+                "stream_two_in_flight": {"seeds_per_s": round(len(tasks) / pstream[0], 1), "gcups": round(cells / pstream[0] / 1e9, 1),
+                                         "ratio_to_hbm_resident": round((cells / pstream[0] / 1e9) / gcups, 3),
+                                         "host_threads": "4 slot threads (2 contexts x 2 slots)", "batches_timed": 16,
+                                         "bit_exact_vs_resident_run": pstream[1]}}
         if ref_leg is not None and world == 1:
             rdt, rcells, rsame, rbytes, rlp = ref_leg
             out["e2e_device_reference"] = {

@@ -512,6 +512,39 @@ extern "C" int bsw_pack_bases(const uint8_t *s, int len, uint64_t *dst)
     return any != 0;
 }
 
+/* a whole task array into one packed arena (the caller-side half of bsw_submit_packed) */
+extern "C" size_t bsw_pack_tasks_bound(const bsw_task *tasks, size_t n)
+{
+    size_t w = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_task &t = tasks[i];
+        if (t.lqlen > 0) w += nwords(t.lqlen) + nwords(t.ltlen > 0 ? t.ltlen : 0);
+        if (t.rqlen > 0) w += nwords(t.rqlen) + nwords(t.rtlen > 0 ? t.rtlen : 0);
+    }
+    return 8 * w + 8;
+}
+
+extern "C" int64_t bsw_pack_tasks(const bsw_task *tasks, size_t n, uint64_t *arena, size_t cap, bsw_task *out)
+{
+    if ((n && (!tasks || !out)) || !arena || ((uintptr_t)arena & 7)) return BSW_E_INVAL;
+    size_t w = 0;
+    const size_t capw = cap / 8;
+    for (size_t i = 0; i < n; ++i) {
+        bsw_task t = tasks[i];
+        const uint8_t **ptr[4] = {&t.lquery, &t.ltarget, &t.rquery, &t.rtarget};
+        const int len[4] = {t.lqlen > 0 ? t.lqlen : 0, t.lqlen > 0 && t.ltlen > 0 ? t.ltlen : 0, t.rqlen > 0 ? t.rqlen : 0, t.rqlen > 0 && t.rtlen > 0 ? t.rtlen : 0};
+        for (int k = 0; k < 4; ++k) {
+            const size_t nw = nwords(len[k]);
+            if (w + nw > capw) return BSW_E_NOMEM;
+            if (len[k] && bsw_pack_bases(*ptr[k], len[k], arena + w) < 0) return BSW_E_INVAL;
+            *ptr[k] = len[k] ? (const uint8_t *)(arena + w) : nullptr;
+            w += nw;
+        }
+        out[i] = t;
+    }
+    return (int64_t)(8 * w);
+}
+
 /* lane kernel needs a bwa-style matrix (bwa_fill_scmat): a on the diagonal, one mismatch score off it,
  * one score for every pair that involves an N */
 static bool lane_matrix_ok(const bsw_params *p)
@@ -534,6 +567,8 @@ struct chunk_info {
     bool direct = false;              /* raw bytes are DMA'd straight out of registered memory */
     bool rev_left = false;            /* left queries sit forwards in raw, their offsets point at the last base (bsw_submit_ref) */
     uint32_t raw_bias = 0;            /* direct: rawoff holds the low 32 bits of the host pointers, raw byte = off - bias */
+    bool packed = false;              /* the caller's sequences are 4-bit packed words already (bsw_submit_packed): they are
+                                         DMA'd straight into `seq`, no pack kernel */
     batch_plan plan;
     bsw_binparams bp;
 };
@@ -565,8 +600,9 @@ static int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams 
  * out by direct DMA the pack kernel subtracts raw_bias, otherwise gather_offsets() replaces them. */
 template <class Src>
 static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, size_t n, bool dev_targets,
-                           bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left)
+                           bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left, bool packed = false)
 {
+    ci.packed = packed;
     const int mx = mat_max(p->mat);
     int rc = fill_binparams(e, p, kern, ci.bp);
     if (rc) return rc;
@@ -579,6 +615,26 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         if (len > 0) { if (s < lo) lo = s; if (s + len > hi) hi = s + len; }
     };
     bsw_task tmp;
+    /* packed input: whether the words can be DMA'd as they lie (registered, compact arena) decides the word offsets, and
+     * the staging records are write-combined memory that must not be read back — so the arena span is found first */
+    bool packed_direct = false;
+    const uint8_t *plo = nullptr;
+    if (packed) {
+        const uint8_t *l0 = (const uint8_t *)UINTPTR_MAX, *h0 = nullptr;
+        uint64_t sum = 0;
+        auto sp = [&](const uint8_t *s, int len) {
+            if (len > 0 && s) { const size_t nb = 8 * nwords(len); sum += nb; if (s < l0) l0 = s; if (s + nb > h0) h0 = s + nb; }
+        };
+        for (size_t i = 0; i < n; ++i) {
+            const bsw_task *tp = src(i, tmp, rc);
+            if (!tp) return rc;
+            if (tp->lqlen > 0) { sp(tp->lquery, tp->lqlen); sp(tp->ltarget, tp->ltlen); }
+            if (tp->rqlen > 0) { sp(tp->rquery, tp->rqlen); sp(tp->rtarget, tp->rtlen); }
+        }
+        const size_t spb = h0 ? (size_t)(h0 - l0) : 0;
+        packed_direct = spb > 0 && spb < (1ull << 32) - RAW_SLACK && spb <= 2 * sum + (1u << 20) && is_registered(l0, spb);
+        plo = l0;
+    }
     for (size_t i = 0; i < n; ++i) {
         const bsw_task *tp = src(i, tmp, rc);
         if (!tp) return rc;
@@ -598,6 +654,31 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         bsw_rawoff &r = ro[i];
         memset(&d, 0, sizeof(d));
         memset(&r, 0, sizeof(r));
+        if (packed) {
+            /* 16 bases per uint64 already (base k in bits [4k, 4k+3], codes 0-3 = ACGT, 4-7 = N), every sequence on an
+             * 8-byte boundary: the spans are whole words, rawoff keeps the pointers' low bits until the arena base is known */
+            if ((t.lqlen && (((uintptr_t)t.lquery | (t.ltlen ? (uintptr_t)t.ltarget : 0)) & 7)) ||
+                (t.rqlen && (((uintptr_t)t.rquery | (t.rtlen ? (uintptr_t)t.rtarget : 0)) & 7)))
+                return fail(e, BSW_E_INVAL, "task %zu: packed sequences must start on 8-byte boundaries", i);
+            /* direct: the registered arena IS the device's seq buffer, word offsets relative to its lowest word (an empty
+             * target takes its query's offset: word 0 of a target may be read even when no row is) */
+            if (t.lqlen) {
+                d.lq_off = packed_direct ? (uint32_t)((t.lquery - plo) >> 3) : (uint32_t)acc;
+                acc += nwords(t.lqlen);
+                d.lt_off = packed_direct ? (uint32_t)(((t.ltlen ? t.ltarget : t.lquery) - plo) >> 3) : (uint32_t)acc;
+                acc += nwords(t.ltlen);
+                accb += 8ull * (nwords(t.lqlen) + nwords(t.ltlen));
+                span(t.lquery, 8 * (int)nwords(t.lqlen)); span(t.ltarget, 8 * (int)nwords(t.ltlen));
+            }
+            if (t.rqlen) {
+                d.rq_off = packed_direct ? (uint32_t)((t.rquery - plo) >> 3) : (uint32_t)acc;
+                acc += nwords(t.rqlen);
+                d.rt_off = packed_direct ? (uint32_t)(((t.rtlen ? t.rtarget : t.rquery) - plo) >> 3) : (uint32_t)acc;
+                acc += nwords(t.rtlen);
+                accb += 8ull * (nwords(t.rqlen) + nwords(t.rtlen));
+                span(t.rquery, 8 * (int)nwords(t.rqlen)); span(t.rtarget, 8 * (int)nwords(t.rtlen));
+            }
+        } else {
         if (t.lqlen) {
             d.lq_off = (uint32_t)acc; acc += nwords(t.lqlen);
             d.lt_off = (uint32_t)acc; acc += nwords(t.ltlen);
@@ -611,6 +692,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
             r.rq = (uint32_t)(uintptr_t)t.rquery; accb += (uint64_t)t.rqlen;
             span(t.rquery, t.rqlen);
             if (!dev_targets) { r.rt = (uint32_t)(uintptr_t)t.rtarget; accb += (uint64_t)t.rtlen; span(t.rtarget, t.rtlen); }
+        }
         }
         d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
         d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
@@ -675,6 +757,14 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     ci.direct = spanb > 0 && spanb < (1ull << 32) - RAW_SLACK && spanb <= 2 * ci.sum_len + (1u << 20) && is_registered(lo, spanb);
     ci.rev_left = rev_left && ci.direct;            /* the gather path mirrors the left queries while copying */
     ci.raw_bias = ci.direct ? (uint32_t)(uintptr_t)lo : 0u;
+    {
+        static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+        if (dbg) fprintf(stderr, "[bsw] chunk n=%zu: %s%s, span %zu B for %zu B referenced\n", n, packed ? "packed " : "", ci.direct ? "direct DMA" : "gather", spanb, ci.sum_len);
+    }
+    if (packed) {
+        ci.direct = packed_direct;
+        if (packed_direct) ci.words = spanb >> 3;
+    }
     return BSW_OK;
 }
 
@@ -698,11 +788,28 @@ static void gather_offsets(const bsw_task *tasks, size_t n, bool dev_targets, bs
 }
 
 static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task *tasks, size_t n, bool dev_targets,
-                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left = false)
+                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left = false, bool packed = false)
 {
-    int rc = prepare_chunk_t(e, p, kern, [tasks](size_t i, bsw_task &, int &) { return tasks + i; }, n, dev_targets, dt, ro, ci, rev_left);
-    if (!rc && !ci.direct) gather_offsets(tasks, n, dev_targets, ro);
+    int rc = prepare_chunk_t(e, p, kern, [tasks](size_t i, bsw_task &, int &) { return tasks + i; }, n, dev_targets, dt, ro, ci, rev_left, packed);
+    if (!rc && !ci.direct && !packed) gather_offsets(tasks, n, dev_targets, ro);
     return rc;
+}
+
+/* packed sequences that are not in registered memory: their words go to the pinned staging arena in seq layout */
+static void gather_packed(const bsw_task *tasks, const bsw_dtask *dt, size_t n, uint64_t *dst)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_task &t = tasks[i];
+        const bsw_dtask &d = dt[i];
+        if (t.lqlen) {
+            memcpy(dst + d.lq_off, t.lquery, 8 * nwords(t.lqlen));
+            if (t.ltlen) memcpy(dst + d.lt_off, t.ltarget, 8 * nwords(t.ltlen));
+        }
+        if (t.rqlen) {
+            memcpy(dst + d.rq_off, t.rquery, 8 * nwords(t.rqlen));
+            if (t.rtlen) memcpy(dst + d.rt_off, t.rtarget, 8 * nwords(t.rtlen));
+        }
+    }
 }
 
 /* copy the sequences of tasks[0..n) into the pinned staging arena laid out by prepare_chunk */
@@ -780,7 +887,7 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
                         const bsw_ref *ref, uint64_t *h2d_bytes, const gate_turn *turn = nullptr, size_t dev_index = 0)
 {
     const size_t n_desc = ref ? n : 0;              /* st.h_desc: one bsw_refx per seed */
-    const size_t rawb = ci.direct ? (size_t)(ci.hi - ci.lo) : ci.sum_len;
+    const size_t rawb = ci.packed ? 0 : (ci.direct ? (size_t)(ci.hi - ci.lo) : ci.sum_len);
     hipError_t he;
     if ((he = st.d_raw.reserve(rawb + RAW_FRONT + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve(ci.words + 4)) != hipSuccess ||
         (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_roff.reserve(n + 1)) != hipSuccess ||
@@ -796,9 +903,11 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
             if (turn->gate->last) HIPCHK(e, hipStreamWaitEvent(s, turn->gate->last, 0));
         }
         hipError_t ce = hipSuccess;
-        if (rawb) ce = hipMemcpyAsync(st.d_raw.p + RAW_FRONT, ci.direct ? ci.lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s);
+        if (ci.packed) {               /* the words are the device layout already: they land in `seq`, nothing is packed */
+            if (ci.words) ce = hipMemcpyAsync(st.d_seq.p, ci.direct ? (const void *)ci.lo : (const void *)st.h_raw.p, ci.words * 8, hipMemcpyHostToDevice, s);
+        } else if (rawb) ce = hipMemcpyAsync(st.d_raw.p + RAW_FRONT, ci.direct ? ci.lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s);
         if (ce == hipSuccess) ce = hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s);
-        if (ce == hipSuccess) ce = hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s);
+        if (ce == hipSuccess && !ci.packed) ce = hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s);
         if (ce == hipSuccess && n_desc) ce = hipMemcpyAsync(st.d_desc.p, st.h_desc.p, n_desc * sizeof(bsw_refx), hipMemcpyHostToDevice, s);
         if (turn) {
             if (ce == hipSuccess) ce = hipEventRecord(turn->ev, s);
@@ -809,10 +918,11 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
         if (ce != hipSuccess) return fail(e, BSW_E_HIP, "input DMA: %s", hipGetErrorString(ce));
     }
     (void)dev_targets;
-    HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, ci.raw_bias, (uint32_t)n, ci.rev_left ? 1 : 0,
-                               ref ? ref->d_pac[dev_index] : nullptr, ref ? ref->l_pac : 0, ref ? st.d_desc.p : nullptr, st.d_seq.p, s));
+    if (!ci.packed)
+        HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, ci.raw_bias, (uint32_t)n, ci.rev_left ? 1 : 0,
+                                   ref ? ref->d_pac[dev_index] : nullptr, ref ? ref->l_pac : 0, ref ? st.d_desc.p : nullptr, st.d_seq.p, s));
     HIPCHK(e, bsw::launch_bin(ci.bp, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
-    if (h2d_bytes) *h2d_bytes = rawb + n * (sizeof(bsw_dtask) + sizeof(bsw_rawoff)) + n_desc * sizeof(bsw_refx);
+    if (h2d_bytes) *h2d_bytes = (ci.packed ? ci.words * 8 : rawb + n * sizeof(bsw_rawoff)) + n * sizeof(bsw_dtask) + n_desc * sizeof(bsw_refx);
     return BSW_OK;
 }
 
@@ -903,7 +1013,7 @@ static int busy_check(bsw_ctx *ctx, const char *what)
 static void fill_refx(const bsw_ref_task *rt, size_t n, bsw_refx *x);
 
 static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out,
-                         const bsw_ref *ref /* NULL: targets come from the host */, const bsw_ref_task *rtasks)
+                         const bsw_ref *ref /* NULL: targets come from the host */, const bsw_ref_task *rtasks, bool packed = false)
 {
     *out = nullptr;
     errs &e = ctx->err;
@@ -917,11 +1027,12 @@ static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *task
     st.set_pinned(false);               /* one-shot upload: plain host staging, synchronous copies */
     chunk_info ci;
     if (st.h_tasks.reserve(n + 1) != hipSuccess || st.h_roff.reserve(n + 1) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
-    rc = prepare_chunk(e, p, ctx->cfg.kernel, tasks, n, ref != nullptr, st.h_tasks.p, st.h_roff.p, ci);
+    rc = prepare_chunk(e, p, ctx->cfg.kernel, tasks, n, ref != nullptr, st.h_tasks.p, st.h_roff.p, ci, false, packed);
     if (rc) { bsw_free_batch(ctx, b); return rc; }
     if (!ci.direct) {
         if (st.h_raw.reserve(ci.sum_len + RAW_SLACK) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
-        gather_raw(tasks, st.h_roff.p, n, ref != nullptr, st.h_raw.p, ctx->cfg.pack_threads);
+        if (packed) gather_packed(tasks, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
+        else gather_raw(tasks, st.h_roff.p, n, ref != nullptr, st.h_raw.p, ctx->cfg.pack_threads);
     }
     if (ref) {
         if (st.h_desc.reserve(n + 1) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
@@ -949,6 +1060,16 @@ extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tas
     int rc = busy_check(ctx, "bsw_upload");
     if (rc) return rc;
     return upload_common(ctx, p, tasks, n, out, nullptr, nullptr);
+}
+
+/* bsw_upload for sequences that are 4-bit packed already (see bsw_submit_packed) */
+extern "C" int bsw_upload_packed(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!out || (!tasks && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_upload_packed: NULL argument");
+    int rc = busy_check(ctx, "bsw_upload_packed");
+    if (rc) return rc;
+    return upload_common(ctx, p, tasks, n, out, nullptr, nullptr, true);
 }
 
 /* ---- device-resident reference (F3) ------------------------------------------------ */
@@ -1157,7 +1278,7 @@ extern "C" int bsw_batch_order(bsw_ctx *ctx, const bsw_dev_batch *b, uint32_t *o
 
 /* ---- one synchronous chunk through a staging slot (small batches; the streaming workers use the same steps) ---- */
 static int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params &p, const bsw_dparams &dp,
-                     const bsw_task *tasks, size_t n, bsw_result *out, int gather_threads, const gate_turn *turn = nullptr)
+                     const bsw_task *tasks, size_t n, bsw_result *out, int gather_threads, const gate_turn *turn = nullptr, bool packed = false)
 {
     if (n == 0) return BSW_OK;
     static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
@@ -1167,12 +1288,13 @@ static int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent
     if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess)
         return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
     chunk_info ci;
-    int rc = prepare_chunk(e, &p, ctx->cfg.kernel, tasks, n, false, st.h_tasks.p, st.h_roff.p, ci);
+    int rc = prepare_chunk(e, &p, ctx->cfg.kernel, tasks, n, false, st.h_tasks.p, st.h_roff.p, ci, false, packed);
     if (rc) return rc;
     const double t_b = dbg ? tnow() : 0;
     if (!ci.direct) {
         if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
-        gather_raw(tasks, st.h_roff.p, n, false, st.h_raw.p, gather_threads);
+        if (packed) gather_packed(tasks, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
+        else gather_raw(tasks, st.h_roff.p, n, false, st.h_raw.p, gather_threads);
     }
     const double t_c = dbg ? tnow() : 0;
     rc = stage_device(e, st, s, ci, n, false, nullptr, nullptr, turn);
@@ -1229,7 +1351,7 @@ static std::vector<std::vector<chunk_span>> plan_chunks(size_t n, size_t chunk, 
 static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp, const bsw_task *tasks,
                        const bsw_ref *ref, const bsw_ref_task *rtasks,   /* non-NULL: seeds against the device-resident reference */
                        bsw_result *out, const std::vector<chunk_span> &chunks, size_t d, size_t s, int gather_threads,
-                       std::atomic<int> &abort_flag, h2d_gate &gate, errs &e)
+                       std::atomic<int> &abort_flag, h2d_gate &gate, errs &e, bool packed)
 {
     std::vector<bsw_task> rt_tasks;                 /* ref mode: this chunk's seeds as tasks (left queries by reference) */
     static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
@@ -1299,12 +1421,13 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
                 gather_offsets(ct, n, true, st.h_roff.p);
             }
         } else {
-            rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci);
+            rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci, false, packed);
             if (rc) return bail(rc);
         }
         if (!ci.direct) {
             if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
-            gather_raw(ct, st.h_roff.p, n, rtasks != nullptr, st.h_raw.p, gather_threads, rtasks != nullptr);
+            if (packed) gather_packed(ct, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
+            else gather_raw(ct, st.h_roff.p, n, rtasks != nullptr, st.h_raw.p, gather_threads, rtasks != nullptr);
         }
         const double t2 = dbg ? tnow() : 0;
         rc = finish();
@@ -1341,7 +1464,7 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
 }
 
 static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, const bsw_ref *ref, const bsw_ref_task *rtasks,
-                           size_t n, bsw_result *out)
+                           size_t n, bsw_result *out, bool packed = false)
 {
     bsw_dparams dp;
     int rc = check_params(ctx->err, &p, &dp);
@@ -1359,8 +1482,8 @@ static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, co
     std::vector<h2d_gate> gates(G);
     std::vector<std::thread> th;
     for (size_t k = 1; k < ws.size(); ++k)
-        th.emplace_back([&, k]() { ws[k].rc = slot_worker(ctx, p, dp, tasks, ref, rtasks, out, chunks[ws[k].d], ws[k].d, ws[k].s, gather_threads, abort_flag, gates[ws[k].d], ws[k].e); });
-    ws[0].rc = slot_worker(ctx, p, dp, tasks, ref, rtasks, out, chunks[ws[0].d], ws[0].d, ws[0].s, gather_threads, abort_flag, gates[ws[0].d], ws[0].e);
+        th.emplace_back([&, k]() { ws[k].rc = slot_worker(ctx, p, dp, tasks, ref, rtasks, out, chunks[ws[k].d], ws[k].d, ws[k].s, gather_threads, abort_flag, gates[ws[k].d], ws[k].e, packed); });
+    ws[0].rc = slot_worker(ctx, p, dp, tasks, ref, rtasks, out, chunks[ws[0].d], ws[0].d, ws[0].s, gather_threads, abort_flag, gates[ws[0].d], ws[0].e, packed);
     for (auto &t : th) t.join();
     for (int pass = 0; pass < 2; ++pass)             /* report the failure itself, not the slots it made give up */
         for (auto &w : ws)
@@ -1381,6 +1504,27 @@ extern "C" int bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tas
     ctx->worker_rc = 0;
     bsw_params pc = *p;
     ctx->worker = std::thread([ctx, pc, tasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, tasks, nullptr, nullptr, n, out); });
+    return BSW_OK;
+}
+
+/* bsw_submit for callers that keep their sequences 4-bit packed — 16 bases per uint64, base k in bits [4k, 4k+3], codes
+ * 0-3 = ACGT, 4-7 = N, every sequence on an 8-byte boundary, lengths still in bases: the device's own layout and the
+ * encoding the reference ships over its link (8 bases per 32-bit word, sw_pe_array_proc_element.v:1638,1677-1683).  The
+ * words of a registered arena are DMA'd straight into the sequence buffer: no pack kernel, less than half the PCIe bytes
+ * of byte-per-base input.  bsw_pack_bases() converts one sequence.  Wait with bsw_wait. */
+extern "C" int bsw_submit_packed(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!p || (!tasks && n) || (!out && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_submit_packed: NULL argument");
+    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "bsw_submit_packed: context is dead (an earlier wait for the GPU timed out)");
+    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "previous bsw_submit not waited for");
+    bsw_dparams dp;
+    int rc = check_params(ctx->err, p, &dp);
+    if (rc) return rc;
+    ctx->worker_active = true;
+    ctx->worker_rc = 0;
+    bsw_params pc = *p;
+    ctx->worker = std::thread([ctx, pc, tasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, tasks, nullptr, nullptr, n, out, true); });
     return BSW_OK;
 }
 

@@ -92,6 +92,9 @@ def lib():
             "bsw_create": (C.c_int, [vp, C.POINTER(vp)]), "bsw_destroy": (None, [vp]),
             "bsw_last_error": (C.c_char_p, [vp]),
             "bsw_submit": (C.c_int, [vp, vp, vp, sz, vp]), "bsw_wait": (C.c_int, [vp]),
+            "bsw_submit_packed": (C.c_int, [vp, vp, vp, sz, vp]),
+            "bsw_upload_packed": (C.c_int, [vp, vp, vp, sz, C.POINTER(vp)]),
+            "bsw_pack_tasks": (C.c_int64, [vp, sz, vp, sz, vp]), "bsw_pack_tasks_bound": (sz, [vp, sz]),
             "bsw_extend_batch": (C.c_int, [vp, vp, vp, sz, vp]),
             "bsw_upload": (C.c_int, [vp, vp, vp, sz, C.POINTER(vp)]),
             "bsw_run": (C.c_int, [vp, vp]), "bsw_sync": (C.c_int, [vp]),
@@ -145,6 +148,7 @@ def lib():
 EXPORTS = ["ksw_global2", "ksw_global", "bsw_global_batch", "bsw_align_batch", "ksw_align2", "ksw_align", "ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_scalar_stats", "bsw_host_alloc", "bsw_host_free",
            "bsw_host_register", "bsw_host_unregister", "bsw_batch_order", "bsw_refbatch_submit", "bsw_refbatch_wait", "bsw_default_params", "bsw_default_config",
            "bsw_device_count", "bsw_create", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
+           "bsw_submit_packed", "bsw_upload_packed", "bsw_pack_tasks", "bsw_pack_tasks_bound",
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
            "bsw_refbatch_encode_results", "bsw_refbatch_decode_results", "bsw_refbatch_run",
@@ -159,6 +163,20 @@ def default_params(**over):
     for k, v in over.items():
         p[k] = v
     return p
+
+
+def pack_tasks(tasks, arena=None):
+    """Byte-per-base tasks -> (tasks whose pointers address 4-bit packed words, the uint64 arena holding them).  `arena`: a
+    uint64 view of registered memory (HostArena.view(np.uint64, ...)) to pack into, or None for a fresh numpy array."""
+    need = int(lib().bsw_pack_tasks_bound(tasks.ctypes.data, len(tasks)))
+    if arena is None:
+        arena = np.zeros(need // 8 + 1, dtype=np.uint64)
+    assert arena.dtype == np.uint64 and arena.nbytes >= need
+    out = np.zeros(len(tasks), dtype=TASK)
+    used = int(lib().bsw_pack_tasks(tasks.ctypes.data, len(tasks), arena.ctypes.data, arena.nbytes, out.ctypes.data))
+    if used < 0:
+        raise RuntimeError("bsw_pack_tasks failed (%d)" % used)
+    return out, arena
 
 
 def bwa_matrix(a=1, b=4, n=-1):
@@ -309,6 +327,25 @@ class BswContext:
     def wait(self):
         self._chk(lib().bsw_wait(self.handle), "bsw_wait")
         self._keep = None
+
+    def submit_packed(self, params, ptasks, out=None):
+        """bsw_submit_packed: `ptasks` from pack_tasks() (sequence pointers address 4-bit packed words)."""
+        if out is None:
+            out = np.zeros(len(ptasks), dtype=RESULT)
+        assert out.dtype == RESULT and len(out) >= len(ptasks)
+        self._keep = (params, ptasks, out)
+        self._chk(lib().bsw_submit_packed(self.handle, params.ctypes.data, ptasks.ctypes.data, len(ptasks), out.ctypes.data), "bsw_submit_packed")
+        return out
+
+    def extend_pairs_packed(self, params, ptasks, out=None):
+        out = self.submit_packed(params, ptasks, out)
+        self.wait()
+        return out[:len(ptasks)]
+
+    def upload_packed(self, params, ptasks):
+        h = C.c_void_p()
+        self._chk(lib().bsw_upload_packed(self.handle, params.ctypes.data, ptasks.ctypes.data, len(ptasks), C.byref(h)), "bsw_upload_packed")
+        return DeviceBatch(self, h, len(ptasks))
 
     def extend_pairs(self, params, tasks, out=None):
         """Streaming path, synchronous.  Pass a reused `out` array to keep page faults of a fresh one out of timings."""

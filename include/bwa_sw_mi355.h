@@ -180,6 +180,17 @@ int      bsw_host_unregister(void *p);
  * TASK ORDER.  out[] and the task sequences must stay valid until bsw_wait returns.        */
 int      bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out);
 int      bsw_wait(bsw_ctx *ctx);
+/* The same for callers that keep sequences 4-BIT PACKED: the bsw_task pointers then address uint64 words, 16 bases
+ * each (base k in bits [4k, 4k+3]; codes 0-3 = ACGT, 4-7 = N), every sequence starting on an 8-byte boundary; the
+ * lengths stay in bases.  This is the device's own layout and the encoding the reference ships over its link (8 bases
+ * per 32-bit word, first base in the top nibble there: sw_pe_array_proc_element.v:1638,1677-1683).  Words in registered
+ * memory are DMA'd straight into the sequence buffer — no pack kernel, ~0.6x the PCIe bytes per seed of bsw_submit.
+ * bsw_pack_bases() packs one byte-per-base sequence; bsw_pack_tasks() a whole task array. */
+int      bsw_submit_packed(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out);
+/* tasks[0..n) (byte per base) -> out[0..n) with the sequences packed into `arena` (8-byte aligned, `cap` bytes);
+ * returns the bytes used or <0 (BSW_E_NOMEM: arena too small).  bsw_pack_tasks_bound() = a sufficient `cap`. */
+int64_t  bsw_pack_tasks(const bsw_task *tasks, size_t n, uint64_t *arena, size_t cap, bsw_task *out);
+size_t   bsw_pack_tasks_bound(const bsw_task *tasks, size_t n);
 /* Batched plain ksw_extend2 (one pass each, w/end_bonus/h0 per task); synchronous. */
 int      bsw_extend_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_ext_task *tasks, size_t n, bsw_ext *out);
 
@@ -240,6 +251,7 @@ kswr_t ksw_align(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, con
 
 /* ---- device-resident batches (inputs in HBM before the timed region) ------- */
 int      bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out);
+int      bsw_upload_packed(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out);   /* 4-bit packed sequences, as bsw_submit_packed */
 int      bsw_run(bsw_ctx *ctx, bsw_dev_batch *b);          /* enqueue kernels only        */
 int      bsw_sync(bsw_ctx *ctx);                            /* hipStreamSynchronize        */
 int      bsw_download(bsw_ctx *ctx, bsw_dev_batch *b, bsw_result *out); /* task order      */

@@ -1,0 +1,63 @@
+"""bsw_submit_packed / bsw_upload_packed: sequences handed over 4-bit packed (16 bases per uint64, the device layout and
+the encoding of the reference's link, sw_pe_array_proc_element.v:1638,1677-1683) must give the same result batch as the
+byte-per-base path and as the oracle — through the direct DMA (registered arena) and through the gather path."""
+import numpy as np
+import pytest
+
+import _gen
+from test_gpu_parity import assert_same
+
+pytestmark = pytest.mark.gpu
+MIXED = dict(seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.1, n_rate=0.002, indel_rate=0.01)
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("registered", [False, True])
+def test_packed_submit_equals_bytes_and_oracle(host, oracle, kernel, registered):
+    tasks, arena = host.synth_tasks(30000, seed=61, **MIXED)
+    p = host.default_params()
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    ha = None
+    if registered:
+        need = int(host.lib().bsw_pack_tasks_bound(tasks.ctypes.data, len(tasks)))
+        ha = host.HostArena(need + 64)
+        pt, words = host.pack_tasks(tasks, ha.view(np.uint64, need // 8 + 1))
+    else:
+        pt, words = host.pack_tasks(tasks)
+    with host.BswContext(device=0, kernel=kernel, chunk_tasks=8192, streams=3) as c:
+        got = c.extend_pairs_packed(p, pt)
+        assert_same(got, want, tasks)
+        assert got.tobytes() == c.extend_pairs(p, tasks).tobytes()
+        b = c.upload_packed(p, pt)                      # resident batch from packed input
+        c.run(b); c.sync()
+        assert c.download(b).tobytes() == want.tobytes()
+        b.free()
+    if ha is not None:
+        ha.free()
+
+
+def test_packed_edge_shapes(host, oracle, ctx):
+    """empty sides, empty targets, 1-base sequences, lengths around the 16-base word, Ns (codes 4..7)"""
+    rng = np.random.default_rng(8)
+    seeds = []
+    for ql in (1, 2, 15, 16, 17, 31, 32, 33, 130, 231):
+        for tl in (0, 1, 16, ql, 2 * ql + 3):
+            q = rng.integers(0, 4, ql).astype(np.uint8)
+            t = np.concatenate([q, rng.integers(0, 4, 300).astype(np.uint8)])[:tl]
+            q[rng.random(ql) < 0.05] = 4
+            seeds.append(dict(rq=q, rt=t, h0=int(rng.integers(1, 20))))
+            seeds.append(dict(lq=q.copy(), lt=t.copy(), h0=int(rng.integers(1, 20))))
+            seeds.append(dict(lq=q.copy(), lt=t.copy(), rq=q[::-1].copy(), rt=t[::-1].copy(), h0=3))
+    tasks, arena = host.make_tasks(seeds)
+    p = host.default_params()
+    pt, words = host.pack_tasks(tasks)
+    assert_same(ctx.extend_pairs_packed(p, pt), oracle.pair_batch(p, tasks), tasks)
+
+
+def test_packed_rejects_misaligned_pointers(host, ctx):
+    tasks, arena = host.synth_tasks(10, seed=2)
+    pt, words = host.pack_tasks(tasks)
+    pt["rquery"][3] += 4
+    with pytest.raises(host.BswError):
+        ctx.extend_pairs_packed(host.default_params(), pt)
+    assert len(ctx.extend_pairs(host.default_params(), tasks)) == 10      # the context survives the refusal
