@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256) void bsw_align_kernel(const bsw_dparams P, con
 
 /* classes: (mode, vectors per lane) -> query length up to lanes * vectors */
 /* (10 / 20 vectors: 150 bp reads, the common case, without the predicated tail of the 16 / 32 vector kernels) */
-static const struct { int byte, slen; } kAlignClasses[] = {{1, 8}, {1, 10}, {1, 16}, {0, 16}, {0, 20}, {0, 32}};
+/* (32 / 64 byte vectors and 64 / 128 word vectors: queries up to 1024 bases — bwa's ksw_align2 has no length limit and
+ * mate rescue of 2x300 reads must not lose its alignment; the long classes run at one wave per SIMD, rare by design) */
+static const struct { int byte, slen; } kAlignClasses[] = {{1, 8}, {1, 10}, {1, 16}, {1, 32}, {1, 64}, {0, 16}, {0, 20}, {0, 32}, {0, 64}, {0, 128}};
 int align_class_count() { return (int)(sizeof(kAlignClasses) / sizeof(kAlignClasses[0])); }
 int align_class_of(int qlen, int byte_mode)
 {
@@ -258,9 +260,13 @@ hipError_t launch_align(int cls, const bsw_dparams &P, const uint64_t *seq, cons
     case 0: hipLaunchKernelGGL((bsw_align_kernel<8, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
     case 1: hipLaunchKernelGGL((bsw_align_kernel<10, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
     case 2: hipLaunchKernelGGL((bsw_align_kernel<16, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
-    case 3: hipLaunchKernelGGL((bsw_align_kernel<16, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
-    case 4: hipLaunchKernelGGL((bsw_align_kernel<20, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
-    case 5: hipLaunchKernelGGL((bsw_align_kernel<32, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 3: hipLaunchKernelGGL((bsw_align_kernel<32, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 4: hipLaunchKernelGGL((bsw_align_kernel<64, true>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 5: hipLaunchKernelGGL((bsw_align_kernel<16, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 6: hipLaunchKernelGGL((bsw_align_kernel<20, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 7: hipLaunchKernelGGL((bsw_align_kernel<32, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 8: hipLaunchKernelGGL((bsw_align_kernel<64, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
+    case 9: hipLaunchKernelGGL((bsw_align_kernel<128, false>), grid, block, 0, s, P, seq, tasks, order, n, blist, out); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -227,7 +227,7 @@ int ksw_global(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
 #define KSW_XSTOP  0x20000
 #define KSW_XSUBO  0x40000
 #define KSW_XSTART 0x80000
-#define BSW_ALIGN_MAX_QLEN 256
+#define BSW_ALIGN_MAX_QLEN 1024
 typedef struct bsw_kswr {            /* = bwa's kswr_t */
     int32_t score, te, qe, score2, te2, tb, qb;
 } bsw_kswr;

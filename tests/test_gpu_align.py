@@ -94,7 +94,30 @@ def test_saturation_limits_and_degenerate_inputs(host, oracle, ctx):
     got = check(host, oracle, ctx, p, make(host, pairs, xt)[0])
     assert got["score"][0] == 255 and got["score"][1] == 256 and got["score"][2] == 250      # 8-bit run saturates, 16-bit does not
     with pytest.raises(host.BswError):
-        ctx.align_batch(p, make(host, [(np.zeros(257, np.uint8), t)], [0])[0])               # beyond BSW_ALIGN_MAX_QLEN: an error, not a fallback
+        ctx.align_batch(p, make(host, [(np.zeros(1025, np.uint8), t)], [0])[0])              # beyond BSW_ALIGN_MAX_QLEN: an error, not a fallback
+
+
+@pytest.mark.parametrize("mode", ["byte", "word"])
+def test_long_queries(host, oracle, ctx, mode):
+    """Reads longer than 256 bases (2x300 mate rescue): the 512- and 1024-column classes of both modes, every
+    vector count boundary, scores far beyond the 8-bit range in word mode and saturating in byte mode."""
+    rng = np.random.default_rng(11 if mode == "byte" else 12)
+    p = host.default_params()
+    pairs, xt = [], []
+    base = XB if mode == "byte" else 0
+    for ql in list(range(257, 1025, 37)) + [256, 257, 300, 511, 512, 513, 1000, 1023, 1024]:
+        t = rng.integers(0, 4, int(rng.integers(ql, ql + 600))).astype(np.uint8)
+        a = int(rng.integers(0, len(t) - ql + 1))
+        q = _gen.mutate(rng, t[a:a + ql], ql, 0.06 if rng.random() < 0.7 else 0.3, 0.02)
+        if rng.random() < 0.2:
+            q = rng.integers(0, 5, ql).astype(np.uint8)
+        for x in (XSUBO | XSTART | 19, XSTART, XSUBO | 40, 0):
+            pairs.append((q, t)); xt.append(base | x)
+    got = check(host, oracle, ctx, p, make(host, pairs, xt)[0])
+    if mode == "word":
+        assert got["score"].max() > 300 and (got["tb"] >= 0).sum() > 20          # far beyond the 8-bit range
+    else:
+        assert (got["score"] == 255).sum() > 10
 
 
 @pytest.mark.parametrize("seed", range(4))
