@@ -1635,9 +1635,16 @@ extern "C" int bsw_extend_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_ext
  * queued (its own call included), runs it as ONE device batch on the process-wide context's staging
  * (persistent pinned + device buffers: no allocation per call) and wakes the others. */
 struct scalar_req {
+    int kind = 0;                     /* 0 ksw_extend2, 1 ksw_align2, 2 ksw_global2: all three share the queue and the trip */
     bsw_params p;
-    bsw_ext_task t;
+    bsw_ext_task t;                   /* extend */
     bsw_ext x;
+    bsw_atask at;                     /* align */
+    bsw_kswr ar;
+    bsw_gtask gt;                     /* global */
+    bsw_gresult gr;
+    int cap = 0;                      /* CIGAR words this call can take (0: score only) */
+    std::vector<uint32_t> cg;
     int rc = 0;
     bool done = false;
 };
@@ -1665,6 +1672,50 @@ static bool same_scoring(const bsw_params &a, const bsw_params &b)
            a.e_ins == b.e_ins && a.zdrop == b.zdrop && a.variant == b.variant;
 }
 
+static bool same_alignment_scoring(const bsw_params &a, const bsw_params &b)
+{
+    return memcmp(a.mat, b.mat, 25) == 0 && a.o_del == b.o_del && a.e_del == b.e_del && a.o_ins == b.o_ins && a.e_ins == b.e_ins;
+}
+
+/* the ksw_align2 / ksw_global2 calls of one trip, grouped by scoring: one bsw_align_batch / bsw_global_batch per group
+ * (they used to be one serialised device round trip per call) */
+static void scalar_side_calls(std::vector<scalar_req *> &batch)
+{
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); ++i) {
+        if (taken[i] || batch[i]->kind == 0) continue;
+        const int kind = batch[i]->kind;
+        std::vector<size_t> grp;
+        for (size_t j = i; j < batch.size(); ++j)
+            if (!taken[j] && batch[j]->kind == kind && same_alignment_scoring(batch[i]->p, batch[j]->p)) { grp.push_back(j); taken[j] = 1; }
+        int rc = BSW_OK;
+        if (kind == 1) {
+            std::vector<bsw_atask> t(grp.size());
+            std::vector<bsw_kswr> o(grp.size());
+            for (size_t k = 0; k < grp.size(); ++k) t[k] = batch[grp[k]]->at;
+            rc = bsw_align_batch(g_ctx, &batch[i]->p, t.data(), t.size(), o.data());
+            if (rc) fprintf(stderr, "ksw_align2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
+            for (size_t k = 0; k < grp.size(); ++k) { batch[grp[k]]->rc = rc; if (!rc) batch[grp[k]]->ar = o[k]; }
+        } else {
+            int cap = 0;
+            for (size_t k : grp) cap = std::max(cap, batch[k]->cap);
+            std::vector<bsw_gtask> t(grp.size());
+            std::vector<bsw_gresult> o(grp.size());
+            std::vector<uint32_t> cg(cap ? grp.size() * (size_t)cap : 1);
+            for (size_t k = 0; k < grp.size(); ++k) t[k] = batch[grp[k]]->gt;
+            rc = bsw_global_batch(g_ctx, &batch[i]->p, t.data(), t.size(), cap, o.data(), cap ? cg.data() : nullptr);
+            if (rc) fprintf(stderr, "ksw_global2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
+            for (size_t k = 0; k < grp.size(); ++k) {
+                scalar_req *r = batch[grp[k]];
+                r->rc = rc;
+                if (rc) continue;
+                r->gr = o[k];
+                if (r->cap && o[k].n_cigar > 0) r->cg.assign(cg.begin() + (ptrdiff_t)(k * (size_t)cap), cg.begin() + (ptrdiff_t)(k * (size_t)cap) + o[k].n_cigar);
+            }
+        }
+    }
+}
+
 static void scalar_round_trip(std::vector<scalar_req *> &batch)
 {
     if (!g_ctx && !g_ctx_rc) {
@@ -1680,14 +1731,16 @@ static void scalar_round_trip(std::vector<scalar_req *> &batch)
         for (scalar_req *r : batch) r->rc = g_ctx_rc;
         return;
     }
+    if (batch.empty()) return;                     /* (called only to create the context) */
     ++g_scalar_trips;
     g_scalar_calls += batch.size();
+    scalar_side_calls(batch);
     std::vector<char> taken(batch.size(), 0);
     for (size_t i = 0; i < batch.size(); ++i) {
-        if (taken[i]) continue;
+        if (taken[i] || batch[i]->kind != 0) continue;
         std::vector<size_t> grp;
         for (size_t j = i; j < batch.size(); ++j)
-            if (!taken[j] && same_scoring(batch[i]->p, batch[j]->p)) { grp.push_back(j); taken[j] = 1; }
+            if (!taken[j] && batch[j]->kind == 0 && same_scoring(batch[i]->p, batch[j]->p)) { grp.push_back(j); taken[j] = 1; }
         std::vector<bsw_ext_task> t(grp.size());
         std::vector<bsw_ext> x(grp.size());
         for (size_t k = 0; k < grp.size(); ++k) t[k] = batch[grp[k]]->t;
@@ -1696,6 +1749,28 @@ static void scalar_round_trip(std::vector<scalar_req *> &batch)
         if (!rc) rc = ext_batch_on(g_ctx, g_ctx->err, g_ctx->small, g_ctx->stream0(), g_ctx->devs[0].events[0], &batch[i]->p, t.data(), t.size(), x.data());
         if (rc) fprintf(stderr, "ksw_extend2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
         for (size_t k = 0; k < grp.size(); ++k) { batch[grp[k]]->rc = rc; if (!rc) batch[grp[k]]->x = x[k]; }
+    }
+}
+
+/* queue the call; whoever finds no trip in flight becomes the leader, takes everything queued and runs it */
+static void scalar_call(scalar_req &req)
+{
+    std::unique_lock<std::mutex> lk(g_mu);
+    g_queue.push_back(&req);
+    while (!req.done) {
+        if (!g_leader) {
+            g_leader = true;
+            std::vector<scalar_req *> batch;
+            batch.swap(g_queue);
+            lk.unlock();
+            scalar_round_trip(batch);
+            lk.lock();
+            for (scalar_req *r : batch) r->done = true;
+            g_leader = false;
+            g_cv.notify_all();
+        } else {
+            g_cv.wait(lk);
+        }
     }
 }
 
@@ -1725,25 +1800,7 @@ extern "C" int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8
     memset(&req.t, 0, sizeof(req.t));
     req.t.query = query; req.t.target = target; req.t.qlen = qlen; req.t.tlen = tlen;
     req.t.w = w; req.t.end_bonus = end_bonus; req.t.h0 = h0;
-    {
-        std::unique_lock<std::mutex> lk(g_mu);
-        g_queue.push_back(&req);
-        while (!req.done) {
-            if (!g_leader) {
-                g_leader = true;
-                std::vector<scalar_req *> batch;
-                batch.swap(g_queue);
-                lk.unlock();
-                scalar_round_trip(batch);
-                lk.lock();
-                for (scalar_req *r : batch) r->done = true;
-                g_leader = false;
-                g_cv.notify_all();
-            } else {
-                g_cv.wait(lk);
-            }
-        }
-    }
+    scalar_call(req);
     if (req.rc) return neutral(-1);
     if (qle) *qle = req.x.qle;
     if (tle) *tle = req.x.tle;
@@ -2164,8 +2221,9 @@ extern "C" int bsw_global_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_gta
     return BSW_OK;
 }
 
-/* drop-in scalar ABI: one alignment per call through the process-wide context (serialised; the batch API above is
- * the fast path).  Failure contract as ksw_extend2: message on stderr, *n_cigar = 0, return -1. */
+/* drop-in scalar ABI through the process-wide context: calls from concurrent threads share device round trips exactly
+ * as ksw_extend2's do (one bsw_global_batch per trip and scoring).  Failure contract as ksw_extend2: message on stderr,
+ * *n_cigar = 0, return -1. */
 extern "C" int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
                            int o_del, int e_del, int o_ins, int e_ins, int w, int *n_cigar_, uint32_t **cigar_)
 {
@@ -2175,40 +2233,24 @@ extern "C" int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8
         fprintf(stderr, "ksw_global2(libbwasw_mi355): unsupported arguments (m must be 5)\n");
         return -1;
     }
-    std::unique_lock<std::mutex> lk(g_mu);
-    while (g_leader) g_cv.wait(lk);                   /* share the scalar context with the ksw_extend2 round trips */
-    g_leader = true;
-    lk.unlock();
+    scalar_req req;
+    req.kind = 2;
+    bsw_default_params(&req.p);
+    memcpy(req.p.mat, mat, 25);
+    req.p.o_del = o_del; req.p.e_del = e_del; req.p.o_ins = o_ins; req.p.e_ins = e_ins;
+    memset(&req.gt, 0, sizeof(req.gt));
+    req.gt.query = query; req.gt.target = target; req.gt.qlen = qlen; req.gt.tlen = tlen; req.gt.w = w < 0 ? 0 : w;
+    const bool want = n_cigar_ && cigar_;
+    req.cap = want ? qlen + tlen + 2 : 0;
+    scalar_call(req);                                  /* coalesced with whatever other threads have queued */
     int score = -1;
-    {
-        std::vector<scalar_req *> none;
-        if (!g_ctx && !g_ctx_rc) scalar_round_trip(none);          /* creates the context */
-        if (g_ctx) {
-            bsw_params p;
-            bsw_default_params(&p);
-            memcpy(p.mat, mat, 25);
-            p.o_del = o_del; p.e_del = e_del; p.o_ins = o_ins; p.e_ins = e_ins;
-            bsw_gtask t;
-            memset(&t, 0, sizeof(t));
-            t.query = query; t.target = target; t.qlen = qlen; t.tlen = tlen; t.w = w < 0 ? 0 : w;
-            const bool want = n_cigar_ && cigar_;
-            const int cap = qlen + tlen + 2;
-            std::vector<uint32_t> cg(want ? (size_t)cap : 1);
-            bsw_gresult r;
-            const int rc = bsw_global_batch(g_ctx, &p, &t, 1, cap, &r, want ? cg.data() : nullptr);
-            if (rc) fprintf(stderr, "ksw_global2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
-            else {
-                score = r.score;
-                if (want && r.n_cigar > 0) {
-                    *cigar_ = (uint32_t *)malloc((size_t)r.n_cigar * sizeof(uint32_t));
-                    if (*cigar_) { memcpy(*cigar_, cg.data(), (size_t)r.n_cigar * sizeof(uint32_t)); *n_cigar_ = r.n_cigar; }
-                }
-            }
+    if (!req.rc) {
+        score = req.gr.score;
+        if (want && req.gr.n_cigar > 0) {
+            *cigar_ = (uint32_t *)malloc((size_t)req.gr.n_cigar * sizeof(uint32_t));
+            if (*cigar_) { memcpy(*cigar_, req.cg.data(), (size_t)req.gr.n_cigar * sizeof(uint32_t)); *n_cigar_ = req.gr.n_cigar; }
         }
     }
-    lk.lock();
-    g_leader = false;
-    g_cv.notify_all();
     return score;
 }
 
@@ -2346,31 +2388,16 @@ static kswr_t align_scalar(int qlen, const uint8_t *query, int tlen, const uint8
         r.score = -1;
         return r;
     }
-    std::unique_lock<std::mutex> lk(g_mu);
-    while (g_leader) g_cv.wait(lk);                   /* share the scalar context with the ksw_extend2 round trips */
-    g_leader = true;
-    lk.unlock();
+    scalar_req req;
+    req.kind = 1;
+    bsw_default_params(&req.p);
+    memcpy(req.p.mat, mat, 25);
+    req.p.o_del = o_del; req.p.e_del = e_del; req.p.o_ins = o_ins; req.p.e_ins = e_ins;
+    memset(&req.at, 0, sizeof(req.at));
+    req.at.query = query; req.at.target = target; req.at.qlen = qlen; req.at.tlen = tlen; req.at.xtra = xtra;
+    scalar_call(req);                                  /* coalesced with whatever other threads have queued */
     r.score = -1;
-    {
-        std::vector<scalar_req *> none;
-        if (!g_ctx && !g_ctx_rc) scalar_round_trip(none);          /* creates the context */
-        if (g_ctx) {
-            bsw_params p;
-            bsw_default_params(&p);
-            memcpy(p.mat, mat, 25);
-            p.o_del = o_del; p.e_del = e_del; p.o_ins = o_ins; p.e_ins = e_ins;
-            bsw_atask t;
-            memset(&t, 0, sizeof(t));
-            t.query = query; t.target = target; t.qlen = qlen; t.tlen = tlen; t.xtra = xtra;
-            bsw_kswr o;
-            const int rc = bsw_align_batch(g_ctx, &p, &t, 1, &o);
-            if (rc) fprintf(stderr, "ksw_align2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
-            else { r.score = o.score; r.te = o.te; r.qe = o.qe; r.score2 = o.score2; r.te2 = o.te2; r.tb = o.tb; r.qb = o.qb; }
-        }
-    }
-    lk.lock();
-    g_leader = false;
-    g_cv.notify_all();
+    if (!req.rc) { r.score = req.ar.score; r.te = req.ar.te; r.qe = req.ar.qe; r.score2 = req.ar.score2; r.te2 = req.ar.te2; r.tb = req.ar.tb; r.qb = req.ar.qb; }
     return r;
 }
 

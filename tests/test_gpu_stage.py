@@ -298,6 +298,68 @@ def test_scalar_abi_from_many_threads(host, oracle):
     assert L.ksw_extend2(0, None, 4, q.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, 100, 5, 100, 9, None, None, None, None, None) == 9
 
 
+def test_all_three_scalar_entry_points_share_round_trips(host, oracle):
+    """ksw_extend2, ksw_align2 and ksw_global2 called concurrently from 12 threads (bwa's -t workers in mem_chain2aln, mate
+    rescue and CIGAR generation): one queue, coalesced device trips, every result equal to the oracle's (the
+    alignment calls used to be one serialised round trip each)."""
+    L = host.lib()
+    m = host.bwa_matrix()
+
+    class KSWR(C.Structure):
+        _fields_ = [(f, C.c_int) for f in ("score", "te", "qe", "score2", "te2", "tb", "qb")]
+    L.ksw_align2.restype = KSWR
+    L.ksw_align2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    nthr, per = 12, 60
+    rng = np.random.default_rng(14)
+    cases = []
+    for k in range(nthr * per):
+        tl = int(rng.integers(60, 500))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        ql = int(rng.integers(20, 150))
+        q = _gen.mutate(rng, t[int(rng.integers(0, 30)):], ql, 0.04, 0.02)
+        cases.append((k % 3, q, t, int(rng.integers(1, 60))))
+    res = [None] * len(cases)
+    c0, t0 = host.scalar_stats()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+
+    def work(tid):
+        for k in range(tid * per, (tid + 1) * per):
+            kind, q, t, h0 = cases[k]
+            if kind == 0:
+                outs = [C.c_int(0) for _ in range(5)]
+                sc = L.ksw_extend2(len(q), q.ctypes.data, len(t), t.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, 100, 5, 100, h0, *[C.addressof(o) for o in outs])
+                res[k] = (sc,) + tuple(o.value for o in outs)
+            elif kind == 1:
+                r = L.ksw_align2(len(q), q.ctypes.data, len(t), t.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, 0x40000 | 0x80000 | 19, None)
+                res[k] = tuple(getattr(r, f) for f in ("score", "te", "qe", "score2", "te2", "tb", "qb"))
+            else:
+                nc, cg = C.c_int(0), C.POINTER(C.c_uint32)()
+                tt = t[:len(q) + 8]
+                sc = L.ksw_global2(len(q), q.ctypes.data, len(tt), tt.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, 30, C.addressof(nc), C.addressof(cg))
+                res[k] = (sc, [cg[i] for i in range(nc.value)])
+                libc.free(cg)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for k, (kind, q, t, h0) in enumerate(cases):
+        if kind == 0:
+            r = oracle.extend2(q, t, m, 6, 1, 6, 1, 100, 5, 100, h0)
+            assert res[k] == (r["score"], r["qle"], r["tle"], r["gtle"], r["gscore"], r["max_off"]), k
+        elif kind == 1:
+            w = oracle.align2(q, t, m, 6, 1, 6, 1, 0x40000 | 0x80000 | 19)
+            assert res[k] == tuple(w[f] for f in ("score", "te", "qe", "score2", "te2", "tb", "qb")), k
+        else:
+            tt = t[:len(q) + 8]
+            g = oracle.global2(q, tt, m, 6, 1, 6, 1, 30)
+            assert res[k][0] == g["score"] and [(c & 0xf, c >> 4) for c in res[k][1]] == g["cigar"], k
+    c1, t1 = host.scalar_stats()
+    assert c1 - c0 == len(cases) and 0 < t1 - t0 < len(cases)          # every call counted; fewer trips than calls: they were shared
+
+
 def test_busy_context_refuses_other_entry_points(host):
     tasks, arena = host.synth_tasks(200000, seed=53)
     p = host.default_params()
