@@ -152,6 +152,11 @@ L2_FN void fill_packed_consts(consts &k)
     k.HI2 = 0xff00ff00u;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BSW_L2_ASM_BODY)
+/* the 8-column block bodies as one list-scheduled asm statement each (tools/gen_lane2_body.py) */
+#include "bsw_lane2_body_asm.inc"
+#endif
+
 struct seedv {                          /* the scalars of one ksw_extend2 call (K1/K9) */
     int qlen, tlen, h0, w, beg, end;
     int mx, max_i, max_j, max_ie, gscore, max_off;
@@ -302,6 +307,25 @@ struct lane2 {
         }
     }
 
+    /* The eight cells of one block.  WN: the N bits of the block's columns in bits 0..7 of each half (NQ only); END /
+     * mi_in: END2 relative to the block and the mask of column j0 - 1 (EDGE only).  On the GPU, with BSW_L2_ASM_BODY, one
+     * hand-scheduled asm statement (bsw_lane2_body_asm.inc) instead of eight cell() calls: same instructions, ordered for
+     * instruction-level parallelism (what the one-wave-per-SIMD kernel needs). */
+    template <bool EDGE, bool NQ>
+    L2_MFN void block8(uint32_t (&T)[8], const uint32_t Wc, const uint32_t WN, const uint32_t Bv2s, const uint32_t D2s, const consts &k,
+                       const uint32_t END, const uint32_t mi_in, uint32_t &h1, uint32_t &f, uint32_t &mk, uint32_t &nz)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BSW_L2_ASM_BODY)
+        if constexpr (EDGE && NQ) block8_asm<true, true, VM, SYM>::run(T, Wc, WN, D2s, Bv2s, k, END, mi_in, h1, f, mk, nz);
+        else if constexpr (EDGE) block8_asm<true, false, VM, SYM>::run(T, Wc, Bv2s, k, END, mi_in, h1, f, mk, nz);
+        else if constexpr (NQ) block8_asm<false, true, VM, SYM>::run(T, Wc, WN, D2s, Bv2s, k, h1, f, mk, nz);
+        else block8_asm<false, false, VM, SYM>::run(T, Wc, Bv2s, k, h1, f, mk, nz);
+#else
+        uint32_t mi_prev = mi_in;
+        sfor<8>([&](auto ci) { cell<decltype(ci)::value, EDGE, NQ>(T[decltype(ci)::value], Wc, WN, Bv2s, D2s, k, END, mi_prev, h1, f, mk, nz); });
+#endif
+    }
+
     /* match-mask words of one seed for target base tb: bit j = (q_j == t_i), neither an N, j >= beg.
      * mw(x, b, rm) loads the NW words precomputed for base b (0..3) of seed x's query: the kernel keeps the four
      * per-base masks in LDS, so a row costs two LDS reads per seed and no plane arithmetic. */
@@ -374,26 +398,31 @@ struct lane2 {
              * skipped updates eh[j] in place, an if/else joins differently allocated versions with a v_mov per column */
             const bool dense = b < bem;                       /* j0 + 8 <= jem: inside every active seed's range */
             const bool nq = (nblk & (1u << b)) != 0;
-            uint32_t dummy = 0;
-            if (dense && !nq) {
-                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
-            }
+            const uint32_t dummy = 0;
+            /* the block's eight columns go through a local array (values, not memory: the bodies take them by reference) */
+            const auto run8 = [&](auto edge, auto nqv, const uint32_t WNc, const uint32_t ENDx, const uint32_t mi_in) {
+                uint32_t T[8];
+                sfor<8>([&](auto ci) { T[decltype(ci)::value] = S.Pr[j0 + decltype(ci)::value]; });
+                block8<decltype(edge)::value, decltype(nqv)::value>(T, Wc, WNc, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
+                sfor<8>([&](auto ci) { S.Pr[j0 + decltype(ci)::value] = T[decltype(ci)::value]; });
+            };
+            using no_t = std::integral_constant<bool, false>;
+            using yes_t = std::integral_constant<bool, true>;
+            if (dense && !nq) run8(no_t{}, no_t{}, 0u, END2, dummy);
             if (dense && nq) {
-                const uint32_t WNc = wn(c);
-                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, false, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
+                const uint32_t WNr = wn(c);
+                run8(no_t{}, yes_t{}, (b & 1) ? (WNr >> 8) : WNr, END2, dummy);     /* the block's N bits in bits 0..7 of each half */
             }
             if (!dense && !nq) {
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));     /* mi of column j0 - 1 */
-                uint32_t mi_prev = pk_nzmask(d0);
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
-                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, false>(S.Pr[j0 + decltype(ci)::value], Wc, 0u, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
+                run8(yes_t{}, no_t{}, 0u, ENDr, pk_nzmask(d0));
             }
             if (!dense && nq) {
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
-                uint32_t mi_prev = pk_nzmask(d0);
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));
-                const uint32_t WNc = wn(c);
-                sfor<8>([&](auto ci) { cell<j0 + decltype(ci)::value, true, true>(S.Pr[j0 + decltype(ci)::value], Wc, WNc, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
+                const uint32_t WNr = wn(c);
+                run8(yes_t{}, yes_t{}, (b & 1) ? (WNr >> 8) : WNr, ENDr, pk_nzmask(d0));
             }
             /* fold the block into its 64-column group / 16-column chunk (column offsets only touch the low key bits) */
             mkg[g] = pk_max(mkg[g], mkb + (uint32_t)(j0 & 63) * 0x00010001u);
@@ -556,27 +585,25 @@ struct lane2l {
             const uint32_t J0d = j0 * 0x00010001u;
             /* four mutually exclusive bodies as four consecutive `if`s, not an if/else tree: a body that is simply run or
              * skipped updates T[] in place, an if/else joins differently allocated versions with a v_mov per column */
-            if (dense && !nq) {
-                sfor<8>([&](auto ci) { B::template cell<decltype(ci)::value, false, false>(T[decltype(ci)::value], Wc, 0u, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
-            }
+            if (dense && !nq) B::template block8<false, false>(T, Wc, 0u, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8);
             if (dense && nq) {
                 const uint32_t WNr = wn(b >> 1);
-                const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;            /* cell() reads bit C of each half */
-                sfor<8>([&](auto ci) { B::template cell<decltype(ci)::value, false, true>(T[decltype(ci)::value], Wc, WNc, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8); });
+                const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;            /* the block's N bits in bits 0..7 of each half */
+                B::template block8<false, true>(T, Wc, WNc, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8);
             }
             if (!dense && !nq) {
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, J0d);    /* mi of column j0 - 1 */
-                uint32_t mi_prev = pk_nzmask(d0);
+                const uint32_t mi_prev = pk_nzmask(d0);
                 const uint32_t ENDr = pk_subs_vs(END2, J0d);
-                sfor<8>([&](auto ci) { B::template cell<decltype(ci)::value, true, false>(T[decltype(ci)::value], Wc, 0u, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
+                B::template block8<true, false>(T, Wc, 0u, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8);
             }
             if (!dense && nq) {
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, J0d);
-                uint32_t mi_prev = pk_nzmask(d0);
+                const uint32_t mi_prev = pk_nzmask(d0);
                 const uint32_t ENDr = pk_subs_vs(END2, J0d);
                 const uint32_t WNr = wn(b >> 1);
                 const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;
-                sfor<8>([&](auto ci) { B::template cell<decltype(ci)::value, true, true>(T[decltype(ci)::value], Wc, WNc, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8); });
+                B::template block8<true, true>(T, Wc, WNc, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8);
             }
             /* row max: the block's key carries the column inside the block; + j0 makes it absolute (< 256: low byte) */
             mk2 = pk_max(mk2, mkb + J0d);

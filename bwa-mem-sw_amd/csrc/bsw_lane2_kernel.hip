@@ -252,16 +252,6 @@ bool lane2_params_ok(const bsw_dparams &P, int variant)
     return a > 0 && pb >= 0 && pn >= 0 && pb >= pn && a + pb < 256 && P.o_del + P.e_del < 256 && P.o_ins + P.e_ins < 256;
 }
 
-/* the 232-column class (250 bp reads): the same kernel at one wave per SIMD (232 row registers + working set > 256) */
-hipError_t launch_lane2_wide(const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
-                             uint32_t n, bsw_result *out, hipStream_t s)
-{
-    if (n == 0) return hipSuccess;
-    const dim3 grid((n + 511u) / 512u), block(256);
-    hipLaunchKernelGGL((bsw_lane2_kernel<29, 1, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
-    return hipGetLastError();
-}
-
 hipError_t launch_lane2(const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
                         uint32_t n, bsw_result *out, hipStream_t s)
 {

@@ -21,6 +21,7 @@
 
 #include "bsw_device.h"
 #define L2_STAMP(k) ((void)0)
+#define BSW_L2_ASM_BODY 1       /* block bodies as hand-scheduled asm (bsw_lane2_body_asm.inc) */
 #include "bsw_lane2_core.h"
 
 namespace bsw {

@@ -424,8 +424,6 @@ int lane_class_bits(int cls) { return kLaneClasses[cls].bits; }
 bool lane2_params_ok(const bsw_dparams &P, int variant);
 hipError_t launch_lane2(const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
                         uint32_t n, bsw_result *out, hipStream_t s);
-hipError_t launch_lane2_wide(const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
-                             uint32_t n, bsw_result *out, hipStream_t s);
 hipError_t launch_lane2l(int cls, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
                          const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
 
@@ -435,12 +433,10 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
     if (n == 0) return hipSuccess;
     {
         /* the 232-column 8-bit class: two seeds per lane with the blocks walked by a loop and the row in AccVGPRs
-         * (bsw_lane2l_kernel.hip).  BSW_LANE2_WIDE=1 / BSW_NO_LANE2L=1 select the unrolled instantiation / round 1's kernel
-         * instead, BSW_LANE2L_NARROW=1 sends the 136-column class through the looped kernel too (measurements). */
-        static const bool wide = getenv("BSW_LANE2_WIDE") != nullptr, nol = getenv("BSW_NO_LANE2L") != nullptr,
-                          narrow = getenv("BSW_LANE2L_NARROW") != nullptr;
-        if (wide && cls == 1 && variant == BSW_VARIANT_H && P.o_del == P.o_ins && P.e_del == P.e_ins && lane2_params_ok(P, variant))
-            return launch_lane2_wide(P, variant, side, seq, tasks, order, n, out, s);
+         * (bsw_lane2l_kernel.hip; the unrolled kernel instantiated for 232 columns is instruction-cache bound at one wave
+         * per SIMD: profiles/r3/lane2_wide_*).  BSW_NO_LANE2L=1 selects round 1's one-seed-per-lane kernel instead,
+         * BSW_LANE2L_NARROW=1 sends the 136-column class through the looped kernel too (measurements). */
+        static const bool nol = getenv("BSW_NO_LANE2L") != nullptr, narrow = getenv("BSW_LANE2L_NARROW") != nullptr;
         if (!nol && (cls == 1 || (cls == 0 && narrow)) && lane2_params_ok(P, variant))
             return launch_lane2l(cls, P, variant, side, seq, tasks, order, n, out, s);
     }

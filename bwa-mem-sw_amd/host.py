@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libbwasw_mi355.so")
+_LIB = os.environ.get("BSW_LIB_PATH") or os.path.join(_HERE, "libbwasw_mi355.so")   # BSW_LIB_PATH: an experimental build (tools only)
 
 PARAMS = np.dtype([("mat", "i1", (25,)), ("_pad", "i1", (3,)), ("o_del", "<i4"), ("e_del", "<i4"),
                    ("o_ins", "<i4"), ("e_ins", "<i4"), ("w", "<i4"), ("pen_clip5", "<i4"),

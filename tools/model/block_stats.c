@@ -87,6 +87,8 @@ int main(int argc, char **argv)
             if (kmode == 3) { key = t->nrows; }
             if (kmode == 4) { int L = tasks[k].rqlen < tasks[k].rtlen ? tasks[k].rqlen : tasks[k].rtlen; int i; for (i = 0; i < L && tasks[k].rquery[i] == tasks[k].rtarget[i]; ++i) {} key = i; }  /* first mismatch */
             if (kmode == 5) { int L = tasks[k].rqlen < tasks[k].rtlen ? tasks[k].rqlen : tasks[k].rtlen; int sc = tasks[k].h0, mn = 1000; for (int i = 0; i < L; ++i) { sc += tasks[k].rquery[i] == tasks[k].rtarget[i] ? 1 : -4; if (sc < mn) mn = sc; } key = mn; }
+            if (kmode == 6) key = -tasks[k].h0;
+            if (kmode == 7) key = -(tasks[k].h0 / 4);
             t->key = key;
         }
         ++nt;
