@@ -16,7 +16,7 @@ def main():
         text = open(sys.argv[1]).read()
     else:
         out = os.path.join(tempfile.mkdtemp(), "lane2.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-DBSW_L2_ASM_BODY=1", "-I", os.path.join(ROOT, "include"), "-o", out,
                                os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_lane2_kernel.hip")], stderr=subprocess.DEVNULL)
         text = open(out).read()
     lines = text.split("\n")
@@ -29,24 +29,24 @@ def main():
         elif cur is not None:
             m = re.match(r"\s+([vs]_\S+)", l)
             if m: cur[1].append(m.group(1))
+        if "codeLenInByte" in l: break
     valu = lambda ops: [o for o in ops if o.startswith("v_")]
-    # dense body = the smallest of the frequent big basic blocks (16 of the 17 column blocks share its size); the path through a dense
-    # block also runs the operand-extraction block in front of the variants (the 8 match-bit extractions: its signature) and
-    # the register-merge block behind them
-    cnt = collections.Counter(len(valu(b[1])) for b in blocks if len(valu(b[1])) > 80)
-    nd = min(sz for sz, c in cnt.items() if c >= 8)                      # four body variants per column block: the dense one is the smallest
+    # the block bodies are one asm statement each (bsw_lane2_body_asm.inc), so a basic block that holds a body holds the whole
+    # path of one 8-column block: the match-byte extraction in front, the body, the folds behind.  Four variants per column
+    # block (dense / with query Ns / edge / edge with Ns); the dense one is the smallest and by far the most frequent.
+    cnt = collections.Counter(len(valu(b[1])) for b in blocks if len(valu(b[1])) > 100)
+    nd = min(sz for sz, c in cnt.items() if c >= 8)
     di = [k for k, b in enumerate(blocks) if len(valu(b[1])) == nd][3]
-    ext = max(k for k in range(di) if (blocks[k][1].count("v_lshrrev_b32_e32") >= 7 or blocks[k][1].count("v_and_b32_e32") >= 7) and len(valu(blocks[k][1])) < 60)
-    mrg = di + 1                                                        # a register-merge block behind the variants, if the compiler made one
-    has_mrg = blocks[mrg][1].count("v_mov_b32_e32") >= 5 and len(valu(blocks[mrg][1])) < 30
-    ops = blocks[ext][1] + blocks[di][1] + (blocks[mrg][1] if has_mrg else [])
+    ops = blocks[di][1]
+    ext = mrg = di
+    has_mrg = False
     hist = collections.Counter(ops)
     v = valu(ops)
     cyc = sum(2 if o in FAST else 4 for o in v)
     pair_cells = 8
     cells_per_cycle_per_simd = 2 * 64 * pair_cells / cyc                 # two seeds per lane
     peak_gcups = cells_per_cycle_per_simd * 1024 * 2.4
-    res = {"kernel": "bsw_lane2_kernel<17,2>", "dense_path_valu_insts": len(v), "of_which_extraction_block": len(valu(blocks[ext][1])), "of_which_merge_block": len(valu(blocks[mrg][1])) if has_mrg else 0, "valu_insts_per_pair_cell": round(len(v) / pair_cells, 2),
+    res = {"kernel": "bsw_lane2_kernel<17,2>", "dense_path_valu_insts": len(v), "valu_insts_per_pair_cell": round(len(v) / pair_cells, 2),
            "full_rate_insts": sum(1 for o in v if o in FAST), "half_rate_insts": sum(1 for o in v if o not in FAST),
            "s_nop": hist.get("s_nop", 0), "salu_other": sum(c for o, c in hist.items() if o.startswith("s_") and o != "s_nop"),
            "nominal_cycles_per_block": cyc, "peak_gcups_dense_body_back_to_back": round(peak_gcups, 1),
