@@ -33,8 +33,9 @@ struct bsw_ref {
 };
 
 /* BSW_KERNEL_AUTO: a lane launch costs one wave's full duration (~1.3 ms for 150 bp seeds) however few seeds it
- * holds, the wave-per-task kernel scales with the seed count; measured crossover ~22k seeds (tools/crossover.py) */
-#define LANE_AUTO_MIN 20000
+ * holds, the wave-per-task kernel scales with the seed count; measured crossover 24.5k seeds (tools/crossover.py,
+ * profiles/r3/crossover_wave_vs_lane.json) */
+#define LANE_AUTO_MIN 24000
 #define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
 #define RAW_FRONT 32                 /* ... and in front of the first one (reversed left queries) */
 

@@ -574,36 +574,28 @@ struct lane2l {
         const uint32_t nblk = opaque_s(u.nblk);
         uint32_t T[8];
         row.load8(blo, T);
-        for (int b = blo; b <= bhi; ++b) {
+        /* one block: `edge` is a compile-time property of the loop it runs in (below), only the N test is per block */
+        const auto step = [&](const int b, auto edge_c) {
+            constexpr bool EDGE = decltype(edge_c)::value;
             const uint32_t j0 = 8u * (uint32_t)b;
             uint32_t wa, wb;
             row.get_rm(b >> 2, wa, wb);
             const uint32_t Wc = byte_pair_dyn(wa, wb, (uint32_t)b & 3u);
-            uint32_t mkb = 0, nz8 = 0, dummy = 0;
-            const bool dense = b < bem;
+            uint32_t mkb = 0, nz8 = 0;
             const bool nq = ((nblk >> b) & 1u) != 0;
             const uint32_t J0d = j0 * 0x00010001u;
-            /* four mutually exclusive bodies as four consecutive `if`s, not an if/else tree: a body that is simply run or
-             * skipped updates T[] in place, an if/else joins differently allocated versions with a v_mov per column */
-            if (dense && !nq) B::template block8<false, false>(T, Wc, 0u, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8);
-            if (dense && nq) {
+            uint32_t ENDx = END2, mi_in = 0;
+            if (EDGE) {
+                mi_in = pk_nzmask(pk_subs_vs(END2 + 0x00010001u, J0d));     /* mi of column j0 - 1 */
+                ENDx = pk_subs_vs(END2, J0d);
+            }
+            /* two mutually exclusive bodies as two consecutive `if`s, not an if/else: a body that is simply run or skipped
+             * updates T[] in place, an if/else joins differently allocated versions with a v_mov per column */
+            if (!nq) B::template block8<EDGE, false>(T, Wc, 0u, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
+            if (nq) {
                 const uint32_t WNr = wn(b >> 1);
                 const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;            /* the block's N bits in bits 0..7 of each half */
-                B::template block8<false, true>(T, Wc, WNc, Bv2, D2, k, END2, dummy, h1, f, mkb, nz8);
-            }
-            if (!dense && !nq) {
-                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, J0d);    /* mi of column j0 - 1 */
-                const uint32_t mi_prev = pk_nzmask(d0);
-                const uint32_t ENDr = pk_subs_vs(END2, J0d);
-                B::template block8<true, false>(T, Wc, 0u, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8);
-            }
-            if (!dense && nq) {
-                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, J0d);
-                const uint32_t mi_prev = pk_nzmask(d0);
-                const uint32_t ENDr = pk_subs_vs(END2, J0d);
-                const uint32_t WNr = wn(b >> 1);
-                const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;
-                B::template block8<true, true>(T, Wc, WNc, Bv2, D2, k, ENDr, mi_prev, h1, f, mkb, nz8);
+                B::template block8<EDGE, true>(T, Wc, WNc, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
             }
             /* row max: the block's key carries the column inside the block; + j0 makes it absolute (< 256: low byte) */
             mk2 = pk_max(mk2, mkb + J0d);
@@ -618,7 +610,14 @@ struct lane2l {
             Fnz = pk_min(Fnz, pk_adds_vs(pk_sub_vs(lb, k.ONE2), J0h));
             Lnz = pk_max(Lnz, pk_mad_vsv(pk_min_vs(nz8, k.ONE2), J0h, nz8));
             row.swap8(b, T);                                 /* eh[8b ..] <- T, T <- eh[8b + 8 ..] */
-        }
+        };
+        /* the blocks below every active seed's `end` first (mask-free bodies), then the ones that hold some seed's `end`:
+         * two loops, so that the dense / edge decision costs no scalar instructions per block (at one wave per SIMD the
+         * scalar instructions of the block loop take issue slots like everything else) */
+        int b = blo;
+        const int bd = imin(bem - 1, bhi);
+        for (; b <= bd; ++b) step(b, std::integral_constant<bool, false>{});
+        for (; b <= bhi; ++b) step(b, std::integral_constant<bool, true>{});
         L2_STAMP(3);
         sfor<2>([&](auto xi) {
             constexpr int x = decltype(xi)::value;

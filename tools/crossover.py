@@ -6,9 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
 host = graft.load_package().host
 p = host.default_params()
-tasks, arena = host.synth_tasks(65536, seed=5)
+tasks, arena = host.synth_tasks(131072, seed=5)
 out = []
-for n in (256, 1024, 2048, 4096, 8192, 16384, 65536):
+for n in (256, 1024, 2048, 4096, 8192, 12288, 16384, 20480, 24576, 32768, 65536, 131072):
     row = {"seeds": n}
     for name, kern in (("wave_ms", host.KERNEL_WAVE), ("lane_ms", host.KERNEL_LANE)):
         with host.BswContext(device=0, kernel=kern) as ctx:
