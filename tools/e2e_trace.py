@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One warm-up + N timed bsw_submit passes over a registered arena (for rocprofv3 --kernel-trace --memory-copy-trace).
-Fourth argument "ref": bsw_submit_ref against a 64 Mbp device-resident synthetic genome instead."""
+Fourth argument "ref": bsw_submit_ref against a 64 Mbp device-resident synthetic genome instead; "packed": bsw_submit_packed."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,9 +27,16 @@ if refmode:
             time.sleep(0.01)
         ctx.ref_free(ref)
     sys.exit(0)
+packed = len(sys.argv) > 4 and sys.argv[4] == "packed"
+if packed:
+    need = int(host.lib().bsw_pack_tasks_bound(tasks.ctypes.data, len(tasks)))
+    pa = host.HostArena(need + 64)
+    tasks, _w = host.pack_tasks(tasks, pa.view(np.uint64, need // 8 + 1))
 with host.BswContext(device=0, streams=streams, chunk_tasks=chunk) as ctx:
-    ctx.extend_pairs(p, tasks, out=obuf)
+    fn = ctx.extend_pairs_packed if packed else ctx.extend_pairs
+    fn(p, tasks, out=obuf)
     for _ in range(2):
+        time.sleep(0.01)
         t0 = time.perf_counter()
-        ctx.extend_pairs(p, tasks, out=obuf)
+        fn(p, tasks, out=obuf)
         print("pass %.3f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
