@@ -326,6 +326,33 @@ struct lane2 {
 #endif
     }
 
+    /* The ragged blocks of a row, column by column with a wave-uniform guard (no query N in the block):
+     *   !EDGE: the row's FIRST block — columns below `guard` = jlo & 7 lie left of every active seed's beg; they would
+     *          compute zeros from zeros (h1 = f = 0 there: a seed with beg > 0 starts its row from 0) and are skipped;
+     *    EDGE: the row's LAST block — columns above `guard` = jhi & 7 lie right of every active seed's `end` column;
+     *          every mask is off there (nothing stored, nothing counted) and they are skipped.
+     * On the GPU one asm statement with scalar branches between the columns (bsw_lane2_body_asm.inc). */
+    template <bool EDGE>
+    L2_MFN void block8_seq(uint32_t (&T)[8], const uint32_t Wc, const uint32_t Bv2s, const consts &k, const uint32_t END, const uint32_t mi_in,
+                           const int guard, uint32_t &h1, uint32_t &f, uint32_t &mk, uint32_t &nz)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BSW_L2_ASM_BODY)
+        if constexpr (EDGE) block8_seq_asm<true, VM, SYM>::run(T, Wc, Bv2s, k, END, mi_in, guard, h1, f, mk, nz);
+        else block8_seq_asm<false, VM, SYM>::run(T, Wc, Bv2s, k, guard, h1, f, mk, nz);
+#else
+        uint32_t mi_prev = mi_in;
+        mk = 0; nz = 0;
+        sfor<8>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (EDGE ? c > guard : c < guard) return;
+            /* (column 0 of cell() assigns mk / nz instead of folding: fold by hand when it was not the first one run) */
+            uint32_t mkc = 0, nzc = 0;
+            cell<c, EDGE, false>(T[c], Wc, 0u, Bv2s, 0u, k, END, mi_prev, h1, f, c ? mk : mkc, c ? nz : nzc);
+            if (c == 0) { mk = mkc; nz = nzc; }
+        });
+#endif
+    }
+
     /* match-mask words of one seed for target base tb: bit j = (q_j == t_i), neither an N, j >= beg.
      * mw(x, b, rm) loads the NW words precomputed for base b (0..3) of seed x's query: the kernel keeps the four
      * per-base masks in LDS, so a row costs two LDS reads per seed and no plane arithmetic. */
@@ -408,12 +435,42 @@ struct lane2 {
             };
             using no_t = std::integral_constant<bool, false>;
             using yes_t = std::integral_constant<bool, true>;
-            if (dense && !nq) run8(no_t{}, no_t{}, 0u, END2, dummy);
+            /* the ragged first / last block of the row column by column (block8_seq).  Exact either way (the CPU model runs
+             * both).  The looped kernel uses both (250 bp: +4.7 %).  Unrolled, two more bodies for EVERY block grow the code
+             * from 213 to 334 KB and the 150 bp headline drops from 2 360 to 2 215 GCUPS (instruction cache); the last-block
+             * body for the top BSW_L2_RAGGED_TOP blocks of the class alone — where the queries of the class end — lifts it
+             * to 2 478 (sweep 1 / 2 / 3 / 4 / 6 / 17 blocks: 2 384 / 2 461 / 2 478 / 2 478 / 2 377 / 2 313,
+             * profiles/r3/ragged_top_sweep.txt) */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BSW_L2_RAGGED_UNROLLED)
+#ifndef BSW_L2_RAGGED_TOP
+#define BSW_L2_RAGGED_TOP 4
+#endif
+            constexpr bool ragged_f = false, ragged_l = b >= QB - BSW_L2_RAGGED_TOP;      /* only the last block, only at the top of the class */
+#else
+            constexpr bool ragged_f = true, ragged_l = true;
+#endif
+            const bool seqf = ragged_f && dense && !nq && b == blo && (u.jlo & 7) != 0;          /* ragged first block */
+            const bool seql = ragged_l && !dense && !nq && b == bhi && (u.jhi & 7) != 7;         /* ragged last block */
+            if (dense && !nq && !seqf) run8(no_t{}, no_t{}, 0u, END2, dummy);
+            if (seqf) {
+                uint32_t T[8];
+                sfor<8>([&](auto ci) { T[decltype(ci)::value] = S.Pr[j0 + decltype(ci)::value]; });
+                block8_seq<false>(T, Wc, Bv2, k, END2, dummy, u.jlo & 7, h1, f, mkb, nz8);
+                sfor<8>([&](auto ci) { S.Pr[j0 + decltype(ci)::value] = T[decltype(ci)::value]; });
+            }
+            if (seql) {
+                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
+                const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));
+                uint32_t T[8];
+                sfor<8>([&](auto ci) { T[decltype(ci)::value] = S.Pr[j0 + decltype(ci)::value]; });
+                block8_seq<true>(T, Wc, Bv2, k, ENDr, pk_nzmask(d0), u.jhi & 7, h1, f, mkb, nz8);
+                sfor<8>([&](auto ci) { S.Pr[j0 + decltype(ci)::value] = T[decltype(ci)::value]; });
+            }
             if (dense && nq) {
                 const uint32_t WNr = wn(c);
                 run8(no_t{}, yes_t{}, (b & 1) ? (WNr >> 8) : WNr, END2, dummy);     /* the block's N bits in bits 0..7 of each half */
             }
-            if (!dense && !nq) {
+            if (!dense && !nq && !seql) {
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));     /* mi of column j0 - 1 */
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
                 run8(yes_t{}, no_t{}, 0u, ENDr, pk_nzmask(d0));
@@ -591,7 +648,9 @@ struct lane2l {
             }
             /* two mutually exclusive bodies as two consecutive `if`s, not an if/else: a body that is simply run or skipped
              * updates T[] in place, an if/else joins differently allocated versions with a v_mov per column */
-            if (!nq) B::template block8<EDGE, false>(T, Wc, 0u, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
+            const bool seq = !nq && (EDGE ? (b == bhi && (u.jhi & 7) != 7) : (b == blo && (u.jlo & 7) != 0));   /* ragged first / last block */
+            if (!nq && !seq) B::template block8<EDGE, false>(T, Wc, 0u, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
+            if (seq) B::template block8_seq<EDGE>(T, Wc, Bv2, k, ENDx, mi_in, EDGE ? (u.jhi & 7) : (u.jlo & 7), h1, f, mkb, nz8);
             if (nq) {
                 const uint32_t WNr = wn(b >> 1);
                 const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;            /* the block's N bits in bits 0..7 of each half */

@@ -238,6 +238,114 @@ def emit(edge, nq, vm, sym):
     return "\n".join(body), (nvalu, nnop, ntmp)
 
 
+def emit_seq(edge, vm, sym):
+    """The ragged first (dense) / last (edge) block of a row: columns in order, a scalar guard between them — entry guards
+    (skip column c while c < first) for the dense body, exit guards (leave once c > last) for the edge body.  Everything
+    that flows from column to column sits in a fixed register (h1, f, mk, nz, the edge mask); temporaries are per column."""
+    lines, ntmp_max = [], 0
+    lines.append("v_mov_b32_e32 %[mk], 0")
+    lines.append("v_mov_b32_e32 %[nz], 0")
+    for c in range(8):
+        if edge and c:
+            lines += ["s_cmp_gt_i32 %d, %%[G]" % c, "s_cbranch_scc1 9f"]           # c > last: done
+        if not edge and c < 7:
+            lines += ["s_cmp_lt_i32 %d, %%[G]" % c, "s_cbranch_scc1 %df" % (10 + c)]   # c < first: next column
+        P = "%%[P%d]" % c
+        bit = (1 << c) * 0x00010001
+        jj = "0" if c == 0 else "%%[JJ%d]" % c
+        T = lambda i: "%%[T%d]" % i
+        col = []
+        # (temporaries: T0 t/X/M/h-chain, T1 hd, T2 tD, T3 es/en, T4 fs, T5 key/np, T6.. edge)
+        col.append("v_and_b32_e32 %s, 0x%x, %%[Wc]" % (T(0), bit))
+        col.append("v_pk_lshlrev_b16 %s, 8, %s op_sel_hi:[0,1]" % (T(1), P))
+        col.append("v_pk_sub_u16 %s, %s, %%[ED] clamp" % (T(3), P))
+        col.append("v_pk_sub_u16 %s, %%[f], %%[%s] clamp" % (T(4), "ED" if sym else "EI"))
+        col.append("v_pk_mad_u16 %s, %s, %%[MC%d], %s" % (T(0), T(0), c, T(1)))
+        if edge:
+            if c:
+                col.append("v_pk_sub_u16 %s, %%[END], %s clamp" % (T(6), jj))
+                col.append("s_nop 0")
+                col.append("v_pk_mad_u16 %s, %s, -1, 0 op_sel_hi:[1,0,0] clamp" % (T(6), T(6)))
+            else:
+                col.append("v_pk_mad_u16 %s, %%[END], -1, 0 op_sel_hi:[1,0,0] clamp" % T(6))
+        col.append("v_pk_sub_u16 %s, %s, %%[B] clamp" % (T(0), T(0)))
+        if vm:
+            col.append("v_pk_mad_u16 %s, %s, -1, 0 op_sel_hi:[1,0,0] clamp" % (T(1), T(1)))
+            col.append("s_nop 0")
+            col.append("v_and_b32_e32 %s, %s, %s" % (T(0), T(0), T(1)))
+        if vm:
+            col.append("v_pk_sub_u16 %s, %s, %%[OED] clamp" % (T(2), T(0)))            # gaps open from M
+            if not sym:
+                col.append("v_pk_sub_u16 %s, %s, %%[OEI] clamp" % (T(5), T(0)))
+        col.append("v_pk_max_u16 %s, %s, %s" % (T(0), T(0), P))
+        col.append("s_nop 0")
+        col.append("v_pk_max_u16 %s, %s, %%[f]" % (T(0), T(0)))                        # h
+        if not vm:
+            col.append("s_nop 0")
+            col.append("v_pk_sub_u16 %s, %s, %%[OED] clamp" % (T(2), T(0)))
+            if not sym:
+                col.append("v_pk_sub_u16 %s, %s, %%[OEI] clamp" % (T(5), T(0)))
+        col.append("s_nop 0")
+        col.append("v_pk_max_u16 %s, %s, %s" % (T(3), T(3), T(2)))                     # en
+        col.append("v_pk_max_u16 %%[f], %s, %s" % (T(4), T(2) if sym else T(5)))       # f
+        if not edge:
+            col.append("v_and_or_b32 %s, %s, %%[HI], %s" % (T(5), T(0), jj))
+            col.append("v_perm_b32 %s, %s, %%[h1], %%[PERM]" % (P, T(3)))
+            col.append("v_pk_max_u16 %%[mk], %%[mk], %s" % T(5))
+            col.append("v_mov_b32_e32 %%[h1], %s" % T(0))
+            col.append("v_pk_min_u16 %s, %s, %%[ONE]" % (T(4), P))
+            col.append("s_nop 0")
+            col.append("v_lshl_or_b32 %%[nz], %s, %d, %%[nz]" % (T(4), c))
+        else:
+            # T6 = mi (c < end), %[mi] = mw (c <= end) from the previous column
+            col.append("v_and_b32_e32 %s, %s, %s" % (T(5), T(0), T(6)))
+            col.append("v_and_b32_e32 %s, %s, %s" % (T(3), T(3), T(6)))
+            col.append("v_and_or_b32 %s, %s, %%[HI], %s" % (T(5), T(5), jj))
+            col.append("v_perm_b32 %s, %s, %%[h1], %%[PERM]" % (T(3), T(3)))
+            col.append("v_pk_max_u16 %%[mk], %%[mk], %s" % T(5))
+            col.append("v_and_b32_e32 %s, %s, %%[mi]" % (T(3), T(3)))
+            col.append("v_bfi_b32 %%[h1], %s, %s, %%[h1]" % (T(6), T(0)))
+            col.append("v_pk_min_u16 %s, %s, %%[ONE]" % (T(4), T(3)))
+            col.append("v_bfi_b32 %s, %%[mi], %s, %s" % (P, T(3), P))
+            col.append("v_lshl_or_b32 %%[nz], %s, %d, %%[nz]" % (T(4), c))
+            col.append("v_mov_b32_e32 %%[mi], %s" % T(6))
+        lines += col
+        if not edge and c < 7:
+            lines.append("%d:" % (10 + c))
+    lines.append("9:")
+    ntmp = 7
+    sig = ["uint32_t (&P)[8]", "uint32_t Wc", "uint32_t B", "const consts &k"]
+    if edge:
+        sig += ["uint32_t END", "uint32_t mi_in"]
+    sig += ["int guard", "uint32_t &h1", "uint32_t &f", "uint32_t &mk", "uint32_t &nz"]
+    outs_c = ['[P%d] "+v"(P[%d])' % (c, c) for c in range(8)] + ['[h1] "+v"(h1)', '[f] "+v"(f)', '[mk] "=&v"(mk)', '[nz] "=&v"(nz)']
+    if edge:
+        outs_c += ['[mi] "+v"(mi)']
+    outs_c += ['[T%d] "=&v"(t%d)' % (i, i) for i in range(ntmp)]
+    ins_c = ['[Wc] "v"(Wc)', '[B] "v"(B)', '[HI] "v"(k.HI2)', '[G] "s"(guard)']
+    if edge:
+        ins_c += ['[END] "v"(END)']
+    ins_c += ['[MC%d] "s"(k.MC[%d])' % (c, c) for c in range(8)]
+    ins_c += ['[JJ%d] "s"(0x%xu)' % (c, c * 0x00010001) for c in range(1, 8)]
+    ins_c += ['[OED] "s"(k.OED2s)', '[ED] "s"(k.ED2s)', '[ONE] "s"(k.ONE2)', '[PERM] "s"(0x07030501u)']
+    if not sym:
+        ins_c += ['[OEI] "s"(k.OEI2s)', '[EI] "s"(k.EI2s)']
+    body = ["/* ragged %s block, VM=%d SYM=%d: columns in order behind scalar guards */" % ("last (edge)" if edge else "first (dense)", vm, sym)]
+    body.append("__device__ __forceinline__ void block8_seq_asm<%s, %s, %s>::run(%s)" % (*("true" if x else "false" for x in (edge, vm, sym)), ", ".join(sig)))
+    body.append("{")
+    body.append("    uint32_t %s;" % ", ".join("t%d" % i for i in range(ntmp)))
+    if edge:
+        body.append("    uint32_t mi = mi_in;")
+    body.append("    asm volatile(")
+    for l in lines:
+        body.append('        "%s\\n\\t"' % l)
+    body[-1] = body[-1].replace('\\n\\t"', '"')
+    body.append("        : " + ", ".join(outs_c))
+    body.append("        : " + ", ".join(ins_c) + " : \"scc\");")
+    body.append("}")
+    return "\n".join(body)
+
+
 def main():
     print("/* GENERATED by tools/gen_lane2_body.py — do not edit.  The 8-column block bodies of the two-seeds-per-lane kernels as")
     print(" * one list-scheduled inline-asm statement per variant; arithmetic = lane2::cell() of bsw_lane2_core.h. */")
@@ -257,6 +365,16 @@ def main():
         text, st = emit(edge, nq, vm, sym)
         stats[(edge, nq, vm, sym)] = st
         print(text)
+    print("template <bool EDGE, bool VM, bool SYM> struct block8_seq_asm;")
+    for edge, vm, sym in itertools.product((0, 1), repeat=3):
+        sig = ["uint32_t (&P)[8]", "uint32_t Wc", "uint32_t B", "const consts &k"]
+        if edge:
+            sig += ["uint32_t END", "uint32_t mi_in"]
+        sig += ["int guard", "uint32_t &h1", "uint32_t &f", "uint32_t &mk", "uint32_t &nz"]
+        print("template <> struct block8_seq_asm<%s, %s, %s> { static __device__ __forceinline__ void run(%s); };" % (
+            *("true" if x else "false" for x in (edge, vm, sym)), ", ".join(sig)))
+    for edge, vm, sym in itertools.product((0, 1), repeat=3):
+        print(emit_seq(edge, vm, sym))
     print("/* instruction counts (EDGE, NQ, VM, SYM) -> (instructions, s_nop, temporaries): %s */" % stats)
 
 
