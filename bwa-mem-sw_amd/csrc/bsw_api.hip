@@ -234,8 +234,11 @@ static int wait_event(bsw_ctx *ctx, errs &e, hipEvent_t ev)
             ctx->dead = true;
             return fail(e, BSW_E_HIP, "timeout: the GPU did not finish within %d ms; context marked dead", (int)limit);
         }
-        /* poll gently: the runtime serialises queries against the other slots' enqueues */
-        std::this_thread::sleep_for(std::chrono::microseconds(ms < 0.2 ? 5 : 25));
+        /* the first 300 us: spin — a sleep of any length costs ~55 us here (timer slack), a third of a scalar-ABI round
+         * trip (profiles/r3/scalar_call_timeline.txt).  After that poll gently: the runtime serialises queries against the
+         * other slots' enqueues */
+        if (ms < 0.3) { for (int k = 0; k < 64; ++k) __builtin_ia32_pause(); }
+        else std::this_thread::sleep_for(std::chrono::microseconds(25));
     }
 }
 
