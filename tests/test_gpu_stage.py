@@ -420,3 +420,15 @@ def test_bsw_bench_cli(host, oracle, devflag):
         s = (s * 1315423911 + (sc & 0xffffffff) + ((ts & 0xffffffff) << 20) + ((qb * 7) & 0xffffffff) + ((re * 13) & 0xffffffff)) & M
     assert j["seeds"] == n and j["result_checksum"] == "%016x" % s
     assert j["cells"] == int(want["left"]["cells"].astype(np.int64).sum() + want["right"]["cells"].astype(np.int64).sum())
+    # the same seeds handed over 4-bit packed, and with bwa's -O del,ins / -E del,ins syntax on the variant-M recurrence
+    rp = subprocess.run([exe, "-n", str(n), "-b", "16384", "--packed"] + devflag, capture_output=True, text=True, timeout=300)
+    assert rp.returncode == 0, rp.stderr
+    jp = json.loads(rp.stdout.strip().splitlines()[-1])
+    assert jp["packed_input"] == 1 and jp["result_checksum"] == j["result_checksum"] and jp["cells"] == j["cells"]
+    rg = subprocess.run([exe, "-n", "20000", "-O", "6,4", "-E", "1,2", "--variant=M", "--packed"] + devflag, capture_output=True, text=True, timeout=300)
+    assert rg.returncode == 0, rg.stderr
+    jg = json.loads(rg.stdout.strip().splitlines()[-1])
+    tg, _ = host.synth_tasks(20000, seed=1, read_len=150, seed_len_min=19, seed_len_max=60, seed_at_start=0,
+                             sub_rate=0.01, indel_rate=0.001, junk_frac=0.05, n_rate=0.0, a=1, w=100, o=6, e=1)
+    wg = oracle.pair_batch(host.default_params(o_del=6, o_ins=4, e_del=1, e_ins=2, variant=1), tg, nthreads=8)
+    assert jg["cells"] == int(wg["left"]["cells"].astype(np.int64).sum() + wg["right"]["cells"].astype(np.int64).sum())

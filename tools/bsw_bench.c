@@ -5,13 +5,16 @@
  * `bwa --target=ASE|Direct mem -t N -b BATCH ...`) with bwa mem's scoring flags:
  *
  *   bsw-bench [--target=hip] [--gpus G | --devices 0,1,..] [-t gather_threads] [-b batch_seeds] [-n seeds] [-l read_len]
- *             [-A a] [-B b] [-O o] [-E e] [-L clip] [-w band] [-d zdrop] [--variant=H|M] [--reps R] [--pageable]
- *             [--dump FILE | --load FILE]
+ *             [-A a] [-B b] [-O o[,o_ins]] [-E e[,e_ins]] [-L clip] [-w band] [-d zdrop] [--variant=H|M] [--reps R] [--pageable]
+ *             [--packed] [--dump FILE | --load FILE]
  *
  * --target=cpu is refused: the library has no CPU path (the CPU oracle lives under oracle/ and is test-only).
  * --gpus G / --devices: ONE context drives all the GPUs; the library sends chunk k of the seed pool to device
  * k mod G, like the reference's round-robin over its 4 PE arrays (batch_manager.v:343-348) — no inter-GPU traffic.
  * Sequences and results live in bsw_host_alloc memory (DMA direct) unless --pageable.
+ * --packed: the sequences are handed over 4-bit packed (bsw_pack_tasks once, then bsw_submit_packed): what a host does
+ * that keeps its reads packed, as the reference's host does on its link.  -O 6,4 / -E 1,2: deletion,insertion penalties
+ * (bwa's own -O / -E syntax).
  * --dump / --load write / read a self-contained task batch (params + seeds + sequences) for reproducible runs.
  * Prints one JSON line; result_checksum folds score, truesc, qb and re of every seed in task order.
  *
@@ -78,6 +81,7 @@ static int load_batch(const char *path, int pageable, bsw_params *p, bsw_task **
 
 int main(int argc, char **argv)
 {
+    int packed = 0, o_ins = -1, e_ins = -1;
     int a = 1, b = 4, o = 6, e = 1, clip = 5, w = 100, zdrop = 100, read_len = 150, variant = BSW_VARIANT_H, threads = 4, reps = 1, pageable = 0;
     int ndev = 1, devs[BSW_MAX_DEVICES] = {0}, k, r, c;
     size_t n = 200000, batch = 65536, i;
@@ -85,7 +89,9 @@ int main(int argc, char **argv)
     for (k = 1; k < argc; ++k) {
         const char *f = argv[k], *v = k + 1 < argc ? argv[k + 1] : "";
         if (!strcmp(f, "-A")) a = atoi(v), ++k; else if (!strcmp(f, "-B")) b = atoi(v), ++k;
-        else if (!strcmp(f, "-O")) o = atoi(v), ++k; else if (!strcmp(f, "-E")) e = atoi(v), ++k;
+        else if (!strcmp(f, "-O")) { o = atoi(v); if (strchr(v, ',')) o_ins = atoi(strchr(v, ',') + 1); ++k; }
+        else if (!strcmp(f, "-E")) { e = atoi(v); if (strchr(v, ',')) e_ins = atoi(strchr(v, ',') + 1); ++k; }
+        else if (!strcmp(f, "--packed")) packed = 1;
         else if (!strcmp(f, "-L")) clip = atoi(v), ++k; else if (!strcmp(f, "-w")) w = atoi(v), ++k;
         else if (!strcmp(f, "-d")) zdrop = atoi(v), ++k; else if (!strcmp(f, "-b")) batch = (size_t)atol(v), ++k;
         else if (!strcmp(f, "-n")) n = (size_t)atol(v), ++k; else if (!strcmp(f, "-l")) read_len = atoi(v), ++k;
@@ -114,7 +120,7 @@ int main(int argc, char **argv)
         bsw_synth_spec sp;
         size_t cap;
         for (r = 0; r < 5; ++r) for (c = 0; c < 5; ++c) p.mat[r * 5 + c] = (int8_t)((r == 4 || c == 4) ? -1 : (r == c ? a : -b));
-        p.o_del = p.o_ins = o; p.e_del = p.e_ins = e; p.pen_clip5 = p.pen_clip3 = clip; p.w = w; p.zdrop = zdrop; p.variant = variant;
+        p.o_del = o; p.o_ins = o_ins >= 0 ? o_ins : o; p.e_del = e; p.e_ins = e_ins >= 1 ? e_ins : e; p.pen_clip5 = p.pen_clip3 = clip; p.w = w; p.zdrop = zdrop; p.variant = variant;
         memset(&sp, 0, sizeof(sp));
         sp.seed = 1; sp.read_len = read_len; sp.seed_len_min = 19; sp.seed_len_max = 60; sp.seed_at_start = 0;
         sp.sub_rate = 0.01; sp.indel_rate = 0.001; sp.junk_frac = 0.05; sp.a = a; sp.w = w; sp.o = o; sp.e = e;
@@ -133,10 +139,17 @@ int main(int argc, char **argv)
     bsw_result *res = arena_alloc((n ? n : 1) * sizeof(*res), pageable);
     if (!res) { fprintf(stderr, "out of memory\n"); return 1; }
     memset(res, 0, (n ? n : 1) * sizeof(*res));
+    if (packed) {                                                   /* pack once: the timed passes hand packed words over */
+        const size_t cap = bsw_pack_tasks_bound(tasks, n);
+        uint64_t *parena = arena_alloc(cap, pageable);
+        bsw_task *pt = malloc((n ? n : 1) * sizeof(*pt));
+        if (!parena || !pt || bsw_pack_tasks(tasks, n, parena, cap, pt) < 0) { fprintf(stderr, "packing failed\n"); return 1; }
+        tasks = pt;
+    }
     double best = 1e30;
     for (r = 0; r < reps + (reps > 1); ++r) {                       /* with --reps > 1 the first pass is a warm-up */
         const double t0 = now();
-        rc = bsw_submit(ctx, &p, tasks, n, res);                    /* = ring CSR_REQ_PEARRAY */
+        rc = packed ? bsw_submit_packed(ctx, &p, tasks, n, res) : bsw_submit(ctx, &p, tasks, n, res);   /* = ring CSR_REQ_PEARRAY */
         if (rc == BSW_OK) rc = bsw_wait(ctx);                       /* = poll the DSM busy bits */
         if (rc != BSW_OK) { fprintf(stderr, "%s\n", bsw_last_error(ctx)); return 1; }
         if ((r > 0 || reps == 1) && now() - t0 < best) best = now() - t0;
@@ -147,7 +160,7 @@ int main(int argc, char **argv)
         cells += res[i].left.cells + res[i].right.cells;
         sum = sum * 1315423911ull + (unsigned)res[i].score + ((unsigned long long)(unsigned)res[i].truesc << 20) + (unsigned)res[i].qb * 7u + (unsigned)res[i].re * 13u;
     }
-    printf("{\"seeds\": %zu, \"gpus\": %d, \"seconds\": %.5f, \"seeds_per_s\": %.1f, \"gcups_pcie_inclusive\": %.2f, \"cells\": %llu, \"result_checksum\": \"%016llx\"}\n",
-           n, ndev, best, (double)n / best, (double)cells / best / 1e9, cells, sum);
+    printf("{\"seeds\": %zu, \"packed_input\": %d, \"gpus\": %d, \"seconds\": %.5f, \"seeds_per_s\": %.1f, \"gcups_pcie_inclusive\": %.2f, \"cells\": %llu, \"result_checksum\": \"%016llx\"}\n",
+           n, packed, ndev, best, (double)n / best, (double)cells / best / 1e9, cells, sum);
     return 0;
 }
