@@ -146,7 +146,8 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "bwa-mem-sw_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.c"))):
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.c"))
+                    + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "Makefile"))):
         h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
     return h.hexdigest()[:16]
 

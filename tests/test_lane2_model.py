@@ -193,3 +193,22 @@ def test_top_of_the_score_range(model, host, oracle, ab):
     want = oracle_side(host, oracle, p, tasks, 1, h0s)
     for f in EXTF:
         assert (got[f][idx] == want[f][idx]).all(), f
+
+
+def test_generated_block_bodies_are_current():
+    """bsw_lane2_body_asm.inc is the output of tools/gen_lane2_body.py: the committed file must be what the generator
+    prints (a hand edit, or a generator change without regenerating, would put unreviewed asm into the kernels)."""
+    import sys
+    want = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "gen_lane2_body.py")],
+                                   env={k: v for k, v in os.environ.items() if not k.startswith("L2GEN_")}).decode()
+    have = open(os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_lane2_body_asm.inc")).read()
+    assert have == want
+    # every variant: EDGE x NQ x VM x SYM interleaved bodies + EDGE x VM x SYM ragged bodies
+    assert have.count("block8_asm<") >= 32 and have.count("block8_seq_asm<") >= 16
+    # a packed result is never read by the very next instruction without a wait state (dst forwarding hazard)
+    lines = [l.strip().strip('"').replace("\\n\\t", "") for l in have.splitlines() if l.strip().startswith('"')]
+    for a, b in zip(lines, lines[1:]):
+        if a.startswith("v_pk_") and not b.startswith("s_") and not b.endswith(":"):
+            dst = a.split()[1].rstrip(",")
+            srcs = b.split(None, 2)[2] if len(b.split(None, 2)) > 2 else ""
+            assert dst not in [x.strip().rstrip(",") for x in srcs.replace(",", " ").split()], (a, b)

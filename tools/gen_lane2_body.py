@@ -153,14 +153,14 @@ def allocate(order, ins, outs):
     out_of = {v: r for r, v in outs.items()}
     reg_in = {"h1_in": "h1", "f_in": "f"}
     loc = {}
-    for v in ins:
+    for v in sorted(ins):
         loc[v] = reg_in.get(v, v)                       # input operands keep their own names (P0.., Wc, B, ...)
     busy = {loc[v]: v for v in ins}
     free_tmp, ntmp = [], 0
     inplace = {"mk", "nz"}
     for i, o in enumerate(real):
         # registers whose value dies at this instruction are free for its destination (read-before-write in one op)
-        for s in set(o.srcs):
+        for s in sorted(set(o.srcs)):                    # (sorted: the output must not depend on hash order)
             if last_use.get(s) == i and s not in outs.values():
                 r = loc[s]
                 if busy.get(r) == s:
@@ -258,9 +258,10 @@ def emit_seq(edge, vm, sym):
         # (temporaries: T0 t/X/M/h-chain, T1 hd, T2 tD, T3 es/en, T4 fs, T5 key/np, T6.. edge)
         col.append("v_and_b32_e32 %s, 0x%x, %%[Wc]" % (T(0), bit))
         col.append("v_pk_lshlrev_b16 %s, 8, %s op_sel_hi:[0,1]" % (T(1), P))
-        col.append("v_pk_sub_u16 %s, %s, %%[ED] clamp" % (T(3), P))
-        col.append("v_pk_sub_u16 %s, %%[f], %%[%s] clamp" % (T(4), "ED" if sym else "EI"))
+        col.append("s_nop 0")
         col.append("v_pk_mad_u16 %s, %s, %%[MC%d], %s" % (T(0), T(0), c, T(1)))
+        col.append("v_pk_sub_u16 %s, %s, %%[ED] clamp" % (T(3), P))                   # (two independent ops behind the mad: its
+        col.append("v_pk_sub_u16 %s, %%[f], %%[%s] clamp" % (T(4), "ED" if sym else "EI"))   #  consumer below needs no wait state)
         if edge:
             if c:
                 col.append("v_pk_sub_u16 %s, %%[END], %s clamp" % (T(6), jj))
@@ -309,10 +310,32 @@ def emit_seq(edge, vm, sym):
             col.append("v_bfi_b32 %s, %%[mi], %s, %s" % (P, T(3), P))
             col.append("v_lshl_or_b32 %%[nz], %s, %d, %%[nz]" % (T(4), c))
             col.append("v_mov_b32_e32 %%[mi], %s" % T(6))
-        lines += col
+        lines += [l for l in col if l != "s_nop 0"]
         if not edge and c < 7:
             lines.append("%d:" % (10 + c))
     lines.append("9:")
+    # one wait state wherever a packed (VOP3P) result is read by the very next instruction (dst forwarding hazard);
+    # a label does not separate two instructions, a scalar instruction does
+    fixed, prev = [], None
+    for l in lines:
+        if l.endswith(":"):
+            fixed.append(l)
+            prev = None                                   # (a join: the predecessor is not known statically; see below)
+            continue
+        ops = l.replace(",", " ").split()
+        if prev is not None and prev[0].startswith("v_pk_") and l.startswith("v_") and prev[1] in ops[2:]:
+            fixed.append("s_nop 0")
+        fixed.append(l)
+        prev = ops
+    # at a label the fall-through predecessor is the instruction above it: check that pair too
+    out2 = []
+    for i, l in enumerate(fixed):
+        if l.endswith(":") and i > 0 and i + 1 < len(fixed):
+            a, b = fixed[i - 1].replace(",", " ").split(), fixed[i + 1].replace(",", " ").split()
+            if a[0].startswith("v_pk_") and fixed[i + 1].startswith("v_") and a[1] in b[2:]:
+                out2.append("s_nop 0")
+        out2.append(l)
+    lines = out2
     ntmp = 7
     sig = ["uint32_t (&P)[8]", "uint32_t Wc", "uint32_t B", "const consts &k"]
     if edge:
