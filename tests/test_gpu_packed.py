@@ -61,3 +61,23 @@ def test_packed_rejects_misaligned_pointers(host, ctx):
     with pytest.raises(host.BswError):
         ctx.extend_pairs_packed(host.default_params(), pt)
     assert len(ctx.extend_pairs(host.default_params(), tasks)) == 10      # the context survives the refusal
+
+
+def test_packed_over_several_devices_and_empty_batches(host, oracle):
+    """chunk k -> devices[k mod n] with packed input (the same ordinal twice on this one-GPU box); n = 0; a ragged tail"""
+    n = 40000
+    tasks, arena = host.synth_tasks(n, seed=62, **MIXED)
+    p = host.default_params(variant=1, o_ins=4, e_ins=2)
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    need = int(host.lib().bsw_pack_tasks_bound(tasks.ctypes.data, len(tasks)))
+    ha = host.HostArena(need + 64)
+    pt, words = host.pack_tasks(tasks, ha.view(np.uint64, need // 8 + 1))
+    with host.BswContext(devices=[0, 0], kernel=host.KERNEL_LANE, streams=2, chunk_tasks=3000) as c:
+        assert_same(c.extend_pairs_packed(p, pt), want, tasks)
+        assert_same(c.extend_pairs_packed(p, pt[:2999]), want[:2999])
+        assert len(c.extend_pairs_packed(p, pt[:0])) == 0
+        b = c.upload_packed(p, pt[:0])
+        c.run(b); c.sync()
+        assert len(c.download(b)) == 0
+        b.free()
+    ha.free()
