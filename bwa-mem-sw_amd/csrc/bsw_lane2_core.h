@@ -83,6 +83,22 @@ L2_FN uint32_t pk_neg(uint32_t a) { uint32_t d; asm("v_pk_sub_u16 %0, 0, %1" : "
 L2_FN uint32_t byte_pair_dyn(uint32_t a, uint32_t b, uint32_t k) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(0x0c000c00u + k * 0x00010001u + 0x00040000u)); return d; }
 L2_FN int popc(uint32_t x) { return __builtin_popcount(x); }
 L2_FN int clz32(uint32_t x) { return __builtin_clz(x); }
+/* the looped kernel's per-block folds (row maximum, K8 trackers: see lane2l::row_body) as one aligned statement, ordered so
+ * that no packed result is read by the instruction behind it */
+L2_FN void fold8(uint32_t &mk2, uint32_t &Fnz, uint32_t &Lnz, uint32_t mkb, uint32_t nz8, uint32_t J0d, uint32_t J0h, uint32_t ONE2)
+{
+    uint32_t t0, t1, t2;
+    asm volatile(".p2align 3\n\t"
+                 "v_pk_min_u16 %[t0], %[nz], %[ONE]\n\t"
+                 "v_pk_add_u16 %[t1], %[mkb], %[J0d]\n\t"
+                 "v_pk_mad_u16 %[t0], %[t0], %[J0h], %[nz]\n\t"
+                 "v_pk_max_u16 %[mk2], %[mk2], %[t1]\n\t"
+                 "v_pk_sub_u16 %[t2], %[t0], %[ONE]\n\t"
+                 "v_pk_max_u16 %[L], %[L], %[t0]\n\t"
+                 "v_pk_min_u16 %[F], %[F], %[t2]"
+                 : [mk2] "+v"(mk2), [F] "+v"(Fnz), [L] "+v"(Lnz), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                 : [nz] "v"(nz8), [mkb] "v"(mkb), [J0d] "s"(J0d), [J0h] "s"(J0h), [ONE] "s"(ONE2));
+}
 /* a wave-uniform value the compiler must re-read here: keeps tests on it from being hoisted out of the row loop */
 L2_FN uint32_t opaque_s(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
 #else
@@ -119,6 +135,13 @@ L2_FN uint32_t pk_neg(uint32_t a) { return pk_sub(0u, a); }
 L2_FN uint32_t byte_pair_dyn(uint32_t a, uint32_t b, uint32_t k) { return ((a >> (8 * k)) & 0xffu) | (((b >> (8 * k)) & 0xffu) << 16); }
 L2_FN int popc(uint32_t x) { return __builtin_popcount(x); }
 L2_FN int clz32(uint32_t x) { return __builtin_clz(x); }
+L2_FN void fold8(uint32_t &mk2, uint32_t &Fnz, uint32_t &Lnz, uint32_t mkb, uint32_t nz8, uint32_t J0d, uint32_t J0h, uint32_t ONE2)
+{
+    const uint32_t key = pk_mad_vsv(pk_min_vs(nz8, ONE2), J0h, nz8);
+    mk2 = pk_max(mk2, mkb + J0d);
+    Lnz = pk_max(Lnz, key);
+    Fnz = pk_min(Fnz, pk_sub_vs(key, ONE2));
+}
 #endif
 
 L2_FN uint32_t dup16(int v) { return (uint32_t)(v & 0xffff) * 0x00010001u; }
@@ -556,7 +579,10 @@ struct lane2 {
  * spends half its time in instruction-cache misses at one wave per SIMD (profiles/r3/lane2_wide_icache.json).
  *   ROW::load8(b, T)            T[c] = eh[8b + c]
  *   ROW::store8(b, T)           eh[8b + c] = T[c]
- *   ROW::swap8(b, T)            eh[8b + c] = T[c], then T[c] = eh[8b + 8 + c]   (one statement: the next block's columns)
+ *   ROW::swap8w(b, T, Wc)       eh[8b + c] = T[c], then T[c] = eh[8b + 8 + c] and Wc = match bytes of block b + 1 (byte
+ *                               (b+1) & 3 of the row's match words (b+1) >> 2, seed A's in [7:0], seed B's in [23:16]):
+ *                               one statement, everything the next block needs under one index-mode window
+ *   ROW::load8w(b, T, Wc)       T[c] = eh[8b + c] and block b's match bytes (the row's first block)
  *   ROW::put_rm(wd, a, b)       this row's match words (32 columns each) of seed A / B, word index static
  *   ROW::get_rm(wd, a, b)       the same, word index chosen at run time
  * Everything that was indexed by the block number at compile time is either block-relative already (key, bit and end
@@ -629,15 +655,13 @@ struct lane2l {
         uint32_t Fnz = 0xffffffffu, Lnz = 0;                /* K8: packed first / last non-zero column trackers */
         const int blo = u.jlo >> 3, bhi = imin(u.jhi >> 3, QB - 1), bem = u.jem >> 3;
         const uint32_t nblk = opaque_s(u.nblk);
-        uint32_t T[8];
-        row.load8(blo, T);
+        uint32_t T[8], Wcur;
+        row.load8w(blo, T, Wcur);
         /* one block: `edge` is a compile-time property of the loop it runs in (below), only the N test is per block */
         const auto step = [&](const int b, auto edge_c) {
             constexpr bool EDGE = decltype(edge_c)::value;
             const uint32_t j0 = 8u * (uint32_t)b;
-            uint32_t wa, wb;
-            row.get_rm(b >> 2, wa, wb);
-            const uint32_t Wc = byte_pair_dyn(wa, wb, (uint32_t)b & 3u);
+            const uint32_t Wc = Wcur;
             uint32_t mkb = 0, nz8 = 0;
             const bool nq = ((nblk >> b) & 1u) != 0;
             const uint32_t J0d = j0 * 0x00010001u;
@@ -656,19 +680,15 @@ struct lane2l {
                 const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;            /* the block's N bits in bits 0..7 of each half */
                 B::template block8<EDGE, true>(T, Wc, WNc, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
             }
-            /* row max: the block's key carries the column inside the block; + j0 makes it absolute (< 256: low byte) */
-            mk2 = pk_max(mk2, mkb + J0d);
-            /* K8: nz8 = non-zero bits of the block's stored eh entries, seed A in [7:0], seed B in [23:16].
-             * first: lowest set bit isolated, minus one (2^k - 1; 0xffff for an empty block), plus j0 << 8, saturating:
-             *        an empty block gives 0xffff and never wins the minimum;
-             * last:  (j0 << 8) + bits for a non-empty block, 0 for an empty one: the maximum keeps the highest block.
+            /* row max: the block's key carries the column inside the block; + j0 makes it absolute (< 256: low byte).
+             * K8: nz8 = non-zero bits of the block's stored eh entries, seed A in [7:0], seed B in [23:16].
+             * last:  key = (j0 << 8) + bits for a non-empty block, 0 for an empty one: the maximum keeps the highest block;
+             * first: key - 1 (no borrow out of the low byte for a non-empty block; 0xffff for an empty one, which never
+             *        wins): the minimum keeps the lowest block, and the tail reads its bits back as (low byte) + 1.
              * (Folding the bits per 32-column word as the unrolled kernel does, with the match words shifted along, was
              * slower here: 1508 vs 1579 GCUPS on the 250 bp workload.) */
-            const uint32_t J0h = J0d << 8;
-            const uint32_t lb = pk_neg(nz8) & nz8;
-            Fnz = pk_min(Fnz, pk_adds_vs(pk_sub_vs(lb, k.ONE2), J0h));
-            Lnz = pk_max(Lnz, pk_mad_vsv(pk_min_vs(nz8, k.ONE2), J0h, nz8));
-            row.swap8(b, T);                                 /* eh[8b ..] <- T, T <- eh[8b + 8 ..] */
+            fold8(mk2, Fnz, Lnz, mkb, nz8, J0d, J0d << 8, k.ONE2);
+            row.swap8w(b, T, Wcur);                          /* eh[8b ..] <- T, T <- eh[8b + 8 ..], match bytes of b + 1 */
         };
         /* the blocks below every active seed's `end` first (mask-free bodies), then the ones that hold some seed's `end`:
          * two loops, so that the dense / edge decision costs no scalar instructions per block (at one wave per SIMD the
@@ -701,7 +721,8 @@ struct lane2l {
             s.mx = gt ? m : s.mx;
             /* K8 next-row range from the packed trackers */
             const uint32_t Fx = (Fnz >> sh) & 0xffffu, Lx = (Lnz >> sh) & 0xffffu;
-            const uint32_t fnzu = Fx == 0xffffu ? 0xffffffffu : (Fx >> 8) + (uint32_t)popc(Fx & 0xffu);
+            const uint32_t fb = (Fx & 0xffu) + 1u;                                  /* the first non-empty block's bits */
+            const uint32_t fnzu = Fx == 0xffffu ? 0xffffffffu : (Fx >> 8) + (uint32_t)popc(~fb & (fb - 1u));
             const int lnz = Lx == 0 ? -1 : (int)(Lx >> 8) + (31 - clz32(Lx & 0xffu));
             const int fnz = fnzu < (uint32_t)s.end ? (int)fnzu : s.end;
             const int nbeg = fnz;

@@ -22,6 +22,7 @@
 #include "bsw_device.h"
 #define L2_STAMP(k) ((void)0)
 #define BSW_L2_ASM_BODY 1       /* block bodies as hand-scheduled asm (bsw_lane2_body_asm.inc) */
+#define BSW_L2_GRID 1           /* ... in their 64-bit-aligned encoding: one wave per SIMD sees every fetch bubble */
 #include "bsw_lane2_core.h"
 
 namespace bsw {
@@ -64,34 +65,72 @@ struct acc_row {
     static constexpr int RM = QMAX + 8;
     __device__ __forceinline__ void load8(int b, uint32_t (&T)[8]) const
     {
-        asm volatile("s_set_gpr_idx_on %8, 0x1\n\ts_nop 0\n\t"
+        asm volatile(".p2align 3\n\ts_set_gpr_idx_on %8, 0x1\n\ts_nop 0\n\t"
                      "v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\t"
                      "v_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\t"
-                     "s_set_gpr_idx_off"
+                     "s_set_gpr_idx_off\n\ts_nop 0"
                      : "=v"(T[0]), "=v"(T[1]), "=v"(T[2]), "=v"(T[3]), "=v"(T[4]), "=v"(T[5]), "=v"(T[6]), "=v"(T[7])
                      : "s"(8 * b));
     }
     __device__ __forceinline__ void store8(int b, const uint32_t (&T)[8])
     {
-        asm volatile("s_set_gpr_idx_on %8, 0x8\n\ts_nop 0\n\t"
+        asm volatile(".p2align 3\n\ts_set_gpr_idx_on %8, 0x8\n\ts_nop 0\n\t"
                      "v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %1\n\tv_accvgpr_write_b32 a2, %2\n\tv_accvgpr_write_b32 a3, %3\n\t"
                      "v_accvgpr_write_b32 a4, %4\n\tv_accvgpr_write_b32 a5, %5\n\tv_accvgpr_write_b32 a6, %6\n\tv_accvgpr_write_b32 a7, %7\n\t"
-                     "s_set_gpr_idx_off"
+                     "s_set_gpr_idx_off\n\ts_nop 0"
                      :
                      : "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]), "v"(T[5]), "v"(T[6]), "v"(T[7]), "s"(8 * b));
     }
-    /* block b's columns out, block b+1's in: one index value serves both (the reads name a8..a15) */
-    __device__ __forceinline__ void swap8(int b, uint32_t (&T)[8])
+    /* Block b's columns out, block b+1's columns and match bytes in, under one index-mode window: the index serves the
+     * writes as destination offset, then (mode switched) the reads, which name a8..a15, as source offset; the match words
+     * sit at another index.  Every 64-bit instruction of the statement starts on the 8-byte grid (tools/isa_align.py):
+     * the 32-bit scalar instructions come in pairs, each s_set_gpr_idx_* with one the block needs anyway (the word number,
+     * the byte selector of v_perm) — which is also the instruction between the mode change and the first indexed move. */
+    __device__ __forceinline__ void swap8w(int b, uint32_t (&T)[8], uint32_t &Wc)
     {
-        asm volatile("s_set_gpr_idx_on %8, 0x8\n\ts_nop 0\n\t"
+        uint32_t wa, wb, st, sel;
+        asm volatile(".p2align 3\n\t"
+                     "s_set_gpr_idx_on %[i8], 0x8\n\t"
+                     "s_lshr_b32 %[st], %[b1], 2\n\t"
                      "v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %1\n\tv_accvgpr_write_b32 a2, %2\n\tv_accvgpr_write_b32 a3, %3\n\t"
                      "v_accvgpr_write_b32 a4, %4\n\tv_accvgpr_write_b32 a5, %5\n\tv_accvgpr_write_b32 a6, %6\n\tv_accvgpr_write_b32 a7, %7\n\t"
-                     "s_set_gpr_idx_mode 0x1\n\ts_nop 0\n\t"
+                     "s_set_gpr_idx_mode 0x1\n\t"
+                     "s_and_b32 %[sel], %[b1], 3\n\t"
                      "v_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9\n\tv_accvgpr_read_b32 %2, a10\n\tv_accvgpr_read_b32 %3, a11\n\t"
                      "v_accvgpr_read_b32 %4, a12\n\tv_accvgpr_read_b32 %5, a13\n\tv_accvgpr_read_b32 %6, a14\n\tv_accvgpr_read_b32 %7, a15\n\t"
-                     "s_set_gpr_idx_off"
-                     : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7])
-                     : "s"(8 * b));
+                     "s_set_gpr_idx_idx %[st]\n\t"
+                     "s_lshl_b32 %[st], %[sel], 16\n\t"
+                     "v_accvgpr_read_b32 %[wa], a[%c[RMA]]\n\tv_accvgpr_read_b32 %[wb], a[%c[RMB]]\n\t"
+                     "s_set_gpr_idx_off\n\t"
+                     "s_or_b32 %[sel], %[sel], %[st]\n\t"
+                     "s_add_i32 %[sel], %[sel], 0x0c040c00\n\t"
+                     "v_perm_b32 %[Wc], %[wb], %[wa], %[sel]"
+                     : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7]),
+                       [wa] "=&v"(wa), [wb] "=&v"(wb), [Wc] "=v"(Wc), [st] "=&s"(st), [sel] "=&s"(sel)
+                     : [i8] "s"(8 * b), [b1] "s"(b + 1), [RMA] "i"(RM), [RMB] "i"(RM + NW)
+                     : "scc");
+    }
+    __device__ __forceinline__ void load8w(int b, uint32_t (&T)[8], uint32_t &Wc) const
+    {
+        uint32_t wa, wb, st, sel;
+        asm volatile(".p2align 3\n\t"
+                     "s_set_gpr_idx_on %[i8], 0x1\n\t"
+                     "s_lshr_b32 %[st], %[b0], 2\n\t"
+                     "v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\t"
+                     "v_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\t"
+                     "s_set_gpr_idx_idx %[st]\n\t"
+                     "s_and_b32 %[sel], %[b0], 3\n\t"
+                     "v_accvgpr_read_b32 %[wa], a[%c[RMA]]\n\tv_accvgpr_read_b32 %[wb], a[%c[RMB]]\n\t"
+                     "s_set_gpr_idx_off\n\t"
+                     "s_lshl_b32 %[st], %[sel], 16\n\t"
+                     "s_or_b32 %[sel], %[sel], %[st]\n\t"
+                     "s_nop 0\n\t"
+                     "s_add_i32 %[sel], %[sel], 0x0c040c00\n\t"
+                     "v_perm_b32 %[Wc], %[wb], %[wa], %[sel]"
+                     : "=&v"(T[0]), "=&v"(T[1]), "=&v"(T[2]), "=&v"(T[3]), "=&v"(T[4]), "=&v"(T[5]), "=&v"(T[6]), "=&v"(T[7]),
+                       [wa] "=&v"(wa), [wb] "=&v"(wb), [Wc] "=v"(Wc), [st] "=&s"(st), [sel] "=&s"(sel)
+                     : [i8] "s"(8 * b), [b0] "s"(b), [RMA] "i"(RM), [RMB] "i"(RM + NW)
+                     : "scc");
     }
     template <int WD>
     __device__ __forceinline__ void put_rm_s(uint32_t a, uint32_t b)
@@ -102,14 +141,6 @@ struct acc_row {
     {
         /* wd is a compile-time constant at every call site (sfor): dispatch to the literal register numbers */
         l2::sfor<NW>([&](auto wi) { if (decltype(wi)::value == wd) put_rm_s<decltype(wi)::value>(a, b); });
-    }
-    __device__ __forceinline__ void get_rm(int wd, uint32_t &a, uint32_t &b) const
-    {
-        asm volatile("s_set_gpr_idx_on %2, 0x1\n\ts_nop 0\n\t"
-                     "v_accvgpr_read_b32 %0, a[%c3]\n\tv_accvgpr_read_b32 %1, a[%c4]\n\t"
-                     "s_set_gpr_idx_off"
-                     : "=v"(a), "=v"(b)
-                     : "s"(wd), "i"(RM), "i"(RM + NW));
     }
 };
 
@@ -148,6 +179,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
         for (int r1 = 0; r1 < NR; ++r1) lds_k1[r1][b] = LB::keep_word(b, 4 * NQ4 + r1);
     }
     __syncthreads();                                                /* the only barrier: the table is shared by the four waves */
+#ifdef L2L_PAD
+    asm volatile(".rept " L2L_PAD "\n\ts_nop 0\n\t.endr");
+#endif
 
     typename L::state S;
     acc_row<QMAX, NW> row;

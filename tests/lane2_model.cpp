@@ -20,9 +20,19 @@ struct array_row {
     uint32_t rm[2][NW];
     void load8(int b, uint32_t (&T)[8]) const { for (int c = 0; c < 8; ++c) T[c] = eh[8 * b + c]; }
     void store8(int b, const uint32_t (&T)[8]) { for (int c = 0; c < 8; ++c) eh[8 * b + c] = T[c]; }
-    void swap8(int b, uint32_t (&T)[8]) { store8(b, T); for (int c = 0; c < 8; ++c) T[c] = eh[8 * b + 8 + c]; }
+    uint32_t match_bytes(int b) const
+    {
+        const int wd = (b >> 2) < NW ? b >> 2 : NW - 1;             // (past the last block: any word, the value is unused)
+        return bsw::l2::byte_pair_dyn(rm[0][wd], rm[1][wd], (uint32_t)b & 3u);
+    }
+    void swap8w(int b, uint32_t (&T)[8], uint32_t &Wc)
+    {
+        store8(b, T);
+        for (int c = 0; c < 8; ++c) T[c] = eh[8 * b + 8 + c];
+        Wc = match_bytes(b + 1);
+    }
+    void load8w(int b, uint32_t (&T)[8], uint32_t &Wc) const { load8(b, T); Wc = match_bytes(b); }
     void put_rm(int wd, uint32_t a, uint32_t b) { rm[0][wd] = a; rm[1][wd] = b; }
-    void get_rm(int wd, uint32_t &a, uint32_t &b) const { a = rm[0][wd]; b = rm[1][wd]; }
 };
 
 template <int QB, bool VM, bool SYM, bool LOOP>

@@ -206,7 +206,10 @@ def test_generated_block_bodies_are_current():
     # every variant: EDGE x NQ x VM x SYM interleaved bodies + EDGE x VM x SYM ragged bodies
     assert have.count("block8_asm<") >= 32 and have.count("block8_seq_asm<") >= 16
     # a packed result is never read by the very next instruction without a wait state (dst forwarding hazard)
-    lines = [l.strip().strip('"').replace("\\n\\t", "") for l in have.splitlines() if l.strip().startswith('"')]
+    # (lines are written with the encoding macros L2E = _e32 / _e64, L2W = the wait state, L2A = the alignment)
+    lines = [l.strip().replace('" L2E "', "_e32").replace("L2W ", '"s_nop 0" ').replace('" "', "").strip('"').replace("\\n\\t", "")
+             for l in have.splitlines() if l.strip().startswith(('"', "L2W"))]
+    assert sum(1 for l in lines if l == "s_nop 0") > 50
     for a, b in zip(lines, lines[1:]):
         if a.startswith("v_pk_") and not b.startswith("s_") and not b.endswith(":"):
             dst = a.split()[1].rstrip(",")

@@ -13,7 +13,7 @@ scan over the final order, and an s_nop 0 is emitted only where a packed result 
 
 Variants: EDGE (the block holds some seed's `end`: per-column masks), NQ (some query has an N in the block), VM (variant M),
 SYM (one shared gap-open term).  Usage: gen_lane2_body.py > bsw_lane2_body_asm.inc"""
-import itertools
+import itertools, re
 import sys
 
 import os
@@ -185,6 +185,52 @@ def allocate(order, ins, outs):
     return loc, ntmp
 
 
+def on_grid(lines):
+    """Two encodings of one body, chosen where the .inc is included (BSW_L2_GRID):
+    * on the grid, for the looped kernel (one wave per SIMD): every instruction as a 64-bit encoding and the statement
+      aligned to 8 bytes — a 64-bit instruction that starts 4 (mod 8) is dearer to fetch (tools/isa_align.py; one dword of
+      shift cost that kernel 7 %).  VOP1/VOP2 forms without a literal take their VOP3 (_e64) encoding, the wait state is
+      a 64-bit v_nop, scalar instructions come in pairs (s_cmp + s_cbranch);
+    * compact, for the unrolled kernel (two waves per SIMD hide the fetch, the instruction cache is what it is short of,
+      and a v_nop would take a VALU slot from the other wave): _e32 forms, s_nop, no alignment.
+    The choice is made by three string macros the lines are written with: L2A, L2E, L2W."""
+    out, nsalu = ["\x03"], 0
+    for l in lines:
+        if l.endswith(":"):
+            assert nsalu % 2 == 0
+            out.append(l)
+            continue
+        if l == "s_nop 0":
+            out.append("\x02")
+            continue
+        if l.startswith("s_"):
+            nsalu += 1
+            out.append(l)
+            continue
+        assert nsalu % 2 == 0, l
+        m = l.split()[0]
+        if m.endswith("_e32"):
+            lit = any(re.fullmatch(r"0x[0-9a-f]+", t) and int(t, 16) > 64 for t in l.replace(",", " ").split()[1:])
+            if not lit:
+                l = l.replace("_e32", "\x01", 1)
+        out.append(l)
+    assert nsalu % 2 == 0
+    return out
+
+
+def c_string(l, last=False):
+    """One asm line as a C string literal (the encoding macros spliced in)."""
+    end = "" if last else "\\n\\t"
+    if l == "\x03":
+        return "L2A"
+    if l == "\x02":
+        return 'L2W "%s"' % end
+    if "\x01" in l:
+        h, t = l.split("\x01")
+        return '"%s" L2E "%s%s"' % (h, t, end)
+    return '"%s%s"' % (l, end)
+
+
 def emit(edge, nq, vm, sym):
     ops, ins, outs = build(edge, nq, vm, sym)
     order = schedule(ops, ins, outs)
@@ -201,6 +247,7 @@ def emit(edge, nq, vm, sym):
         lines.append(o.fmt.replace("{d}", d).format(*srcs) if "{0}" in o.fmt else o.fmt.replace("{d}", d))
     nvalu = sum(1 for o in order if o != "nop")
     nnop = sum(1 for o in order if o == "nop")
+    lines = on_grid(lines)
     name = "block8_asm"
     sig = ["uint32_t (&P)[8]", "uint32_t Wc"]
     if nq:
@@ -229,9 +276,8 @@ def emit(edge, nq, vm, sym):
     if ntmp:
         body.append("    uint32_t %s;" % ", ".join("t%d" % i for i in range(ntmp)))
     body.append("    asm volatile(")
-    for l in lines:
-        body.append('        "%s\\n\\t"' % l)
-    body[-1] = body[-1].replace('\\n\\t"', '"')
+    for i, l in enumerate(lines):
+        body.append("        " + c_string(l, i == len(lines) - 1))
     body.append("        : " + ", ".join(outs_c))
     body.append("        : " + ", ".join(ins_c) + ");")
     body.append("}")
@@ -255,57 +301,66 @@ def emit_seq(edge, vm, sym):
         jj = "0" if c == 0 else "%%[JJ%d]" % c
         T = lambda i: "%%[T%d]" % i
         col = []
-        # (temporaries: T0 t/X/M/h-chain, T1 hd, T2 tD, T3 es/en, T4 fs, T5 key/np, T6.. edge)
+        # (temporaries: T0 t/X/M/h-chain, T1 hd, T2 tD, T3 es/en, T4 fs/nb, T5 key (tI before it), T6 edge mask)
+        # One column is a serial chain (hd -> X -> M -> me -> h -> tD -> en); what does not depend on it is placed INTO its
+        # gaps (a packed result read by the next instruction costs a wait state, which at one wave per SIMD is an issue slot)
         col.append("v_and_b32_e32 %s, 0x%x, %%[Wc]" % (T(0), bit))
         col.append("v_pk_lshlrev_b16 %s, 8, %s op_sel_hi:[0,1]" % (T(1), P))
-        col.append("s_nop 0")
+        col.append("v_pk_sub_u16 %s, %s, %%[ED] clamp" % (T(3), P))                                   # es
         col.append("v_pk_mad_u16 %s, %s, %%[MC%d], %s" % (T(0), T(0), c, T(1)))
-        col.append("v_pk_sub_u16 %s, %s, %%[ED] clamp" % (T(3), P))                   # (two independent ops behind the mad: its
-        col.append("v_pk_sub_u16 %s, %%[f], %%[%s] clamp" % (T(4), "ED" if sym else "EI"))   #  consumer below needs no wait state)
         if edge:
             if c:
                 col.append("v_pk_sub_u16 %s, %%[END], %s clamp" % (T(6), jj))
-                col.append("s_nop 0")
-                col.append("v_pk_mad_u16 %s, %s, -1, 0 op_sel_hi:[1,0,0] clamp" % (T(6), T(6)))
-            else:
-                col.append("v_pk_mad_u16 %s, %%[END], -1, 0 op_sel_hi:[1,0,0] clamp" % T(6))
-        col.append("v_pk_sub_u16 %s, %s, %%[B] clamp" % (T(0), T(0)))
+        else:
+            col.append("v_pk_sub_u16 %s, %%[f], %%[%s] clamp" % (T(4), "ED" if sym else "EI"))      # fs
+        col.append("v_pk_sub_u16 %s, %s, %%[B] clamp" % (T(0), T(0)))                                  # M
+        if edge:
+            col.append("v_pk_mad_u16 %s, %s, -1, 0 op_sel_hi:[1,0,0] clamp" % (T(6), T(6) if c else "%[END]"))   # mi
         if vm:
             col.append("v_pk_mad_u16 %s, %s, -1, 0 op_sel_hi:[1,0,0] clamp" % (T(1), T(1)))
-            col.append("s_nop 0")
+            if edge:
+                col.append("v_pk_sub_u16 %s, %%[f], %%[%s] clamp" % (T(4), "ED" if sym else "EI"))  # fs
             col.append("v_and_b32_e32 %s, %s, %s" % (T(0), T(0), T(1)))
-        if vm:
-            col.append("v_pk_sub_u16 %s, %s, %%[OED] clamp" % (T(2), T(0)))            # gaps open from M
+            col.append("v_pk_sub_u16 %s, %s, %%[OED] clamp" % (T(2), T(0)))                            # gaps open from M
             if not sym:
                 col.append("v_pk_sub_u16 %s, %s, %%[OEI] clamp" % (T(5), T(0)))
-        col.append("v_pk_max_u16 %s, %s, %s" % (T(0), T(0), P))
-        col.append("s_nop 0")
-        col.append("v_pk_max_u16 %s, %s, %%[f]" % (T(0), T(0)))                        # h
+        elif edge:
+            col.append("v_pk_sub_u16 %s, %%[f], %%[%s] clamp" % (T(4), "ED" if sym else "EI"))      # fs
+        col.append("v_pk_max_u16 %s, %s, %s" % (T(0), T(0), P))                                        # me
+        col.append("v_pk_max_u16 %s, %s, %%[f]" % (T(0), T(0)))                                        # h
         if not vm:
-            col.append("s_nop 0")
             col.append("v_pk_sub_u16 %s, %s, %%[OED] clamp" % (T(2), T(0)))
             if not sym:
                 col.append("v_pk_sub_u16 %s, %s, %%[OEI] clamp" % (T(5), T(0)))
-        col.append("s_nop 0")
-        col.append("v_pk_max_u16 %s, %s, %s" % (T(3), T(3), T(2)))                     # en
-        col.append("v_pk_max_u16 %%[f], %s, %s" % (T(4), T(2) if sym else T(5)))       # f
         if not edge:
-            col.append("v_and_or_b32 %s, %s, %%[HI], %s" % (T(5), T(0), jj))
-            col.append("v_perm_b32 %s, %s, %%[h1], %%[PERM]" % (P, T(3)))
+            if sym:
+                col.append("v_mov_b32_e32 %s, %%[h1]" % T(6))                                          # H(i,j-1) for the stored pair
+                col.append("v_mov_b32_e32 %%[h1], %s" % T(0))
+            col.append("v_pk_max_u16 %s, %s, %s" % (T(3), T(3), T(2)))                                 # en
+            col.append("v_pk_max_u16 %%[f], %s, %s" % (T(4), T(2) if sym else T(5)))                   # f
+            col.append("v_and_or_b32 %s, %s, %%[HI], %s" % (T(5), T(0), jj))                           # key
+            if sym:
+                col.append("v_perm_b32 %s, %s, %s, %%[PERM]" % (P, T(3), T(6)))
+            else:
+                col.append("v_perm_b32 %s, %s, %%[h1], %%[PERM]" % (P, T(3)))
+                col.append("v_mov_b32_e32 %%[h1], %s" % T(0))
             col.append("v_pk_max_u16 %%[mk], %%[mk], %s" % T(5))
-            col.append("v_mov_b32_e32 %%[h1], %s" % T(0))
             col.append("v_pk_min_u16 %s, %s, %%[ONE]" % (T(4), P))
-            col.append("s_nop 0")
             col.append("v_lshl_or_b32 %%[nz], %s, %d, %%[nz]" % (T(4), c))
         else:
             # T6 = mi (c < end), %[mi] = mw (c <= end) from the previous column
-            col.append("v_and_b32_e32 %s, %s, %s" % (T(5), T(0), T(6)))
-            col.append("v_and_b32_e32 %s, %s, %s" % (T(3), T(3), T(6)))
-            col.append("v_and_or_b32 %s, %s, %%[HI], %s" % (T(5), T(5), jj))
-            col.append("v_perm_b32 %s, %s, %%[h1], %%[PERM]" % (T(3), T(3)))
+            if sym:
+                col.append("v_and_b32_e32 %s, %s, %s" % (T(5), T(0), T(6)))                             # h & mi
+            col.append("v_pk_max_u16 %s, %s, %s" % (T(3), T(3), T(2)))                                 # en
+            col.append("v_pk_max_u16 %%[f], %s, %s" % (T(4), T(2) if sym else T(5)))                   # f
+            if not sym:
+                col.append("v_and_b32_e32 %s, %s, %s" % (T(5), T(0), T(6)))                             # h & mi (T5 held tI until f)
+            col.append("v_and_or_b32 %s, %s, %%[HI], %s" % (T(5), T(5), jj))                           # key
+            col.append("v_and_b32_e32 %s, %s, %s" % (T(3), T(3), T(6)))                                 # en & mi
             col.append("v_pk_max_u16 %%[mk], %%[mk], %s" % T(5))
-            col.append("v_and_b32_e32 %s, %s, %%[mi]" % (T(3), T(3)))
+            col.append("v_perm_b32 %s, %s, %%[h1], %%[PERM]" % (T(3), T(3)))
             col.append("v_bfi_b32 %%[h1], %s, %s, %%[h1]" % (T(6), T(0)))
+            col.append("v_and_b32_e32 %s, %s, %%[mi]" % (T(3), T(3)))
             col.append("v_pk_min_u16 %s, %s, %%[ONE]" % (T(4), T(3)))
             col.append("v_bfi_b32 %s, %%[mi], %s, %s" % (P, T(3), P))
             col.append("v_lshl_or_b32 %%[nz], %s, %d, %%[nz]" % (T(4), c))
@@ -335,7 +390,7 @@ def emit_seq(edge, vm, sym):
             if a[0].startswith("v_pk_") and fixed[i + 1].startswith("v_") and a[1] in b[2:]:
                 out2.append("s_nop 0")
         out2.append(l)
-    lines = out2
+    lines = on_grid(out2)
     ntmp = 7
     sig = ["uint32_t (&P)[8]", "uint32_t Wc", "uint32_t B", "const consts &k"]
     if edge:
@@ -360,9 +415,8 @@ def emit_seq(edge, vm, sym):
     if edge:
         body.append("    uint32_t mi = mi_in;")
     body.append("    asm volatile(")
-    for l in lines:
-        body.append('        "%s\\n\\t"' % l)
-    body[-1] = body[-1].replace('\\n\\t"', '"')
+    for i, l in enumerate(lines):
+        body.append("        " + c_string(l, i == len(lines) - 1))
     body.append("        : " + ", ".join(outs_c))
     body.append("        : " + ", ".join(ins_c) + " : \"scc\");")
     body.append("}")
@@ -372,6 +426,15 @@ def emit_seq(edge, vm, sym):
 def main():
     print("/* GENERATED by tools/gen_lane2_body.py — do not edit.  The 8-column block bodies of the two-seeds-per-lane kernels as")
     print(" * one list-scheduled inline-asm statement per variant; arithmetic = lane2::cell() of bsw_lane2_core.h. */")
+    print("#if defined(BSW_L2_GRID)")
+    print('#define L2A ".p2align 3\\n\\t"')
+    print('#define L2E "_e64"')
+    print('#define L2W "v_nop_e64"')
+    print("#else")
+    print('#define L2A ""')
+    print('#define L2E "_e32"')
+    print('#define L2W "s_nop 0"')
+    print("#endif")
     print("template <bool EDGE, bool NQ, bool VM, bool SYM> struct block8_asm;")
     for edge, nq, vm, sym in itertools.product((0, 1), repeat=4):
         sig = ["uint32_t (&P)[8]", "uint32_t Wc"]
