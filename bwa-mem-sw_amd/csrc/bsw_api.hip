@@ -925,7 +925,7 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
     if (!ci.packed)
         HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, ci.raw_bias, (uint32_t)n, ci.rev_left ? 1 : 0,
                                    ref ? ref->d_pac[dev_index] : nullptr, ref ? ref->l_pac : 0, ref ? st.d_desc.p : nullptr, st.d_seq.p, s));
-    HIPCHK(e, bsw::launch_bin(ci.bp, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
+    HIPCHK(e, bsw::launch_bin(ci.bp, st.d_seq.p, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
     if (h2d_bytes) *h2d_bytes = (ci.packed ? ci.words * 8 : rawb + n * sizeof(bsw_rawoff)) + n * sizeof(bsw_dtask) + n_desc * sizeof(bsw_refx);
     return BSW_OK;
 }
@@ -959,37 +959,45 @@ extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, si
     plan_segments(ci.plan, seg);
     if (order) {
         /* the device's rules (bsw_bin_count/scan/scatter) replayed on the host: lists by class, lane sides by
-         * (class, query length descending); the order inside one query length is task order here, arbitrary there */
+         * (class, query with / without an N, query length descending); the order inside one query length is task
+         * order here, arbitrary there */
         const bsw_binparams &bp = ci.bp;
         std::vector<uint32_t> cur(BSW_BIN_WORDS, 0), hist(BSW_BIN_WAVE0, 0);
-        auto keys = [&](const bsw_dtask &T, int &k0, int &k1, int &k2) {
+        auto has_n = [](const uint8_t *q, int len) {
+            for (int j = 0; j < len; ++j)
+                if (q[j] >= 4) return 1;
+            return 0;
+        };
+        auto keys = [&](size_t i, int &k0, int &k1, int &k2) {
+            const bsw_dtask &T = dt[i];
             k1 = k2 = -1;
             const int bits = bsw_seed_lane_bits(&bp, T.lqlen, T.rqlen, T.h0);
             if (!bits) { k0 = BSW_BIN_WAVE0 + bsw_wave_class_of(&bp, std::max(T.lqlen, T.rqlen)); return; }
             k0 = BSW_BIN_LANEALL;
-            if (T.lqlen) k1 = (0 * BSW_MAX_LANE_CLASSES + bsw_side_lane_class(&bp, bits, T.lqlen)) * BSW_LANE_QBINS + T.lqlen;
-            if (T.rqlen) k2 = (1 * BSW_MAX_LANE_CLASSES + bsw_side_lane_class(&bp, bits, T.rqlen)) * BSW_LANE_QBINS + T.rqlen;
+            if (T.lqlen) k1 = BSW_BIN_SIDE(0, bsw_side_lane_class(&bp, bits, T.lqlen), has_n(tasks[i].lquery, T.lqlen), T.lqlen);
+            if (T.rqlen) k2 = BSW_BIN_SIDE(1, bsw_side_lane_class(&bp, bits, T.rqlen), has_n(tasks[i].rquery, T.rqlen), T.rqlen);
         };
         for (size_t i = 0; i < n; ++i) {
             int k0, k1, k2;
-            keys(dt[i], k0, k1, k2);
+            keys(i, k0, k1, k2);
             if (k1 >= 0) ++hist[(size_t)k1];
             if (k2 >= 0) ++hist[(size_t)k2];
         }
         for (int side = 0; side < 2; ++side)
             for (int c = 0; c < bp.n_lane; ++c) {
                 uint32_t run = side ? bp.laneR_off[c] : bp.laneL_off[c];
-                for (int q = BSW_LANE_QBINS - 1; q >= 0; --q) {
-                    const size_t idx = (size_t)((side * BSW_MAX_LANE_CLASSES + c) * BSW_LANE_QBINS + q);
-                    cur[idx] = run;
-                    run += hist[idx];
-                }
+                for (int hn = 1; hn >= 0; --hn)
+                    for (int q = BSW_LANE_QBINS - 1; q >= 0; --q) {
+                        const size_t idx = (size_t)BSW_BIN_SIDE(side, c, hn, q);
+                        cur[idx] = run;
+                        run += hist[idx];
+                    }
             }
         for (int c = 0; c < bp.n_wave; ++c) cur[(size_t)(BSW_BIN_WAVE0 + c)] = bp.wave_start[c];
         cur[BSW_BIN_LANEALL] = bp.lane_all_off;
         for (size_t i = 0; i < n; ++i) {
             int k0, k1, k2;
-            keys(dt[i], k0, k1, k2);
+            keys(i, k0, k1, k2);
             order[cur[(size_t)k0]++] = (uint32_t)i;
             if (k1 >= 0) order[cur[(size_t)k1]++] = (uint32_t)i;
             if (k2 >= 0) order[cur[(size_t)k2]++] = (uint32_t)i;
@@ -1984,7 +1992,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
     HIPCHK(e, hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(st.d_woff.p, st.h_woff.p, n * sizeof(bsw_wireoff), hipMemcpyHostToDevice, s));
     HIPCHK(e, bsw::launch_wire_pack((const uint32_t *)st.d_raw.p, st.d_tasks.p, st.d_woff.p, (uint32_t)n, st.d_seq.p, s));
-    HIPCHK(e, bsw::launch_bin(bp, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
+    HIPCHK(e, bsw::launch_bin(bp, st.d_seq.p, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
     rc = enqueue_batch(e, dp, variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, pl, st.d_out.p, s, nullptr);
     if (rc) return rc;
     /* the result DMA is issued by refbatch_collect once the kernels are done: a copy queued now would sit in its DMA

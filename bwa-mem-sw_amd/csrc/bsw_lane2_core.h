@@ -658,27 +658,32 @@ struct lane2l {
         uint32_t T[8], Wcur;
         row.load8w(blo, T, Wcur);
         /* one block: `edge` is a compile-time property of the loop it runs in (below), only the N test is per block */
-        const auto step = [&](const int b, auto edge_c) {
+        /* one block.  KIND 0: the plain body; 1: the ragged body (the row's first / last block, columns in order behind
+         * scalar guards); 2: plain or query-N body by the wave's N mask — the only kind with a test per block */
+        const auto step = [&](const int b, auto edge_c, auto kind_c) {
             constexpr bool EDGE = decltype(edge_c)::value;
+            constexpr int KIND = decltype(kind_c)::value;
             const uint32_t j0 = 8u * (uint32_t)b;
             const uint32_t Wc = Wcur;
             uint32_t mkb = 0, nz8 = 0;
-            const bool nq = ((nblk >> b) & 1u) != 0;
             const uint32_t J0d = j0 * 0x00010001u;
             uint32_t ENDx = END2, mi_in = 0;
             if (EDGE) {
                 mi_in = pk_nzmask(pk_subs_vs(END2 + 0x00010001u, J0d));     /* mi of column j0 - 1 */
                 ENDx = pk_subs_vs(END2, J0d);
             }
-            /* two mutually exclusive bodies as two consecutive `if`s, not an if/else: a body that is simply run or skipped
-             * updates T[] in place, an if/else joins differently allocated versions with a v_mov per column */
-            const bool seq = !nq && (EDGE ? (b == bhi && (u.jhi & 7) != 7) : (b == blo && (u.jlo & 7) != 0));   /* ragged first / last block */
-            if (!nq && !seq) B::template block8<EDGE, false>(T, Wc, 0u, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
-            if (seq) B::template block8_seq<EDGE>(T, Wc, Bv2, k, ENDx, mi_in, EDGE ? (u.jhi & 7) : (u.jlo & 7), h1, f, mkb, nz8);
-            if (nq) {
-                const uint32_t WNr = wn(b >> 1);
-                const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;            /* the block's N bits in bits 0..7 of each half */
-                B::template block8<EDGE, true>(T, Wc, WNc, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
+            if constexpr (KIND == 0) B::template block8<EDGE, false>(T, Wc, 0u, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
+            if constexpr (KIND == 1) B::template block8_seq<EDGE>(T, Wc, Bv2, k, ENDx, mi_in, EDGE ? (u.jhi & 7) : (u.jlo & 7), h1, f, mkb, nz8);
+            if constexpr (KIND == 2) {
+                /* two mutually exclusive bodies as two consecutive `if`s, not an if/else: a body that is simply run or
+                 * skipped updates T[] in place, an if/else joins differently allocated versions with a v_mov per column */
+                const bool nq = ((nblk >> b) & 1u) != 0;
+                if (!nq) B::template block8<EDGE, false>(T, Wc, 0u, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
+                if (nq) {
+                    const uint32_t WNr = wn(b >> 1);
+                    const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;        /* the block's N bits in bits 0..7 of each half */
+                    B::template block8<EDGE, true>(T, Wc, WNc, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
+                }
             }
             /* row max: the block's key carries the column inside the block; + j0 makes it absolute (< 256: low byte).
              * K8: nz8 = non-zero bits of the block's stored eh entries, seed A in [7:0], seed B in [23:16].
@@ -690,13 +695,32 @@ struct lane2l {
             fold8(mk2, Fnz, Lnz, mkb, nz8, J0d, J0d << 8, k.ONE2);
             row.swap8w(b, T, Wcur);                          /* eh[8b ..] <- T, T <- eh[8b + 8 ..], match bytes of b + 1 */
         };
+        using dense_t = std::integral_constant<bool, false>;
+        using edge_t = std::integral_constant<bool, true>;
+        using plain_t = std::integral_constant<int, 0>;
+        using ragged_t = std::integral_constant<int, 1>;
+        using ntest_t = std::integral_constant<int, 2>;
         /* the blocks below every active seed's `end` first (mask-free bodies), then the ones that hold some seed's `end`:
          * two loops, so that the dense / edge decision costs no scalar instructions per block (at one wave per SIMD the
-         * scalar instructions of the block loop take issue slots like everything else) */
+         * scalar instructions of the block loop take issue slots like everything else).  A wave whose queries hold no N
+         * (the usual case) runs loops without any test per block, the ragged first / last block peeled off them. */
         int b = blo;
         const int bd = imin(bem - 1, bhi);
-        for (; b <= bd; ++b) step(b, std::integral_constant<bool, false>{});
-        for (; b <= bhi; ++b) step(b, std::integral_constant<bool, true>{});
+#ifdef BSW_L2L_NOFAST
+        if (false) {
+#else
+        if (nblk == 0) {
+#endif
+            if ((u.jlo & 7) != 0 && b <= bd) { step(b, dense_t{}, ragged_t{}); ++b; }
+            for (; b <= bd; ++b) step(b, dense_t{}, plain_t{});
+            const bool rl = (u.jhi & 7) != 7;
+            const int be = rl ? bhi - 1 : bhi;
+            for (; b <= be; ++b) step(b, edge_t{}, plain_t{});
+            if (rl && b <= bhi) step(b, edge_t{}, ragged_t{});
+        } else {
+            for (; b <= bd; ++b) step(b, dense_t{}, ntest_t{});
+            for (; b <= bhi; ++b) step(b, edge_t{}, ntest_t{});
+        }
         L2_STAMP(3);
         sfor<2>([&](auto xi) {
             constexpr int x = decltype(xi)::value;

@@ -5,9 +5,10 @@
 #include <hip/hip_runtime.h>
 #include "bsw_device.h"
 
-/* layout of the `bins` scratch array (uint32): per (side, lane class, query length) histogram -> cursor,
+/* layout of the `bins` scratch array (uint32): per (side, lane class, query holds an N, query length) histogram -> cursor,
  * then one cursor per wave class list, then the cursor of the list of all lane seeds */
-#define BSW_BIN_WAVE0   (2 * BSW_MAX_LANE_CLASSES * BSW_LANE_QBINS)
+#define BSW_BIN_SIDE(side, cls, has_n, q) ((((side) * BSW_MAX_LANE_CLASSES + (cls)) * 2 + (has_n)) * BSW_LANE_QBINS + (q))
+#define BSW_BIN_WAVE0   (2 * BSW_MAX_LANE_CLASSES * 2 * BSW_LANE_QBINS)
 #define BSW_BIN_LANEALL (BSW_BIN_WAVE0 + BSW_MAX_WAVE_CLASSES)
 #define BSW_BIN_WORDS   (BSW_BIN_LANEALL + 8)
 
@@ -42,7 +43,7 @@ int align_class_count();
 int align_class_of(int qlen, int byte_mode);                 /* -1: query too long for the mode */
 hipError_t launch_align(int cls, const bsw_dparams &P, const uint64_t *seq, const bsw_adtask *tasks, const uint32_t *order, uint32_t n,
                         unsigned long long *blist, bsw_kswr *out, hipStream_t s);
-hipError_t launch_bin(const bsw_binparams &bp, const bsw_dtask *tasks, uint32_t n, uint32_t *bins, uint32_t *order, hipStream_t s);
+hipError_t launch_bin(const bsw_binparams &bp, const uint64_t *seq, const bsw_dtask *tasks, uint32_t n, uint32_t *bins, uint32_t *order, hipStream_t s);
 }  // namespace bsw
 
 #endif

@@ -8,8 +8,11 @@
  * bytes; these kernels do the rest:
  *   bsw_pack_kernel      byte-per-base -> 16 bases per uint64 (codes > 4 become 4 = N)
  *   bsw_bin_count/scan/scatter   counting sort of the seeds into kernel bins: wave-per-task classes
- *                        by eh[] columns per lane, lane bins per side by (class, query length
- *                        descending) — BASELINE.json's "(qlen, tlen, band-width) bins"
+ *                        by eh[] columns per lane, lane bins per side by (class, query with /
+ *                        without an N, query length descending) — BASELINE.json's "(qlen, tlen,
+ *                        band-width) bins"; the N key keeps the wavefronts of the two-seeds-per-
+ *                        lane kernels free of the query-N block bodies (a wave runs them for a
+ *                        block as soon as ONE of its 128 queries has an N there)
  *   bsw_wire_pack_kernel the reference's 256 KiB wire format (8 bases per 32-bit word, first base in
  *                        bits [31:28], one nibble stream per task: proc_element.v:1638,1677) -> seq
  * All three are HBM-bound byte/index work (no MFMA, nothing to tile): coalesced dword loads,
@@ -163,11 +166,24 @@ __global__ __launch_bounds__(256) void bsw_pack_kernel(const uint8_t *__restrict
 }
 
 /* ---- binning ---- */
-__device__ __forceinline__ int bin_side(int side, int cls, int q) { return (side * BSW_MAX_LANE_CLASSES + cls) * BSW_LANE_QBINS + q; }
+__device__ __forceinline__ int bin_side(int side, int cls, int has_n, int q) { return BSW_BIN_SIDE(side, cls, has_n, q); }
+
+/* does the packed sequence (16 bases per word, N = 4) hold an N?  (bases past `len` in the last word are not looked at) */
+__device__ __forceinline__ int packed_has_n(const uint64_t *__restrict__ seq, const uint32_t off, const int len)
+{
+    const int nw = (len + 15) >> 4;
+    uint64_t acc = 0;
+    for (int k = 0; k < nw; ++k) {
+        uint64_t v = seq[off + (uint32_t)k];
+        if (k == nw - 1 && (len & 15)) v &= (1ull << (4 * (len & 15))) - 1ull;
+        acc |= v;
+    }
+    return (acc & 0x4444444444444444ull) != 0;
+}
 
 struct seed_bins { int k0, k1, k2; };      /* class list, left-side bin, right-side bin (-1: none) */
 
-__device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const bsw_dtask &T)
+__device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const uint64_t *__restrict__ seq, const bsw_dtask &T)
 {
     seed_bins s;
     s.k1 = s.k2 = -1;
@@ -177,20 +193,20 @@ __device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const bs
         s.k0 = BSW_BIN_WAVE0 + (c < 0 ? 0 : c);     /* c < 0 cannot happen: the host rejects such seeds */
     } else {
         s.k0 = BSW_BIN_LANEALL;
-        if (T.lqlen) s.k1 = bin_side(0, bsw_side_lane_class(&bp, bits, T.lqlen), T.lqlen);
-        if (T.rqlen) s.k2 = bin_side(1, bsw_side_lane_class(&bp, bits, T.rqlen), T.rqlen);
+        if (T.lqlen) s.k1 = bin_side(0, bsw_side_lane_class(&bp, bits, T.lqlen), packed_has_n(seq, T.lq_off, T.lqlen), T.lqlen);
+        if (T.rqlen) s.k2 = bin_side(1, bsw_side_lane_class(&bp, bits, T.rqlen), packed_has_n(seq, T.rq_off, T.rqlen), T.rqlen);
     }
     return s;
 }
 
-__global__ __launch_bounds__(256) void bsw_bin_count(const bsw_binparams bp, const bsw_dtask *__restrict__ tasks, const uint32_t n,
-                                                     uint32_t *__restrict__ bins)
+__global__ __launch_bounds__(256) void bsw_bin_count(const bsw_binparams bp, const uint64_t *__restrict__ seq,
+                                                     const bsw_dtask *__restrict__ tasks, const uint32_t n, uint32_t *__restrict__ bins)
 {
     __shared__ uint32_t h[BSW_BIN_WAVE0];
     for (int b = threadIdx.x; b < BSW_BIN_WAVE0; b += 256) h[b] = 0;
     __syncthreads();
     for (uint32_t ti = blockIdx.x * 256u + threadIdx.x; ti < n; ti += gridDim.x * 256u) {
-        const seed_bins s = seed_keys(bp, tasks[ti]);
+        const seed_bins s = seed_keys(bp, seq, tasks[ti]);
         if (s.k1 >= 0) atomicAdd(&h[s.k1], 1u);
         if (s.k2 >= 0) atomicAdd(&h[s.k2], 1u);
     }
@@ -199,33 +215,38 @@ __global__ __launch_bounds__(256) void bsw_bin_count(const bsw_binparams bp, con
         if (h[b]) atomicAdd(&bins[b], h[b]);
 }
 
-/* one block: per (side, lane class) turn the query-length histogram into start offsets, longest queries first
- * (a wave then holds equal-length queries and the most work starts first) */
+/* one block: per (side, lane class) turn the two query-length histograms into start offsets — the queries with an N,
+ * longest first, then the ones without (a wave then holds equal-length queries and the most work starts first: a list
+ * that ENDED with the long N queries left a few long waves running alone, 1 743 -> 1 339 GCUPS on the 250 bp workload) */
 __global__ __launch_bounds__(256) void bsw_bin_scan(const bsw_binparams bp, uint32_t *__restrict__ bins)
 {
     __shared__ uint32_t sc[256];
     const int t = threadIdx.x, q = 255 - t;
     for (int side = 0; side < 2; ++side)
         for (int c = 0; c < bp.n_lane; ++c) {
-            const int idx = bin_side(side, c, q);
-            const uint32_t v = bins[idx];
-            sc[t] = v;
-            __syncthreads();
-            for (int d = 1; d < 256; d <<= 1) {
-                const uint32_t add = t >= d ? sc[t - d] : 0u;
+            uint32_t base = side ? bp.laneR_off[c] : bp.laneL_off[c];
+            for (int hn = 1; hn >= 0; --hn) {
+                const int idx = bin_side(side, c, hn, q);
+                const uint32_t v = bins[idx];
+                sc[t] = v;
                 __syncthreads();
-                sc[t] += add;
+                for (int d = 1; d < 256; d <<= 1) {
+                    const uint32_t add = t >= d ? sc[t - d] : 0u;
+                    __syncthreads();
+                    sc[t] += add;
+                    __syncthreads();
+                }
+                bins[idx] = base + sc[t] - v;
+                base += sc[255];
                 __syncthreads();
             }
-            const uint32_t base = side ? bp.laneR_off[c] : bp.laneL_off[c];
-            bins[idx] = base + sc[t] - v;
-            __syncthreads();
         }
     if (t < bp.n_wave) bins[BSW_BIN_WAVE0 + t] = bp.wave_start[t];
     if (t == 0) bins[BSW_BIN_LANEALL] = bp.lane_all_off;
 }
 
-__global__ __launch_bounds__(256) void bsw_bin_scatter(const bsw_binparams bp, const bsw_dtask *__restrict__ tasks, const uint32_t n,
+__global__ __launch_bounds__(256) void bsw_bin_scatter(const bsw_binparams bp, const uint64_t *__restrict__ seq,
+                                                       const bsw_dtask *__restrict__ tasks, const uint32_t n,
                                                        uint32_t *__restrict__ bins, uint32_t *__restrict__ order)
 {
     __shared__ uint32_t cnt[BSW_BIN_WORDS], base[BSW_BIN_WORDS];
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(256) void bsw_bin_scatter(const bsw_binparams bp, c
     s.k0 = s.k1 = s.k2 = -1;
     uint32_t r0 = 0, r1 = 0, r2 = 0;
     if (ti < n) {
-        s = seed_keys(bp, tasks[ti]);
+        s = seed_keys(bp, seq, tasks[ti]);
         r0 = atomicAdd(&cnt[s.k0], 1u);
         if (s.k1 >= 0) r1 = atomicAdd(&cnt[s.k1], 1u);
         if (s.k2 >= 0) r2 = atomicAdd(&cnt[s.k2], 1u);
@@ -316,15 +337,15 @@ hipError_t launch_wire_pack(const uint32_t *wire, const bsw_dtask *tasks, const 
     return hipGetLastError();
 }
 
-hipError_t launch_bin(const bsw_binparams &bp, const bsw_dtask *tasks, uint32_t n, uint32_t *bins, uint32_t *order, hipStream_t s)
+hipError_t launch_bin(const bsw_binparams &bp, const uint64_t *seq, const bsw_dtask *tasks, uint32_t n, uint32_t *bins, uint32_t *order, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(bins, 0, BSW_BIN_WORDS * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     uint32_t blocks = (n + 255u) / 256u;
-    hipLaunchKernelGGL(bsw_bin_count, dim3(blocks > 1024u ? 1024u : blocks), dim3(256), 0, s, bp, tasks, n, bins);
+    hipLaunchKernelGGL(bsw_bin_count, dim3(blocks > 1024u ? 1024u : blocks), dim3(256), 0, s, bp, seq, tasks, n, bins);
     hipLaunchKernelGGL(bsw_bin_scan, dim3(1), dim3(256), 0, s, bp, bins);
-    hipLaunchKernelGGL(bsw_bin_scatter, dim3(blocks), dim3(256), 0, s, bp, tasks, n, bins, order);
+    hipLaunchKernelGGL(bsw_bin_scatter, dim3(blocks), dim3(256), 0, s, bp, seq, tasks, n, bins, order);
     return hipGetLastError();
 }
 

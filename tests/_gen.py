@@ -47,3 +47,17 @@ def random_seeds(rng, n, qmin=1, qmax=140, tfac=2.0, sub=0.03, indel=0.01, junk=
         s["tag"] = int(rng.integers(0, 2 ** 32))
         seeds.append(s)
     return seeds
+
+
+def query_has_n(tasks, arena, side):
+    """Per task: does the left (side 0) / right (side 1) query hold a base code >= 4?  (the binning's second key)"""
+    import numpy as np
+    pf, lf = ("lquery", "lqlen") if side == 0 else ("rquery", "rqlen")
+    base = arena.ctypes.data
+    a = np.asarray(arena).view(np.uint8).ravel()
+    out = np.zeros(len(tasks), bool)
+    for i, (p, l) in enumerate(zip(tasks[pf], tasks[lf])):
+        if l:
+            o = int(p) - base
+            out[i] = bool((a[o:o + int(l)] >= 4).any())
+    return out

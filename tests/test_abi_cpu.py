@@ -142,7 +142,7 @@ def test_pack_bases_matches_reference_packer(host):
 
 def test_batch_plan_bins(host):
     """Host batch manager (no GPU): every seed lands in exactly one kernel bin; lane bins hold each side once,
-    sorted by query length inside a class; N-rich, long or wide-score seeds go to the wave classes."""
+    sorted by (query holds an N, query length descending) inside a class; long or wide-score seeds go to the wave classes."""
     import _gen
     rng = np.random.default_rng(3)
     seeds = _gen.random_seeds(rng, 8000, qmax=300, nrate=0.002, h0max=80)
@@ -180,7 +180,9 @@ def test_batch_plan_bins(host):
                 if len(t) == 0:
                     continue
                 q = t[qf]
-                assert (np.diff(q) <= 0).all() and (q + 1 <= ncol).all()          # longest queries first
+                hn = _gen.query_has_n(tasks, arena, side)[order[seg[base + c]:seg[base + c + 1]]]
+                key = (~hn).astype(np.int64) * 1000 - q.astype(np.int64)
+                assert (np.diff(key) >= 0).all() and (q + 1 <= ncol).all()        # queries with an N first, each part longest first
                 tt = t["h0"].astype(np.int64) + t["lqlen"] + t["rqlen"]
                 # 8-bit classes need h0 + qlen*a + b <= 255 (b = 4: the packed kernel forms H + a + b in 8 bits)
                 assert ((tt + 4 <= 255) if bits == 8 else (tt + 4 > 255) | (np.maximum(t["lqlen"], t["rqlen"]) + 1 > 232)).all()

@@ -30,7 +30,7 @@ def rebase(tasks, arena, dst_u8, content=None):
 @pytest.mark.parametrize("kernel", [0, 1, 2])
 def test_device_binning_matches_the_plan(host, kernel):
     """bsw_bin_* on the GPU must produce the lists bsw_plan_batch promises: same segments, every list a
-    permutation of the host replay's, lane sides sorted by query length (longest first)."""
+    permutation of the host replay's, lane sides sorted by (query holds an N, query length descending)."""
     n = host.LANE_AUTO_MIN + 7000
     tasks, arena = host.synth_tasks(n, seed=5, read_len=250, seed_len_min=19, seed_len_max=120, seed_at_start=0,
                                     junk_frac=0.1, n_rate=0.001)
@@ -45,10 +45,13 @@ def test_device_binning_matches_the_plan(host, kernel):
     for s in range(25):
         lo, hi = int(seg[s]), int(seg[s + 1])
         assert sorted(order[lo:hi]) == sorted(want_order[lo:hi]), s
-    for base, qf in ((9, "lqlen"), (17, "rqlen")):
+    for side, base, qf in ((0, 9, "lqlen"), (1, 17, "rqlen")):
+        hn = _gen.query_has_n(tasks, arena, side)
         for c in range(4):
-            q = tasks[qf][order[seg[base + c]:seg[base + c + 1]]]
-            assert (np.diff(q.astype(np.int64)) <= 0).all()
+            idx = order[seg[base + c]:seg[base + c + 1]]
+            key = (~hn[idx]).astype(np.int64) * 1000 - tasks[qf][idx].astype(np.int64)  # queries with an N first, each part longest first
+            assert (np.diff(key) >= 0).all()
+        assert hn.any() and not hn.all()
 
 
 def test_codes_above_four_are_n(host, oracle, ctx):
