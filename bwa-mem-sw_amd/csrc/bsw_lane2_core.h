@@ -584,7 +584,6 @@ struct lane2 {
  *                               one statement, everything the next block needs under one index-mode window
  *   ROW::load8w(b, T, Wc)       T[c] = eh[8b + c] and block b's match bytes (the row's first block)
  *   ROW::put_rm(wd, a, b)       this row's match words (32 columns each) of seed A / B, word index static
- *   ROW::get_rm(wd, a, b)       the same, word index chosen at run time
  * Everything that was indexed by the block number at compile time is either block-relative already (key, bit and end
  * constants) or folded as it goes: the row max with the absolute column added per block, the first / last non-zero
  * column as a packed running minimum / maximum (K8). */

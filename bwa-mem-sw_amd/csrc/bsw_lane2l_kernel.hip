@@ -11,6 +11,12 @@
  * columns just computed), eight v_accvgpr_read (the next block's), two more reads for the match words.  The compiler
  * never allocates AccVGPRs here (the kernel needs < 256 VGPRs; audited in the build: no compiler v_accvgpr_*, no
  * scratch), the reservation statement below makes the kernel descriptor allocate them.
+ * One wave per SIMD means nothing hides what the wave itself does not issue, so three things a two-wave kernel gets
+ * for free are arranged by hand here (profiles/r3/fetch_alignment.txt): every 64-bit instruction of the block loop
+ * starts on the 8-byte grid of the instruction stream (a body shifted by one dword ran 7 % slower: aligned statements,
+ * all-64-bit encodings, scalar instructions in pairs); the scalar work of a block is fifteen instructions, eight of
+ * them riding in the swap statement's pairs; and a wave none of whose queries holds an N — nine in ten, the bins are
+ * keyed by it (bsw_stage_kernel.hip) — runs block loops without any test, the ragged first / last block peeled off.
  * The per-lane arithmetic is lane2l in bsw_lane2_core.h (shared with the CPU model of the tests; the DP cell itself is
  * the unrolled kernel's function).  The reference's PE handles qlen <= 255 in one datapath (sw_pe_array_sw_extend.v:101-102).
  */
