@@ -342,9 +342,15 @@ def main():
     if len(batches) > 1:                         # kernel time per step = the step's bsw_run calls together
         kern_ms = [float(sum(kern_ms[i:i + len(batches)])) for i in range(0, len(kern_ms), len(batches))]
 
+    # streams kept two deep: two contexts; slots per context and chunk size per input format from the sweeps in
+    # profiles/r3/e2e_hw_queues.txt (the HIP runtime maps streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default)
+    STREAM_CFG = {"bytes": (2, 2 * chunk), "packed": (4, 131072), "ref": (2, chunk)}
+    def stream_threads(kind):
+        return "%d slot threads (2 contexts x %d slots, %d-seed chunks)" % (2 * STREAM_CFG[kind][0], STREAM_CFG[kind][0], STREAM_CFG[kind][1])
+
     def stream_two_in_flight(make_ctx, submit, reps=8):
-        """A stream of batches, two in flight: two contexts of two slots each (4 slot threads in all), submit k+2 issued as
-        soon as k is waited for — how an aligner that keeps producing seed batches uses the library.  Seconds per batch."""
+        """A stream of batches, two in flight: two contexts, submit k+2 issued as soon as k is waited for — how an aligner
+        that keeps producing seed batches uses the library.  Seconds per batch."""
         ca, cb = make_ctx(), make_ctx()
         sa, sb = submit(ca, out_buf), submit(cb, out_buf2)
         sa(); ca.wait(); sb(); cb.wait()                          # warm up both
@@ -376,7 +382,7 @@ def main():
         e2e_stream = None
         if world == 1:
             d2, same2, (ca, cb) = stream_two_in_flight(
-                lambda: host.BswContext(device=local_rank, kernel=args.kernel, streams=2, pack_threads=2, chunk_tasks=2 * chunk),
+                lambda: host.BswContext(device=local_rank, kernel=args.kernel, streams=STREAM_CFG["bytes"][0], pack_threads=2, chunk_tasks=STREAM_CFG["bytes"][1]),
                 lambda c, o: (lambda: c.submit(params, tasks, o)))
             e2e_stream = (d2, same2 and bool(out_buf.tobytes() == res.tobytes()))
             ca.close(); cb.close()
@@ -401,7 +407,7 @@ def main():
         psame = bool(gotp.tobytes() == res.tobytes())
         pctx.close()
         d2, same2, (ca, cb) = stream_two_in_flight(
-            lambda: host.BswContext(device=local_rank, kernel=args.kernel, streams=2, pack_threads=2, chunk_tasks=2 * chunk),
+            lambda: host.BswContext(device=local_rank, kernel=args.kernel, streams=STREAM_CFG["packed"][0], pack_threads=2, chunk_tasks=STREAM_CFG["packed"][1]),
             lambda c, o: (lambda: c.submit_packed(params, ptasks, o)))
         pstream = (d2, same2 and bool(out_buf.tobytes() == res.tobytes()))
         ca.close(); cb.close()
@@ -435,7 +441,7 @@ def main():
         if world == 1:
             refs = {}
             def mk():
-                c = host.BswContext(device=local_rank, kernel=args.kernel, streams=2, pack_threads=2, chunk_tasks=chunk)
+                c = host.BswContext(device=local_rank, kernel=args.kernel, streams=STREAM_CFG["ref"][0], pack_threads=2, chunk_tasks=STREAM_CFG["ref"][1])
                 refs[id(c)] = c.ref_upload(pac, lp)
                 return c
             d2, same2, (ca, cb) = stream_two_in_flight(mk, lambda c, o: (lambda: c.submit_ref(params, refs[id(c)], rtasks, out=o)))
@@ -511,7 +517,7 @@ def main():
             if e2e_stream is not None:
                 out["e2e"]["stream_two_in_flight"] = {
                     "seeds_per_s": round(len(tasks) / e2e_stream[0], 1), "gcups": round(cells / e2e_stream[0] / 1e9, 1),
-                    "ratio_to_hbm_resident": round((cells / e2e_stream[0] / 1e9) / gcups, 3), "host_threads": "4 slot threads (2 contexts x 2 slots)",
+                    "ratio_to_hbm_resident": round((cells / e2e_stream[0] / 1e9) / gcups, 3), "host_threads": stream_threads("bytes"),
                     "batches_timed": 16, "bit_exact_vs_resident_run": e2e_stream[1]}
         if packed_leg is not None:
             pdt, psame, pbytes, pstream = packed_leg
@@ -524,7 +530,7 @@ def main():
                 "bit_exact_vs_resident_run": psame,
                 "stream_two_in_flight": {"seeds_per_s": round(len(tasks) / pstream[0], 1), "gcups": round(cells / pstream[0] / 1e9, 1),
                                          "ratio_to_hbm_resident": round((cells / pstream[0] / 1e9) / gcups, 3),
-                                         "host_threads": "4 slot threads (2 contexts x 2 slots)", "batches_timed": 16,
+                                         "host_threads": stream_threads("packed"), "batches_timed": 16,
                                          "bit_exact_vs_resident_run": pstream[1]}}
         if ref_leg is not None and world == 1:
             rdt, rcells, rsame, rbytes, rlp = ref_leg
@@ -541,7 +547,7 @@ def main():
                 out["e2e_device_reference"]["stream_two_in_flight"] = {
                     "seeds_per_s": round(n_local / ref_stream[0], 1), "gcups": round(rcells / ref_stream[0] / 1e9, 1),
                     "ratio_to_hbm_resident": round((n_local / ref_stream[0]) / (tasks_all * args.steps / dt_all), 3),
-                    "host_threads": "4 slot threads (2 contexts x 2 slots)", "batches_timed": 16, "bit_exact_vs_single_submit": ref_stream[1]}
+                    "host_threads": stream_threads("ref"), "batches_timed": 16, "bit_exact_vs_single_submit": ref_stream[1]}
         if world == 1 and not args.no_cpu_baseline and tasks is not None:
             orc = graft.load_oracle()
             ncpu = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)

@@ -19,7 +19,8 @@ ho = [host.HostArena(n * host.RESULT.itemsize) for _ in range(3)]
 outs = [h.view(host.RESULT, n) for h in ho]
 mode = sys.argv[1] if len(sys.argv) > 1 else "packed"
 src = pt if mode == "packed" else tasks
-for nctx, streams, chunk in [(2, 2, 262144), (2, 2, 131072), (2, 3, 131072), (2, 2, 196608), (3, 2, 131072), (3, 1, 262144), (2, 4, 98304), (2, 1, 524288)]:
+print("GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES"), flush=True)
+for nctx, streams, chunk in [(2, 2, 262144), (2, 2, 131072), (2, 3, 131072), (2, 2, 196608), (3, 2, 131072), (2, 4, 98304), (2, 4, 131072), (2, 3, 98304), (1, 8, 98304), (1, 6, 131072)]:
     ctxs = [host.BswContext(device=0, streams=streams, pack_threads=2, chunk_tasks=chunk) for _ in range(nctx)]
     sub = [(lambda c=c, o=o: (c.submit_packed(p, src, o) if mode == "packed" else c.submit(p, src, o))) for c, o in zip(ctxs, outs)]
     for c, s in zip(ctxs, sub):
