@@ -619,6 +619,14 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         if (len > 0) { if (s < lo) lo = s; if (s + len > hi) hi = s + len; }
     };
     bsw_task tmp;
+    /* H5/H6 per query length, computed once per length and chunk (two integer divisions each: with them per seed they were
+     * most of this pass) */
+    std::vector<uint16_t> gl5((size_t)BSW_MAX_QLEN + 1, 0), gl3((size_t)BSW_MAX_QLEN + 1, 0);
+    const auto glim = [&](std::vector<uint16_t> &tab, int qlen, int clip) -> uint16_t {
+        uint16_t &v = tab[(size_t)qlen];
+        if (!v) v = (uint16_t)gap_limit(p, mx, qlen, clip);       /* >= 1: zero means not computed yet */
+        return v;
+    };
     /* packed input: whether the words can be DMA'd as they lie (registered, compact arena) decides the word offsets, and
      * the staging records are write-combined memory that must not be read back — so the arena span is found first */
     bool packed_direct = false;
@@ -654,8 +662,8 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
             (t.rqlen && (!t.rquery || (t.rtlen && !t.rtarget && !dev_targets))))
             return fail(e, BSW_E_INVAL, "task %zu: NULL sequence pointer", i);
         if (t.wlim_l < 0 || t.wlim_r < 0) return fail(e, BSW_E_INVAL, "task %zu: negative wlim", i);
-        bsw_dtask &d = dt[i];
-        bsw_rawoff &r = ro[i];
+        bsw_dtask d;                                /* built here, stored once: dt[] is write-combined staging */
+        bsw_rawoff r;
         memset(&d, 0, sizeof(d));
         memset(&r, 0, sizeof(r));
         if (packed) {
@@ -701,9 +709,11 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
         d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
         /* H5/H6: host-supplied band limits win over the library's formula (proc_element.v:925,933) */
-        d.wlim_l = (uint16_t)(t.wlim_l > 0 ? std::min(t.wlim_l, 65535) : gap_limit(p, mx, t.lqlen, p->pen_clip5));
-        d.wlim_r = (uint16_t)(t.wlim_r > 0 ? std::min(t.wlim_r, 65535) : gap_limit(p, mx, t.rqlen, p->pen_clip3));
+        d.wlim_l = (uint16_t)(t.wlim_l > 0 ? std::min(t.wlim_l, 65535) : glim(gl5, t.lqlen, p->pen_clip5));
+        d.wlim_r = (uint16_t)(t.wlim_r > 0 ? std::min(t.wlim_r, 65535) : glim(gl3, t.rqlen, p->pen_clip3));
         d.h0 = t.h0; d.init_score = t.init_score; d.qbeg = t.qbeg; d.tag = t.tag;
+        dt[i] = d;
+        if (!packed) ro[i] = r;                     /* (packed input has no byte offsets) */
         /* class counts (the device sorts with the same functions) */
         const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
         const int wc = bsw_wave_class_of(&bp, qm);
