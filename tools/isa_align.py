@@ -6,7 +6,7 @@ s_nop in the prologue) costs 7 % — a 64-bit instruction that starts at an addr
 that starts on the grid, and the block bodies are ~150 64-bit instructions in a row.  The asm statements therefore align
 themselves (.p2align 3) and pair their 32-bit scalar instructions; this tool audits the result:
 
-    python3 tools/isa_align.py bwa-mem-sw_amd/csrc/bsw_lane2l_kernel.hip [-D...] [--kernel SUBSTR]
+    python3 tools/isa_align.py bwa-mem-sw_amd/csrc/bsw_lane2l_kernel.hip [-D...] [--kernel SUBSTR] [--loops]
 
 prints, per kernel, the number of 64-bit instructions on / off the grid, and the longest off-grid runs with their addresses.
 """
@@ -61,6 +61,36 @@ def audit(text, want):
     return res
 
 
+def loops(text, want):
+    """Per backward branch of a kernel (= per loop, spans > 600 bytes): instructions, 64-bit ones, how many of those
+    start off the 8-byte grid."""
+    out, cur, rows = [], None, {}
+    ins = re.compile(r"^\s+(\S+)(.*)//\s*([0-9A-F]+):((?:\s[0-9A-F]{8})+)")
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            rows[cur] = []
+            continue
+        m = ins.match(line)
+        if m and cur:
+            rows[cur].append((int(m.group(3), 16), len(m.group(4).split()), m.group(1), m.group(2).strip()))
+    for k, lst in rows.items():
+        if want and want not in k:
+            continue
+        for a, n, op, rest in lst:
+            if op.startswith("s_cbranch") or op == "s_branch":
+                imm = int(rest.split()[0])
+                if imm >= 32768:
+                    imm -= 65536
+                tgt = a + 4 + imm * 4
+                if tgt < a and a - tgt > 600:
+                    seg = [r for r in lst if tgt <= r[0] <= a]
+                    out.append(dict(kernel=k, start=tgt, end=a, instructions=len(seg), scalar=sum(1 for x in seg if x[2].startswith("s_")),
+                                    wide=sum(1 for x in seg if x[1] >= 2), wide_off_grid=sum(1 for x in seg if x[1] >= 2 and x[0] % 8)))
+    return out
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     want = None
@@ -68,6 +98,14 @@ if __name__ == "__main__":
         i = args.index("--kernel")
         want = args[i + 1]
         del args[i:i + 2]
+    show_loops = "--loops" in args
+    if show_loops:
+        args.remove("--loops")
     src, extra = args[0], args[1:]
-    for k, v in audit(disassemble(src, extra), want).items():
+    text = disassemble(src, extra)
+    for k, v in audit(text, want).items():
         print(k[:70], v)
+    if show_loops:
+        for l in loops(text, want):
+            print("  loop %x..%x: %d instructions (%d scalar), %d 64-bit, %d of them off the grid" % (
+                l["start"], l["end"], l["instructions"], l["scalar"], l["wide"], l["wide_off_grid"]))
