@@ -415,7 +415,7 @@ struct lane2 {
     L2_MFN void row_body(state &S, const consts &k, const int i, const rowv &r, const uni &u, const int (&tb)[2],
                                const QP &qp, const KP &kp, const WN &wn)
     {
-        if (u.anybite) zero_dropped(S, r, u);
+        if (__builtin_expect(u.anybite, 0)) zero_dropped(S, r, u);   /* (rare; 136 masked moves kept out of the hot path's layout) */
         uint32_t rmA[NW], rmB[NW];
         match_words(qp, kp, 0, tb[0], S.s[0].beg, rmA);
         match_words(qp, kp, 1, tb[1], S.s[1].beg, rmB);
@@ -489,7 +489,7 @@ struct lane2 {
                 block8_seq<true>(T, Wc, Bv2, k, ENDr, pk_nzmask(d0), u.jhi & 7, h1, f, mkb, nz8);
                 sfor<8>([&](auto ci) { S.Pr[j0 + decltype(ci)::value] = T[decltype(ci)::value]; });
             }
-            if (dense && nq) {
+            if (__builtin_expect(dense && nq, 0)) {          /* (unlikely: the bins keep the queries with an N apart; cold code out of line) */
                 const uint32_t WNr = wn(c);
                 run8(no_t{}, yes_t{}, (b & 1) ? (WNr >> 8) : WNr, END2, dummy);     /* the block's N bits in bits 0..7 of each half */
             }
@@ -498,7 +498,7 @@ struct lane2 {
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
                 run8(yes_t{}, no_t{}, 0u, ENDr, pk_nzmask(d0));
             }
-            if (!dense && nq) {
+            if (__builtin_expect(!dense && nq, 0)) {
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));
                 const uint32_t WNr = wn(c);

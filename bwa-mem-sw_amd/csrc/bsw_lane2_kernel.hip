@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         L::row_begin(S, i, r);
         if (__builtin_amdgcn_ballot_w64(r.act[0] || r.act[1]) == 0) break;
         L2_STAMP(0);
-        if ((i & (BSW_L2_TCHUNK * 16 - 1)) == 0) {                    /* stage the next 128 target bases of every seed */
+        if (__builtin_expect((i & (BSW_L2_TCHUNK * 16 - 1)) == 0, 0)) {   /* stage the next 128 target bases of every seed (one row in 64: out of line) */
             const int wbase = i >> 4;
             /* all 16 loads are issued before the first is waited for: the index is clamped instead of branched on
              * (words past the end are never used: row i reads word i >> 4 < ntw; seq has slack behind the last word) */
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         u.jem = -wave_max2(max(r.act[0] ? -e0 : INT_MIN, r.act[1] ? -e1 : INT_MIN));
         u.anybite = __builtin_amdgcn_ballot_w64(r.bite[0] || r.bite[1]) != 0;
         u.zl = 0; u.zh = 0;
-        if (u.anybite) {
+        if (__builtin_expect(u.anybite, 0)) {
             u.zl = -wave_max2(max(r.bite[0] ? -r.zlo[0] : INT_MIN, r.bite[1] ? -r.zlo[1] : INT_MIN));
             u.zh = wave_max2(max(r.bite[0] ? r.zhi[0] : INT_MIN, r.bite[1] ? r.zhi[1] : INT_MIN));
         }
