@@ -182,7 +182,7 @@ int      bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, si
 int      bsw_wait(bsw_ctx *ctx);
 /* The same for callers that keep sequences 4-BIT PACKED: the bsw_task pointers then address uint64 words, 16 bases
  * each (base k in bits [4k, 4k+3]; codes 0-3 = ACGT, 4-7 = N), every sequence starting on an 8-byte boundary; the
- * lengths stay in bases.  This is the device's own layout and the encoding the reference ships over its link (8 bases
+ * lengths stay in bases; the unused nibbles behind a sequence's last base may hold anything.  This is the device's own layout and the encoding the reference ships over its link (8 bases
  * per 32-bit word, first base in the top nibble there: sw_pe_array_proc_element.v:1638,1677-1683).  Words in registered
  * memory are DMA'd straight into the sequence buffer — no pack kernel, ~0.6x the PCIe bytes per seed of bsw_submit.
  * bsw_pack_bases() packs one byte-per-base sequence; bsw_pack_tasks() a whole task array. */

@@ -81,3 +81,25 @@ def test_packed_over_several_devices_and_empty_batches(host, oracle):
         assert len(c.download(b)) == 0
         b.free()
     ha.free()
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_padding_nibbles_of_the_last_word_are_ignored(host, oracle, kernel):
+    """A caller's packed buffer need not be zero behind a sequence's last base: whatever sits in the unused nibbles of its
+    last word (the next read's bases in a tightly packed stream, say) changes nothing — not the DP, not the bins' N key."""
+    tasks, arena = host.synth_tasks(40000, seed=77, **MIXED)
+    p = host.default_params()
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    pt, words = host.pack_tasks(tasks)
+    rng = np.random.default_rng(5)
+    base = words.ctypes.data
+    w = words.view(np.uint64)
+    for qf, lf in (("lquery", "lqlen"), ("ltarget", "ltlen"), ("rquery", "rqlen"), ("rtarget", "rtlen")):
+        ln = pt[lf].astype(np.int64)
+        sel = np.nonzero((ln > 0) & (ln % 16 != 0))[0]
+        idx = ((pt[qf][sel].astype(np.int64) - base) >> 3) + (ln[sel] - 1) // 16          # the sequence's last word
+        keep = (np.uint64(1) << (np.uint64(4) * (ln[sel] % 16).astype(np.uint64))) - np.uint64(1)
+        junk = rng.integers(0, 2 ** 63, len(sel), dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+        w[idx] = (w[idx] & keep) | (junk & ~keep)
+    with host.BswContext(device=0, kernel=kernel, chunk_tasks=16384) as c:
+        assert_same(c.extend_pairs_packed(p, pt), want, tasks)
