@@ -152,6 +152,19 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def issue_ceiling(pmc, cells, kavg_ms):
+    """What two waves per SIMD can issue at all: a stream of independent VALU instructions runs at 2 + 2.1 / W cycles per
+    instruction and SIMD with W waves resident (tools/ubench/fetch_align.hip, profiles/r3/ubench_fetch_align.txt: 4.18 /
+    3.05 / 2.69 / 2.52 cycles at W = 1 / 2 / 3 / 4) — the guide's 2 cycles need many waves, the row registers allow two.
+    The kernel's own figure from the counters of the same kernel sources (None without them)."""
+    if not pmc.get("valu_lane_insts_per_cell") or not pmc.get("clock_ghz"):
+        return None
+    per_simd = cells * pmc["valu_lane_insts_per_cell"] / 64.0 / (kavg_ms * 1e-3) / 1024.0        # VALU instructions / s / SIMD
+    cyc = pmc["clock_ghz"] * 1e9 / per_simd
+    return {"waves_per_simd": 2, "ceiling_cycles_per_valu_inst": 3.05, "kernel_cycles_per_valu_inst": round(cyc, 3),
+            "frac_of_ceiling": round(3.05 / cyc, 3), "source": "tools/ubench/fetch_align.hip"}
+
+
 def pmc_summary(workload, tasks):
     """(counters, source) of the committed rocprofv3 PMC passes of this same command (profiles/pmc_latest.json).  The counters
     come from an EARLIER run of this command under rocprofv3 --pmc, not from the run that prints them: they are quoted only
@@ -495,6 +508,7 @@ def main():
                 "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"), "valu_issue_busy": pmc.get("valu_issue_busy"),
                 "traffic": traffic, "traffic_kernels": pmc.get("traffic_kernels"),
                 "counters_source": pmc_src,
+                "issue_ceiling": issue_ceiling(pmc, cells, kavg_ms),
                 "kernel_ms_avg": round(kavg_ms, 4),
                 "note": "integer max/add DP at ~0.02 B/cell: VALU issue binds, not HBM and not MFMA; see roofline_hbm",
             },

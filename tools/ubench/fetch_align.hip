@@ -59,6 +59,8 @@ int main()
 {
     run<0, true, 1>("64-bit"); run<1, true, 1>("64-bit"); run<2, true, 1>("64-bit"); run<3, true, 1>("64-bit");
     run<0, true, 2>("64-bit"); run<1, true, 2>("64-bit");
+    run<0, true, 3>("64-bit"); run<0, true, 4>("64-bit"); run<1, true, 4>("64-bit"); run<0, true, 8>("64-bit");
+    run<0, false, 2>("32-bit"); run<0, false, 4>("32-bit");
     run<0, false, 1>("32-bit"); run<1, false, 1>("32-bit");
     return 0;
 }
