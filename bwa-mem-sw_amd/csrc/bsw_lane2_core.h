@@ -101,6 +101,8 @@ L2_FN void fold8(uint32_t &mk2, uint32_t &Fnz, uint32_t &Lnz, uint32_t mkb, uint
 }
 /* a wave-uniform value the compiler must re-read here: keeps tests on it from being hoisted out of the row loop */
 L2_FN uint32_t opaque_s(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
+/* the same for a value the compiler may have computed on the vector side although it is wave-uniform */
+L2_FN uint32_t opaque_u(uint32_t x) { x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x); asm volatile("" : "+s"(x)); return x; }
 #else
 L2_FN uint16_t lo16(uint32_t a) { return (uint16_t)a; }
 L2_FN uint16_t hi16(uint32_t a) { return (uint16_t)(a >> 16); }
@@ -129,6 +131,7 @@ L2_FN uint32_t ffbl(uint32_t x) { return x ? (uint32_t)__builtin_ctz(x) : 0xffff
 L2_FN uint32_t ffbh(uint32_t x) { return x ? (uint32_t)__builtin_clz(x) : 0xffffffffu; }
 L2_FN int mul24(int a, int b) { return a * b; }
 L2_FN uint32_t opaque_s(uint32_t x) { return x; }
+L2_FN uint32_t opaque_u(uint32_t x) { return x; }
 L2_FN uint32_t pk_adds_vs(uint32_t a, uint32_t sb) { const uint32_t lo = lo16(a) + lo16(sb), hi = hi16(a) + hi16(sb); return mk2(lo > 0xffffu ? 0xffffu : lo, hi > 0xffffu ? 0xffffu : hi); }
 L2_FN uint32_t pk_sub_vs(uint32_t a, uint32_t sb) { return pk_sub(a, sb); }
 L2_FN uint32_t pk_neg(uint32_t a) { return pk_sub(0u, a); }
@@ -435,10 +438,31 @@ struct lane2 {
 
         const int blo = u.jlo >> 3, bhi = u.jhi >> 3, bem = u.jem >> 3;      /* block granularity of the dispatch */
         const uint32_t nblk = opaque_s(u.nblk);
+        /* Which body each block takes, as one bit mask per body, set up ONCE per row: per block the dispatch is then a bit
+         * test and a branch per candidate body.  (Written as comparisons of b with blo / bhi / bem inside the block loop, the
+         * compiler rebuilt ~25 scalar instructions and five branches around every block — a sixth of a wave's time in
+         * the blocks, during which the SIMD's other wave issues at the lone-wave rate.) */
+#ifndef BSW_L2_RAGGED_TOP
+#define BSW_L2_RAGGED_TOP 4
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BSW_L2_RAGGED_UNROLLED)
+        constexpr uint32_t RAG_F = 0u, RAG_L = ((1u << QB) - 1u) & ~((1u << (QB - BSW_L2_RAGGED_TOP)) - 1u);   /* only the last block, only at the top of the class */
+#else
+        constexpr uint32_t RAG_F = (1u << QB) - 1u, RAG_L = (1u << QB) - 1u;
+#endif
+        const uint32_t ALLB = (1u << QB) - 1u;
+        const uint32_t m_run = ALLB & ~((1u << imin(blo, 31)) - 1u) & ((2u << imin(bhi, 30)) - 1u);        /* blo <= b <= bhi */
+        const uint32_t m_lt_em = (1u << imin(imax(bem, 0), 31)) - 1u;                                       /* b < bem: dense */
+        const uint32_t m_seqf = ((u.jlo & 7) != 0 ? (1u << imin(blo, 31)) : 0u) & RAG_F & m_lt_em & ~nblk & m_run;
+        const uint32_t m_seql = ((u.jhi & 7) != 7 ? (1u << imin(bhi, 31)) : 0u) & RAG_L & ~m_lt_em & ~nblk & m_run;
+        const uint32_t m_dense = opaque_u(m_run & m_lt_em & ~nblk & ~m_seqf);
+        const uint32_t m_edge = opaque_u(m_run & ~m_lt_em & ~nblk & ~m_seql);
+        const uint32_t m_dnq = opaque_u(m_run & m_lt_em & nblk);
+        const uint32_t m_enq = opaque_u(m_run & ~m_lt_em & nblk);
+        const uint32_t m_sf = opaque_u(m_seqf), m_sl = opaque_u(m_seql), m_any = opaque_u(m_run);
         sfor<QB>([&](auto bi) {
             constexpr int b = decltype(bi)::value, j0 = b * 8, g = j0 >> 6, c = j0 >> 4, wd = j0 >> 5;
-            if (b < blo) return;                              /* j0 + 8 <= jlo */
-            if (b > bhi) return;                              /* j0 > jhi */
+            if (!((m_any >> b) & 1u)) return;                 /* j0 + 8 <= jlo or j0 > jhi */
             /* both seeds' match bits of this 16-column chunk: low half seed A, high half seed B */
             const uint32_t Wc = byte_pair<b & 3>(rmA[wd], rmB[wd]);   /* this block's 8 match bits of seed A / B in bits 0..7 of the low / high half */
             uint32_t mkb = 0, nz8 = 0;                        /* this block's row-max key and non-zero bits */
@@ -446,8 +470,6 @@ struct lane2 {
              * before the loop and spill) */
             /* four mutually exclusive bodies as four consecutive `if`s, not an if/else tree: a body that is simply run or
              * skipped updates eh[j] in place, an if/else joins differently allocated versions with a v_mov per column */
-            const bool dense = b < bem;                       /* j0 + 8 <= jem: inside every active seed's range */
-            const bool nq = (nblk & (1u << b)) != 0;
             const uint32_t dummy = 0;
             /* the block's eight columns go through a local array (values, not memory: the bodies take them by reference) */
             const auto run8 = [&](auto edge, auto nqv, const uint32_t WNc, const uint32_t ENDx, const uint32_t mi_in) {
@@ -464,24 +486,14 @@ struct lane2 {
              * body for the top BSW_L2_RAGGED_TOP blocks of the class alone — where the queries of the class end — lifts it
              * to 2 478 (sweep 1 / 2 / 3 / 4 / 6 / 17 blocks: 2 384 / 2 461 / 2 478 / 2 478 / 2 377 / 2 313,
              * profiles/r3/ragged_top_sweep.txt) */
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(BSW_L2_RAGGED_UNROLLED)
-#ifndef BSW_L2_RAGGED_TOP
-#define BSW_L2_RAGGED_TOP 4
-#endif
-            constexpr bool ragged_f = false, ragged_l = b >= QB - BSW_L2_RAGGED_TOP;      /* only the last block, only at the top of the class */
-#else
-            constexpr bool ragged_f = true, ragged_l = true;
-#endif
-            const bool seqf = ragged_f && dense && !nq && b == blo && (u.jlo & 7) != 0;          /* ragged first block */
-            const bool seql = ragged_l && !dense && !nq && b == bhi && (u.jhi & 7) != 7;         /* ragged last block */
-            if (dense && !nq && !seqf) run8(no_t{}, no_t{}, 0u, END2, dummy);
-            if (seqf) {
+            if ((m_dense >> b) & 1u) run8(no_t{}, no_t{}, 0u, END2, dummy);
+            if (RAG_F != 0u && ((m_sf >> b) & 1u)) {
                 uint32_t T[8];
                 sfor<8>([&](auto ci) { T[decltype(ci)::value] = S.Pr[j0 + decltype(ci)::value]; });
                 block8_seq<false>(T, Wc, Bv2, k, END2, dummy, u.jlo & 7, h1, f, mkb, nz8);
                 sfor<8>([&](auto ci) { S.Pr[j0 + decltype(ci)::value] = T[decltype(ci)::value]; });
             }
-            if (seql) {
+            if (((RAG_L >> b) & 1u) != 0u && ((m_sl >> b) & 1u)) {
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));
                 uint32_t T[8];
@@ -489,16 +501,16 @@ struct lane2 {
                 block8_seq<true>(T, Wc, Bv2, k, ENDr, pk_nzmask(d0), u.jhi & 7, h1, f, mkb, nz8);
                 sfor<8>([&](auto ci) { S.Pr[j0 + decltype(ci)::value] = T[decltype(ci)::value]; });
             }
-            if (__builtin_expect(dense && nq, 0)) {          /* (unlikely: the bins keep the queries with an N apart; cold code out of line) */
+            if (__builtin_expect((m_dnq >> b) & 1u, 0)) {          /* (unlikely: the bins keep the queries with an N apart; cold code out of line) */
                 const uint32_t WNr = wn(c);
                 run8(no_t{}, yes_t{}, (b & 1) ? (WNr >> 8) : WNr, END2, dummy);     /* the block's N bits in bits 0..7 of each half */
             }
-            if (!dense && !nq && !seql) {
+            if ((m_edge >> b) & 1u) {
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));     /* mi of column j0 - 1 */
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
                 run8(yes_t{}, no_t{}, 0u, ENDr, pk_nzmask(d0));
             }
-            if (__builtin_expect(!dense && nq, 0)) {
+            if (__builtin_expect((m_enq >> b) & 1u, 0)) {
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));
                 const uint32_t WNr = wn(c);
