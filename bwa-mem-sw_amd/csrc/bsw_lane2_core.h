@@ -459,7 +459,7 @@ struct lane2 {
         const uint32_t m_edge = opaque_u(m_run & ~m_lt_em & ~nblk & ~m_seql);
         const uint32_t m_dnq = opaque_u(m_run & m_lt_em & nblk);
         const uint32_t m_enq = opaque_u(m_run & ~m_lt_em & nblk);
-        const uint32_t m_sf = opaque_u(m_seqf), m_sl = opaque_u(m_seql), m_any = opaque_u(m_run);
+        const uint32_t m_sf = opaque_u(m_seqf), m_sl = opaque_u(m_seql), m_any = opaque_u(m_run), m_cold = opaque_u(m_run & nblk);
         sfor<QB>([&](auto bi) {
             constexpr int b = decltype(bi)::value, j0 = b * 8, g = j0 >> 6, c = j0 >> 4, wd = j0 >> 5;
             if (!((m_any >> b) & 1u)) return;                 /* j0 + 8 <= jlo or j0 > jhi */
@@ -501,20 +501,23 @@ struct lane2 {
                 block8_seq<true>(T, Wc, Bv2, k, ENDr, pk_nzmask(d0), u.jhi & 7, h1, f, mkb, nz8);
                 sfor<8>([&](auto ci) { S.Pr[j0 + decltype(ci)::value] = T[decltype(ci)::value]; });
             }
-            if (__builtin_expect((m_dnq >> b) & 1u, 0)) {          /* (unlikely: the bins keep the queries with an N apart; cold code out of line) */
+            /* (query-N bodies: unlikely, the bins keep the queries with an N apart — one test for both, cold code out of line) */
+            if (__builtin_expect((m_cold >> b) & 1u, 0)) {
+            if ((m_dnq >> b) & 1u) {
                 const uint32_t WNr = wn(c);
                 run8(no_t{}, yes_t{}, (b & 1) ? (WNr >> 8) : WNr, END2, dummy);     /* the block's N bits in bits 0..7 of each half */
+            }
+            if ((m_enq >> b) & 1u) {
+                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
+                const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));
+                const uint32_t WNr = wn(c);
+                run8(yes_t{}, yes_t{}, (b & 1) ? (WNr >> 8) : WNr, ENDr, pk_nzmask(d0));
+            }
             }
             if ((m_edge >> b) & 1u) {
                 const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));     /* mi of column j0 - 1 */
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
                 run8(yes_t{}, no_t{}, 0u, ENDr, pk_nzmask(d0));
-            }
-            if (__builtin_expect((m_enq >> b) & 1u, 0)) {
-                const uint32_t d0 = pk_subs_vs(END2 + 0x00010001u, dup16(j0));
-                const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));
-                const uint32_t WNr = wn(c);
-                run8(yes_t{}, yes_t{}, (b & 1) ? (WNr >> 8) : WNr, ENDr, pk_nzmask(d0));
             }
             /* fold the block into its 64-column group / 16-column chunk (column offsets only touch the low key bits) */
             mkg[g] = pk_max(mkg[g], mkb + (uint32_t)(j0 & 63) * 0x00010001u);
