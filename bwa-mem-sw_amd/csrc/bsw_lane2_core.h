@@ -443,10 +443,13 @@ struct lane2 {
          * compiler rebuilt ~25 scalar instructions and five branches around every block — a sixth of a wave's time in
          * the blocks, during which the SIMD's other wave issues at the lone-wave rate.) */
 #ifndef BSW_L2_RAGGED_TOP
-#define BSW_L2_RAGGED_TOP 4
+#define BSW_L2_RAGGED_TOP 10        /* with the bit-mask dispatch: 4 / 8 / 10 / 12 / 17 -> headline 2681 / 2663 / 2675 / 2650 / 2619, 72-column bin 2127 / 2350 / 2345 / 2318 / 2317, mixed bins 2305 / 2330 / 2340 / 2319 / 2352 */
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BSW_L2_RAGGED_UNROLLED)
-        constexpr uint32_t RAG_F = 0u, RAG_L = ((1u << QB) - 1u) & ~((1u << (QB - BSW_L2_RAGGED_TOP)) - 1u);   /* only the last block, only at the top of the class */
+#ifndef BSW_L2_RAGGED_FIRST
+#define BSW_L2_RAGGED_FIRST 0
+#endif
+        constexpr uint32_t RAG_F = (1u << BSW_L2_RAGGED_FIRST) - 1u, RAG_L = ((1u << QB) - 1u) & ~((1u << (QB - BSW_L2_RAGGED_TOP)) - 1u);   /* only the last block, only at the top of the class */
 #else
         constexpr uint32_t RAG_F = (1u << QB) - 1u, RAG_L = (1u << QB) - 1u;
 #endif
