@@ -49,6 +49,19 @@ __device__ __forceinline__ int wave_max2(int x)
     x = max(x, dpp2<0x143, 0xc>(INT_MIN, x));
     return __builtin_amdgcn_readlane(x, 63);
 }
+/* three wave-wide signed maxima at once, the three DPP chains interleaved by hand: every step reads a register written
+ * three instructions earlier, so none of the two wait states a DPP read of a fresh VALU result needs is an s_nop (the
+ * compiler's version ran the chains one after the other through one register, 6 dependent steps + 5 s_nop 1 each) */
+__device__ __forceinline__ void wave_max3(int &a, int &b, int &c)
+{
+#define BSW_DPP3(ctl) "v_max_i32_dpp %[a], %[a], %[a] " ctl "\n\tv_max_i32_dpp %[b], %[b], %[b] " ctl "\n\tv_max_i32_dpp %[c], %[c], %[c] " ctl "\n\t"
+    asm volatile(BSW_DPP3("row_shr:1 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 BSW_DPP3("row_shr:4 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 BSW_DPP3("row_bcast:15 row_mask:0xa bank_mask:0xf") BSW_DPP3("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
+                 : [a] "+v"(a), [b] "+v"(b), [c] "+v"(c));
+#undef BSW_DPP3
+    a = __builtin_amdgcn_readlane(a, 63); b = __builtin_amdgcn_readlane(b, 63); c = __builtin_amdgcn_readlane(c, 63);
+}
 
 /* every 4th bit of a 64-bit word (bit `b` of each nibble) gathered into 16 contiguous bits */
 __device__ __forceinline__ uint32_t nib_plane(uint64_t w, int b)
@@ -211,9 +224,12 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
          * reach past jem (the smallest `end`) run the masked body */
         l2::uni u;
         const int b0 = S.s[0].beg, b1 = S.s[1].beg, e0 = S.s[0].end, e1 = S.s[1].end;
-        u.jlo = -wave_max2(max(r.act[0] ? -b0 : INT_MIN, r.act[1] ? -b1 : INT_MIN));
-        u.jhi = wave_max2(max(r.act[0] ? e0 : INT_MIN, r.act[1] ? e1 : INT_MIN));
-        u.jem = -wave_max2(max(r.act[0] ? -e0 : INT_MIN, r.act[1] ? -e1 : INT_MIN));
+        {
+            int ra = max(r.act[0] ? -b0 : INT_MIN, r.act[1] ? -b1 : INT_MIN), rb = max(r.act[0] ? e0 : INT_MIN, r.act[1] ? e1 : INT_MIN),
+                rc = max(r.act[0] ? -e0 : INT_MIN, r.act[1] ? -e1 : INT_MIN);
+            wave_max3(ra, rb, rc);
+            u.jlo = -ra; u.jhi = rb; u.jem = -rc;
+        }
         u.anybite = __builtin_amdgcn_ballot_w64(r.bite[0] || r.bite[1]) != 0;
         u.zl = 0; u.zh = 0;
         if (__builtin_expect(u.anybite, 0)) {
