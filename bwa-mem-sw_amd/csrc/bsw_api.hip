@@ -33,9 +33,9 @@ struct bsw_ref {
 };
 
 /* BSW_KERNEL_AUTO: a lane launch costs one wave's full duration (~1.3 ms for 150 bp seeds) however few seeds it
- * holds, the wave-per-task kernel scales with the seed count; measured crossover 24.5k seeds (tools/crossover.py,
+ * holds, the wave-per-task kernel scales with the seed count; measured crossover 17.4k seeds (a lone wave runs the headline bin's side in 1.00 ms since the bit-mask block dispatch, 1.37 ms before; tools/crossover.py,
  * profiles/r3/crossover_wave_vs_lane.json) */
-#define LANE_AUTO_MIN 24000
+#define LANE_AUTO_MIN 17500
 #define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
 #define RAW_FRONT 32                 /* ... and in front of the first one (reversed left queries) */
 
