@@ -105,38 +105,129 @@ PRESETS = {
 }
 
 
+def rank_cpu_sets(n):
+    """One CPU set per rank: the CPUs this process may use, split among the ranks along NUMA nodes where the machine has
+    several (>= 6x at 8 GPUs needs NUMA-local host threads; the reference's single manager sits next to its
+    4 PE arrays, batch_manager.v:343-348).  With a PCI bus id per GPU (amdgpu sysfs, no GPU call) rank r gets the CPUs of
+    ITS card's node; without, the nodes are dealt round-robin.  Returns a list of sorted CPU lists (None = leave alone)."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return [None] * n
+    nodes = []
+    try:
+        for d in sorted(os.listdir("/sys/devices/system/node")):
+            if d.startswith("node") and d[4:].isdigit():
+                cpus = parse_cpulist(open("/sys/devices/system/node/%s/cpulist" % d).read())
+                cpus = [c for c in cpus if c in set(avail)]
+                if cpus:
+                    nodes.append((int(d[4:]), cpus))
+    except OSError:
+        pass
+    if not nodes:
+        nodes = [(0, avail)]
+    gpu_node = gpu_numa_nodes()
+    by_node = {}
+    for r in range(n):
+        node = gpu_node[r] if r < len(gpu_node) and gpu_node[r] in dict(nodes) else nodes[r % len(nodes)][0]
+        by_node.setdefault(node, []).append(r)
+    sets = [None] * n
+    for node, ranks in by_node.items():
+        cpus = dict(nodes)[node]
+        per = max(1, len(cpus) // len(ranks))
+        for k, r in enumerate(ranks):
+            mine = cpus[k * per:(k + 1) * per] if k * per < len(cpus) else cpus
+            sets[r] = mine or cpus
+    return sets
+
+
+def parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes():
+    """NUMA node of every amdgpu render node in enumeration order, from sysfs (no HIP call: the launcher must not touch the
+    GPU).  [] when the kernel does not say (-1) or the layout is unknown."""
+    out = []
+    try:
+        cards = sorted((d for d in os.listdir("/sys/class/drm") if d.startswith("renderD")), key=lambda d: int(d[7:]))
+        for c in cards:
+            dev = os.path.realpath("/sys/class/drm/%s/device" % c)
+            drv = os.path.basename(os.path.realpath(dev + "/driver")) if os.path.exists(dev + "/driver") else ""
+            if drv != "amdgpu":
+                continue
+            out.append(int(open(dev + "/numa_node").read().strip()))
+    except (OSError, ValueError):
+        return []
+    return out
+
+
 def self_launch(n):
     """One fresh child process per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set as torchrun would), rank 0's stdout relayed.
     The parent never initialises the GPU and never execs: the reference's one manager feeding several PE arrays
-    (batch_manager.v:343-348) becomes one launcher feeding N per-GPU ranks.  Exit code: non-zero if any rank failed."""
+    (batch_manager.v:343-348) becomes one launcher feeding N per-GPU ranks, each pinned to the CPUs of its share
+    (BSW_RANK_CPUS, applied by the child before it imports torch).  All children are polled against one deadline; the
+    first rank that fails takes the others down.  Exit code: non-zero if any rank failed."""
     import socket
     import subprocess
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    sets = rank_cpu_sets(n)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if sets[r] and "BSW_RANK_CPUS" not in os.environ:
+            env["BSW_RANK_CPUS"] = ",".join(str(c) for c in sets[r])
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    rcs = []
-    deadline = time.time() + 600
-    for p in procs:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    sys.stdout.write(out0)
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("BSW_LAUNCH_TIMEOUT", "900"))
+    rcs = [None] * n
+    while any(c is None for c in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        failed = any(c not in (None, 0) for c in rcs)
+        if failed or time.time() > deadline:
+            for r, p in enumerate(procs):       # a rank that died before the rendezvous leaves the others in a collective
+                if rcs[r] is None:
+                    p.kill()
+                    p.wait()
+                    rcs[r] = -9
+            break
+        time.sleep(0.05)
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
     if bad:
         print("bench.py: ranks failed (rank, exit code): %s" % bad, file=sys.stderr)
         return 1
     return 0
+
+
+def apply_rank_affinity():
+    """BSW_RANK_CPUS (set by self_launch, or by whoever starts the ranks) -> this process's CPU affinity, before torch and
+    the library start their threads.  Returns the CPU list in effect."""
+    spec = os.environ.get("BSW_RANK_CPUS")
+    try:
+        if spec:
+            os.sched_setaffinity(0, set(parse_cpulist(spec)))
+        return sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError, ValueError):
+        return None
 
 
 def kernel_source_hash():
@@ -227,6 +318,7 @@ def main():
         # `python bench.py --gpus N` without torchrun: start N fresh per-GPU ranks BEFORE anything here touches the GPU
         sys.exit(self_launch(args.gpus))
 
+    cpu_affinity = apply_rank_affinity()             # before torch / the library start threads
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

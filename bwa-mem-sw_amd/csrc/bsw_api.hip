@@ -48,7 +48,12 @@ struct batch_plan {
     uint32_t redo_off = 0;
     uint32_t order_len = 0;          /* entries before the redo counter */
     int redo_cls = 0;
+    /* dep[lc] bit rc: some seed has its left side in lane class lc and its right side in lane class rc — the right-side
+     * launch of class rc then has to wait for the left-side launch of class lc (h0 of the right extension is the score
+     * after the left one, sw_pe_array_proc_element.v:1671).  All ones = not known. */
+    uint8_t dep[BSW_MAX_LANE_CLASSES] = {0xff, 0xff, 0xff, 0xff};
 };
+static_assert(BSW_MAX_LANE_CLASSES == 4, "batch_plan::dep initialiser");
 
 /* error text travels with the thread that produced it; the context keeps the last one */
 struct errs {
@@ -146,9 +151,22 @@ struct stage_t {
     }
 };
 
+/* The lane classes of one side are independent launches: they run side by side on auxiliary streams so that one class's
+ * tail (its last waves running alone) fills with the other's waves — a 72-column wave (168 registers, 47 KB of LDS per
+ * four waves) and a 136-column wave (256, 70 KB) fit one SIMD / one CU together.  One set per slot stream, created right
+ * behind it (the runtime deals streams onto its hardware queues in creation order; streams that share a queue run
+ * their kernels one after the other, profiles/r3/e2e_hw_queues.txt). */
+#define BSW_FORK_AUX (BSW_MAX_LANE_CLASSES - 1)
+struct fork_t {
+    hipStream_t aux[BSW_FORK_AUX] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_left[BSW_MAX_LANE_CLASSES] = {nullptr}, ev_right[BSW_MAX_LANE_CLASSES] = {nullptr};
+    bool ok = false;
+};
+
 struct dev_state {
     int device = 0;
     std::vector<hipStream_t> streams;
+    std::vector<fork_t> forks;        /* one per stream */
     std::vector<hipEvent_t> events;   /* one per stream, for the watchdog */
     std::vector<hipEvent_t> h2d_done; /* one per stream: the chunk's input DMAs have finished */
     std::vector<stage_t> slots;
@@ -351,7 +369,14 @@ static void ctx_release(bsw_ctx *ctx)
     for (auto &d : ctx->devs) {
         (void)hipSetDevice(d.device);
         if (!dead) {
-            for (auto s : d.streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+            for (auto s : d.streams) (void)hipStreamSynchronize(s);
+            for (auto &f : d.forks) {
+                for (auto a : f.aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
+                if (f.ev_fork) (void)hipEventDestroy(f.ev_fork);
+                for (auto ev : f.ev_left) if (ev) (void)hipEventDestroy(ev);
+                for (auto ev : f.ev_right) if (ev) (void)hipEventDestroy(ev);
+            }
+            for (auto s : d.streams) (void)hipStreamDestroy(s);
             for (auto ev : d.events) (void)hipEventDestroy(ev);
             for (auto ev : d.h2d_done) (void)hipEventDestroy(ev);
             for (auto &sl : d.slots) sl.release();
@@ -412,6 +437,27 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
             hipEvent_t ev = nullptr;
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
             d.streams.push_back(st);
+            {
+                /* off unless BSW_FORK=1: with the narrow class folded wherever wider sides exist, the only workload with two
+                 * classes per side is 250 bp (136 + 232 columns) — 1 971 GCUPS forked, 1 974 not (gpurun_out/r4h, r4b) */
+                static const bool nofork = getenv("BSW_FORK") == nullptr;
+                fork_t f;
+                bool good = !nofork;
+                /* the auxiliary streams run at the LOWEST priority: the widest class of a side (the slot stream's) has the
+                 * longest waves and must get its slots first — released at the same instant, the narrow class's many short
+                 * workgroups took half the slots and the long waves started late (right side 2.8 ms instead of 2.0,
+                 * gpurun_out/r4c trace) */
+                int least = 0, greatest = 0;
+                static const bool noprio = getenv("BSW_FORK_NOPRIO") != nullptr;
+                if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || noprio) least = 0;
+                for (int a = 0; a < BSW_FORK_AUX && good; ++a) good = hipStreamCreateWithPriority(&f.aux[a], hipStreamNonBlocking, least) == hipSuccess;
+                good = good && hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming) == hipSuccess;
+                for (int c = 0; c < BSW_MAX_LANE_CLASSES && good; ++c)
+                    good = hipEventCreateWithFlags(&f.ev_left[c], hipEventDisableTiming) == hipSuccess &&
+                           hipEventCreateWithFlags(&f.ev_right[c], hipEventDisableTiming) == hipSuccess;
+                f.ok = good;
+                d.forks.push_back(f);              /* (not ok: the classes of a side run one after the other on the slot stream) */
+            }
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
             d.events.push_back(ev);
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
@@ -597,6 +643,40 @@ static int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams 
     return BSW_OK;
 }
 
+/* The narrow lane class (72 columns, three waves per SIMD) is its own launch per side.  It pays where a chunk holds NO
+ * wider 8-bit sides — reads with long exact seeds, whose flanks are all short: the 72 / 64 / 40 / 16-column single bins run
+ * 12 / 13 / 16 / 24 % faster there (gpurun_out/r4b, r4d).  Beside wider sides it LOSES, whatever their share: one launch
+ * per class means the short waves no longer fill the tail of the long ones (longest-first order inside ONE launch is what
+ * packs a side onto the wave slots; every launch has a floor of one wave's whole lifetime), and a 72-column wave next to a
+ * 136-column one gets no third wave (256 + 168 registers).  Synthetic PE mixed bins (42 % of the lane work in short
+ * sides): 2 350 -> 2 080 GCUPS with the launches one after the other, 2 190 on forked streams with priorities; still
+ * -15 % with 97 % of the work in short sides (gpurun_out/r4c, r4h, r4i).  So the host decides per chunk: the class is
+ * used when its sides hold at least NARROW_MIN_SHARE of the chunk's 8-bit lane work (work of a side ~ its query length:
+ * rows ~ 2 qlen, live band ~ constant), otherwise it is folded into the next class (lane_cols = 0: the device's
+ * bsw_side_lane_class skips it).  BSW_NARROW_SHARE overrides the threshold (0: always, 2: never). */
+#define NARROW_MIN_SHARE 1.0
+static bool narrow_foldable(const bsw_binparams &bp)
+{
+    return bp.n_lane >= 2 && bp.lane_bits[0] == bp.lane_bits[1] && bp.lane_cols[0] > 0 && bp.lane_cols[0] < bp.lane_cols[1];
+}
+static double narrow_min_share()
+{
+    static const double v = getenv("BSW_NARROW_SHARE") ? atof(getenv("BSW_NARROW_SHARE")) : NARROW_MIN_SHARE;
+    return v;
+}
+/* fold class 0 into class 1: counts, dependency bits, and the class table the device sorts with */
+static void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_t *dep)
+{
+    cl[1] += cl[0]; cr[1] += cr[0]; cl[0] = cr[0] = 0;
+    if (dep) {
+        for (int lc = 0; lc < BSW_MAX_LANE_CLASSES; ++lc)
+            if (dep[lc] & 1u) dep[lc] = (uint8_t)((dep[lc] & ~1u) | 2u);
+        dep[1] |= dep[0];
+        dep[0] = 0;
+    }
+    bp.lane_cols[0] = 0;
+}
+
 /* tasks[0..n) -> dt[0..n) (device task records), ro[0..n) (gather layout of the raw bytes), class counts -> plan */
 /* One pass over the seeds of a chunk: validate, lay the 4-bit arena out, count the kernel classes.  `src(i, tmp, rc)`
  * hands out seed i as a bsw_task (a pointer into the caller's array, or `tmp` filled on the fly — bsw_submit_ref never
@@ -615,6 +695,8 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
     uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0};
     uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0;
+    uint8_t dep[BSW_MAX_LANE_CLASSES] = {0};
+    uint64_t lane_work[BSW_MAX_LANE_CLASSES] = {0};          /* sum of query lengths per lane class (narrow_fold) */
     auto span = [&](const uint8_t *s, int len) {
         if (len > 0) { if (s < lo) lo = s; if (s + len > hi) hi = s + len; }
     };
@@ -723,21 +805,30 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         if (!bits) ++cw[wc];
         else {
             ++n_lane;
+            int lc = -1;
             if (t.lqlen) {
-                const int c = bsw_side_lane_class(&bp, bits, t.lqlen);
+                const int c = lc = bsw_side_lane_class(&bp, bits, t.lqlen);
                 if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i);
                 ++cl[c];
+                lane_work[c] += (uint64_t)t.lqlen;
             }
             if (t.rqlen) {
                 const int c = bsw_side_lane_class(&bp, bits, t.rqlen);
                 if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i);
                 ++cr[c];
+                lane_work[c] += (uint64_t)t.rqlen;
+                if (lc >= 0) dep[lc] |= (uint8_t)(1u << c);
             }
         }
     }
     if (acc >= (1ull << 32)) return fail(e, BSW_E_LIMIT, "batch sequence arena beyond 2^32 words; split the batch");
     if (accb >= (1ull << 32) - RAW_SLACK) return fail(e, BSW_E_LIMIT, "batch holds more than 4 GiB of bases; split the batch");
     if (kern == BSW_KERNEL_AUTO && n_lane < LANE_AUTO_MIN) bp.lane_on = 0;
+    if (bp.lane_on && narrow_foldable(bp)) {
+        uint64_t all8 = 0;
+        for (int c = 0; c < bp.n_lane; ++c) if (bp.lane_bits[c] == bp.lane_bits[0]) all8 += lane_work[c];
+        if ((double)lane_work[0] < narrow_min_share() * (double)all8) narrow_fold(bp, cl, cr, dep);
+    }
     if (!bp.lane_on) {
         memcpy(cw, cw_all, sizeof(cw));
         memset(cl, 0, sizeof(cl));
@@ -758,6 +849,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     pl.redo_off = cur;
     pl.order_len = cur + n_lane;
     pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
+    memcpy(pl.dep, dep, sizeof(pl.dep));
     memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
     bp.lane_all_off = pl.lane_all_off;
     memcpy(bp.laneL_off, pl.laneL_off, sizeof(bp.laneL_off));
@@ -856,8 +948,17 @@ static void gather_raw(const bsw_task *tasks, const bsw_rawoff *ro, size_t n, bo
 }
 
 /* ---- device side of a chunk: DMA, pack, (fetch), bin, and optionally the DP kernels ---------- */
+static const fork_t *fork_for(const bsw_ctx *ctx, hipStream_t s)
+{
+    for (const dev_state &d : ctx->devs)
+        for (size_t k = 0; k < d.streams.size(); ++k)
+            if (d.streams[k] == s) return k < d.forks.size() && d.forks[k].ok ? &d.forks[k] : nullptr;
+    return nullptr;
+}
+
 static int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
-                         uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches)
+                         uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches,
+                         const fork_t *fk = nullptr)
 {
     const int nc = bsw::wave_class_count();
     for (int c = 0; c < nc; ++c) {
@@ -870,13 +971,41 @@ static int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint6
         uint32_t *redo_cnt = d_order + pl.order_len;
         HIPCHK(e, hipMemsetAsync(redo_cnt, 0, sizeof(uint32_t), s));
         const int nlc = bsw::lane_class_count();
-        for (int side = 0; side < 2; ++side) {
-            const uint32_t *offs = side ? pl.laneR_off : pl.laneL_off;
+        /* The classes of a side side by side: the k-th non-empty class of a side (widest first: its waves run longest) goes
+         * to stream k — the slot stream, then the auxiliary ones.  A right-side launch waits for exactly the left-side
+         * launches that hold one of its seeds (plan.dep); streams are in-order, so only other streams' launches need an event. */
+        hipStream_t lstream[BSW_MAX_LANE_CLASSES] = {nullptr}, rstream[BSW_MAX_LANE_CLASSES] = {nullptr};
+        int nl = 0, nr = 0;
+        for (int c = nlc - 1; c >= 0; --c) {
+            if (pl.laneL_off[c + 1] - pl.laneL_off[c]) { lstream[c] = (fk && nl > 0 && nl <= BSW_FORK_AUX) ? fk->aux[nl - 1] : s; ++nl; }
+            if (pl.laneR_off[c + 1] - pl.laneR_off[c]) { rstream[c] = (fk && nr > 0 && nr <= BSW_FORK_AUX) ? fk->aux[nr - 1] : s; ++nr; }
+        }
+        const bool forked = fk && (nl > 1 || nr > 1);
+        if (forked) {
+            HIPCHK(e, hipEventRecord(fk->ev_fork, s));                 /* everything queued on s so far (input DMAs, pack, bins) */
+            for (int a = 0; a < BSW_FORK_AUX; ++a) HIPCHK(e, hipStreamWaitEvent(fk->aux[a], fk->ev_fork, 0));
+        }
+        for (int c = nlc - 1; c >= 0; --c) {
+            const uint32_t cnt = pl.laneL_off[c + 1] - pl.laneL_off[c];
+            if (!cnt) continue;
+            HIPCHK(e, bsw::launch_lane(c, variant, P, 0, d_seq, d_tasks, d_order + pl.laneL_off[c], cnt, d_out, lstream[c]));
+            if (forked) HIPCHK(e, hipEventRecord(fk->ev_left[c], lstream[c]));
+            if (launches) ++*launches;
+        }
+        for (int c = nlc - 1; c >= 0; --c) {
+            const uint32_t cnt = pl.laneR_off[c + 1] - pl.laneR_off[c];
+            if (!cnt) continue;
+            if (forked)
+                for (int lc = 0; lc < nlc; ++lc)
+                    if (lstream[lc] && lstream[lc] != rstream[c] && ((pl.dep[lc] >> c) & 1)) HIPCHK(e, hipStreamWaitEvent(rstream[c], fk->ev_left[lc], 0));
+            HIPCHK(e, bsw::launch_lane(c, variant, P, 1, d_seq, d_tasks, d_order + pl.laneR_off[c], cnt, d_out, rstream[c]));
+            if (forked && rstream[c] != s) HIPCHK(e, hipEventRecord(fk->ev_right[c], rstream[c]));
+            if (launches) ++*launches;
+        }
+        if (forked) {                                                   /* join: the slot stream waits for whatever ran elsewhere */
             for (int c = 0; c < nlc; ++c) {
-                const uint32_t cnt = offs[c + 1] - offs[c];
-                if (!cnt) continue;
-                HIPCHK(e, bsw::launch_lane(c, variant, P, side, d_seq, d_tasks, d_order + offs[c], cnt, d_out, s));
-                if (launches) ++*launches;
+                if (lstream[c] && lstream[c] != s) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_left[c], 0));
+                if (rstream[c] && rstream[c] != s) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_right[c], 0));
             }
         }
         HIPCHK(e, bsw::launch_finalize(P, d_tasks, d_order + pl.lane_all_off, pl.lane_all_cnt, d_out,
@@ -1224,7 +1353,7 @@ extern "C" int bsw_run(bsw_ctx *ctx, bsw_dev_batch *b)
     }
     HIPCHK(e, hipEventRecord(e0, s));
     b->launches = 0;
-    rc = enqueue_batch(e, b->P, b->variant, b->st.d_seq.p, b->st.d_tasks.p, b->st.d_order.p, b->plan, b->st.d_out.p, s, &b->launches);
+    rc = enqueue_batch(e, b->P, b->variant, b->st.d_seq.p, b->st.d_tasks.p, b->st.d_order.p, b->plan, b->st.d_out.p, s, &b->launches, fork_for(ctx, s));
     if (rc) return rc;
     HIPCHK(e, hipEventRecord(e1, s));
     ctx->ev_last0 = e0; ctx->ev_last1 = e1;
@@ -1321,7 +1450,7 @@ static int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent
     const double t_c = dbg ? tnow() : 0;
     rc = stage_device(e, st, s, ci, n, false, nullptr, nullptr, turn);
     if (rc) return rc;
-    rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, s, nullptr);
+    rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, s, nullptr, fork_for(ctx, s));
     if (rc) return rc;
     const bool out_direct = is_registered(out, n * sizeof(bsw_result));
     if (!out_direct && (he = st.h_out.reserve(n)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
@@ -1459,7 +1588,7 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         turn.gate = &gate; turn.seq = k; turn.ev = dev.h2d_done[s]; turn.abort_flag = &abort_flag;
         queued = true;
         rc = stage_device(e, st, stream, ci, n, rtasks != nullptr, ref, nullptr, &turn, d);
-        if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr);
+        if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr, fork_for(ctx, stream));
         if (rc) return bail(rc);
         bsw_result *co = out + chunks[k].base;
         pend.direct = is_registered(co, n * sizeof(bsw_result));
@@ -1699,45 +1828,74 @@ static bool same_alignment_scoring(const bsw_params &a, const bsw_params &b)
     return memcmp(a.mat, b.mat, 25) == 0 && a.o_del == b.o_del && a.e_del == b.e_del && a.o_ins == b.o_ins && a.e_ins == b.e_ins;
 }
 
-/* the ksw_align2 / ksw_global2 calls of one trip, grouped by scoring: one bsw_align_batch / bsw_global_batch per group
- * (they used to be one serialised device round trip per call) */
-static void scalar_side_calls(std::vector<scalar_req *> &batch)
+/* A batch API rejects the WHOLE batch on its first bad task (a query beyond the class limits, an unknown xtra bit ...).
+ * Calls of different threads share a batch here, so one thread's over-limit call must not fail the others: when a group of
+ * several calls comes back with a per-task error (BSW_E_LIMIT / BSW_E_INVAL) its members are rerun one by one and only the
+ * offender keeps the error. */
+static bool per_task_error(int rc) { return rc == BSW_E_LIMIT || rc == BSW_E_INVAL; }
+
+static int scalar_align_group(std::vector<scalar_req *> &batch, const std::vector<size_t> &grp, bool quiet)
 {
-    std::vector<char> taken(batch.size(), 0);
-    for (size_t i = 0; i < batch.size(); ++i) {
-        if (taken[i] || batch[i]->kind == 0) continue;
-        const int kind = batch[i]->kind;
-        std::vector<size_t> grp;
-        for (size_t j = i; j < batch.size(); ++j)
-            if (!taken[j] && batch[j]->kind == kind && same_alignment_scoring(batch[i]->p, batch[j]->p)) { grp.push_back(j); taken[j] = 1; }
-        int rc = BSW_OK;
-        if (kind == 1) {
-            std::vector<bsw_atask> t(grp.size());
-            std::vector<bsw_kswr> o(grp.size());
-            for (size_t k = 0; k < grp.size(); ++k) t[k] = batch[grp[k]]->at;
-            rc = bsw_align_batch(g_ctx, &batch[i]->p, t.data(), t.size(), o.data());
-            if (rc) fprintf(stderr, "ksw_align2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
-            for (size_t k = 0; k < grp.size(); ++k) { batch[grp[k]]->rc = rc; if (!rc) batch[grp[k]]->ar = o[k]; }
-        } else {
-            int cap = 0;
-            for (size_t k : grp) cap = std::max(cap, batch[k]->cap);
-            std::vector<bsw_gtask> t(grp.size());
-            std::vector<bsw_gresult> o(grp.size());
-            std::vector<uint32_t> cg(cap ? grp.size() * (size_t)cap : 1);
-            for (size_t k = 0; k < grp.size(); ++k) t[k] = batch[grp[k]]->gt;
-            rc = bsw_global_batch(g_ctx, &batch[i]->p, t.data(), t.size(), cap, o.data(), cap ? cg.data() : nullptr);
-            if (rc) fprintf(stderr, "ksw_global2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
-            for (size_t k = 0; k < grp.size(); ++k) {
-                scalar_req *r = batch[grp[k]];
-                r->rc = rc;
-                if (rc) continue;
-                r->gr = o[k];
-                if (r->cap && o[k].n_cigar > 0) r->cg.assign(cg.begin() + (ptrdiff_t)(k * (size_t)cap), cg.begin() + (ptrdiff_t)(k * (size_t)cap) + o[k].n_cigar);
-            }
+    std::vector<bsw_atask> t(grp.size());
+    std::vector<bsw_kswr> o(grp.size());
+    for (size_t k = 0; k < grp.size(); ++k) t[k] = batch[grp[k]]->at;
+    const int rc = bsw_align_batch(g_ctx, &batch[grp[0]]->p, t.data(), t.size(), o.data());
+    if (rc && !quiet) fprintf(stderr, "ksw_align2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
+    for (size_t k = 0; k < grp.size(); ++k) { batch[grp[k]]->rc = rc; if (!rc) batch[grp[k]]->ar = o[k]; }
+    return rc;
+}
+
+static int scalar_global_group(std::vector<scalar_req *> &batch, const std::vector<size_t> &grp, bool quiet)
+{
+    int cap = 0;
+    for (size_t k : grp) cap = std::max(cap, batch[k]->cap);
+    std::vector<bsw_gtask> t(grp.size());
+    std::vector<bsw_gresult> o(grp.size());
+    std::vector<uint32_t> cg(cap ? grp.size() * (size_t)cap : 1);
+    for (size_t k = 0; k < grp.size(); ++k) t[k] = batch[grp[k]]->gt;
+    const int rc = bsw_global_batch(g_ctx, &batch[grp[0]]->p, t.data(), t.size(), cap, o.data(), cap ? cg.data() : nullptr);
+    if (rc && !quiet) fprintf(stderr, "ksw_global2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
+    for (size_t k = 0; k < grp.size(); ++k) {
+        scalar_req *r = batch[grp[k]];
+        r->rc = rc;
+        if (rc) continue;
+        r->gr = o[k];
+        if (r->cap && o[k].n_cigar > 0) r->cg.assign(cg.begin() + (ptrdiff_t)(k * (size_t)cap), cg.begin() + (ptrdiff_t)(k * (size_t)cap) + o[k].n_cigar);
+    }
+    return rc;
+}
+
+static int scalar_extend_group(std::vector<scalar_req *> &batch, const std::vector<size_t> &grp, bool quiet)
+{
+    std::vector<bsw_ext_task> t(grp.size());
+    std::vector<bsw_ext> x(grp.size());
+    for (size_t k = 0; k < grp.size(); ++k) t[k] = batch[grp[k]]->t;
+    int rc = BSW_OK;
+    if (hipSetDevice(g_ctx->device0()) != hipSuccess) rc = BSW_E_HIP;
+    if (!rc) rc = ext_batch_on(g_ctx, g_ctx->err, g_ctx->small, g_ctx->stream0(), g_ctx->devs[0].events[0], &batch[grp[0]]->p, t.data(), t.size(), x.data());
+    if (rc && !quiet) fprintf(stderr, "ksw_extend2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
+    for (size_t k = 0; k < grp.size(); ++k) { batch[grp[k]]->rc = rc; if (!rc) batch[grp[k]]->x = x[k]; }
+    return rc;
+}
+
+/* one group of calls that share their scoring: one device batch; per-task errors are isolated to their callers */
+static void scalar_run_group(std::vector<scalar_req *> &batch, const std::vector<size_t> &grp, int kind)
+{
+    const auto run = [&](const std::vector<size_t> &g, bool quiet) {
+        return kind == 1 ? scalar_align_group(batch, g, quiet) : kind == 2 ? scalar_global_group(batch, g, quiet) : scalar_extend_group(batch, g, quiet);
+    };
+    const int rc = run(grp, grp.size() > 1);
+    if (rc && grp.size() > 1) {
+        if (!per_task_error(rc)) {                 /* a device failure: everybody's, reported once */
+            fprintf(stderr, "%s(libbwasw_mi355): GPU path failed (%d): %s\n", kind == 1 ? "ksw_align2" : kind == 2 ? "ksw_global2" : "ksw_extend2", rc, bsw_last_error(g_ctx));
+            return;
         }
+        for (size_t k : grp) run(std::vector<size_t>{k}, false);
     }
 }
 
+/* the calls of one trip, grouped by kind and scoring: one bsw_extend / bsw_align_batch / bsw_global_batch launch sequence per
+ * group (ksw_align2 / ksw_global2 used to be one serialised device round trip per call) */
 static void scalar_round_trip(std::vector<scalar_req *> &batch)
 {
     if (!g_ctx && !g_ctx_rc) {
@@ -1756,22 +1914,17 @@ static void scalar_round_trip(std::vector<scalar_req *> &batch)
     if (batch.empty()) return;                     /* (called only to create the context) */
     ++g_scalar_trips;
     g_scalar_calls += batch.size();
-    scalar_side_calls(batch);
     std::vector<char> taken(batch.size(), 0);
-    for (size_t i = 0; i < batch.size(); ++i) {
-        if (taken[i] || batch[i]->kind != 0) continue;
-        std::vector<size_t> grp;
-        for (size_t j = i; j < batch.size(); ++j)
-            if (!taken[j] && batch[j]->kind == 0 && same_scoring(batch[i]->p, batch[j]->p)) { grp.push_back(j); taken[j] = 1; }
-        std::vector<bsw_ext_task> t(grp.size());
-        std::vector<bsw_ext> x(grp.size());
-        for (size_t k = 0; k < grp.size(); ++k) t[k] = batch[grp[k]]->t;
-        int rc = BSW_OK;
-        if (hipSetDevice(g_ctx->device0()) != hipSuccess) rc = BSW_E_HIP;
-        if (!rc) rc = ext_batch_on(g_ctx, g_ctx->err, g_ctx->small, g_ctx->stream0(), g_ctx->devs[0].events[0], &batch[i]->p, t.data(), t.size(), x.data());
-        if (rc) fprintf(stderr, "ksw_extend2(libbwasw_mi355): GPU path failed (%d): %s\n", rc, bsw_last_error(g_ctx));
-        for (size_t k = 0; k < grp.size(); ++k) { batch[grp[k]]->rc = rc; if (!rc) batch[grp[k]]->x = x[k]; }
-    }
+    for (int pass = 0; pass < 2; ++pass)           /* the alignment kinds first, then the extensions (as before) */
+        for (size_t i = 0; i < batch.size(); ++i) {
+            const int kind = batch[i]->kind;
+            if (taken[i] || (pass == 0) != (kind != 0)) continue;
+            std::vector<size_t> grp;
+            for (size_t j = i; j < batch.size(); ++j)
+                if (!taken[j] && batch[j]->kind == kind &&
+                    (kind == 0 ? same_scoring(batch[i]->p, batch[j]->p) : same_alignment_scoring(batch[i]->p, batch[j]->p))) { grp.push_back(j); taken[j] = 1; }
+            scalar_run_group(batch, grp, kind);
+        }
 }
 
 /* queue the call; whoever finds no trip in flight becomes the leader, takes everything queued and runs it */
@@ -1976,6 +2129,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
         n_lane += pt.n_lane;
     }
     if (ctx->cfg.kernel == BSW_KERNEL_AUTO && n_lane < LANE_AUTO_MIN) bp.lane_on = 0;
+    if (bp.lane_on && narrow_foldable(bp)) narrow_fold(bp, cl, cr, nullptr);     /* (wire-format groups: one launch per side) */
     if (!bp.lane_on) { memcpy(cw, cw_all, sizeof(cw)); memset(cl, 0, sizeof(cl)); memset(cr, 0, sizeof(cr)); n_lane = 0; }
     batch_plan &pl = ci.plan;
     pl = batch_plan();
@@ -1988,6 +2142,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
     pl.laneR_off[BSW_MAX_LANE_CLASSES] = cur;
     pl.redo_off = cur; pl.order_len = cur + n_lane;
     pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
+    /* (pl.dep stays all ones: the wire-format groups run their classes on one stream) */
     memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
     bp.lane_all_off = pl.lane_all_off;
     memcpy(bp.laneL_off, pl.laneL_off, sizeof(bp.laneL_off));

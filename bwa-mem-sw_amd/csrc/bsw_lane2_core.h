@@ -432,6 +432,9 @@ struct lane2 {
         const int hi1 = S.s[1].beg == 0 ? imax(S.s[1].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
         uint32_t h1 = pack2(hi0, hi1) << 8, f = 0;          /* scaled, like every score inside the row */
         L2_STAMP(2);
+#if defined(BSW_L2_PRIO) && defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_s_setprio(0);                      /* (experiment) the block phase yields to a wave in its serial row head / tail */
+#endif
         uint32_t mkg[NG], nzc[NC];
         sfor<NG>([&](auto gi) { mkg[decltype(gi)::value] = 0; });
         sfor<NC>([&](auto ci) { nzc[decltype(ci)::value] = 0; });
@@ -449,7 +452,7 @@ struct lane2 {
 #ifndef BSW_L2_RAGGED_FIRST
 #define BSW_L2_RAGGED_FIRST 0
 #endif
-        constexpr uint32_t RAG_F = (1u << BSW_L2_RAGGED_FIRST) - 1u, RAG_L = ((1u << QB) - 1u) & ~((1u << (QB - BSW_L2_RAGGED_TOP)) - 1u);   /* only the last block, only at the top of the class */
+        constexpr uint32_t RAG_F = (1u << BSW_L2_RAGGED_FIRST) - 1u, RAG_L = ((1u << QB) - 1u) & ~((1u << (QB > BSW_L2_RAGGED_TOP ? QB - BSW_L2_RAGGED_TOP : 0)) - 1u);   /* only the last block, only at the top of the class */
 #else
         constexpr uint32_t RAG_F = (1u << QB) - 1u, RAG_L = (1u << QB) - 1u;
 #endif
@@ -528,6 +531,9 @@ struct lane2 {
         });
 
         L2_STAMP(3);
+#if defined(BSW_L2_PRIO) && defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_s_setprio(BSW_L2_PRIO);
+#endif
         /* row max over the groups, both seeds at once: the low byte of a group's key is the column inside the group
          * (< 64), so adding 64 g makes it absolute without touching the score byte */
         uint32_t mk2 = mkg[0];

@@ -55,7 +55,9 @@ __device__ __forceinline__ int wave_max2(int x)
 __device__ __forceinline__ void wave_max3(int &a, int &b, int &c)
 {
 #define BSW_DPP3(ctl) "v_max_i32_dpp %[a], %[a], %[a] " ctl "\n\tv_max_i32_dpp %[b], %[b], %[b] " ctl "\n\tv_max_i32_dpp %[c], %[c], %[c] " ctl "\n\t"
-    asm volatile(BSW_DPP3("row_shr:1 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:2 row_mask:0xf bank_mask:0xf")
+    /* (s_nop 1 first: a DPP read of a VGPR needs two wait states behind the VALU write of it, and the hazard recogniser does
+     * not look inside an asm statement — a, b, c are computed just before it) */
+    asm volatile("s_nop 1\n\t" BSW_DPP3("row_shr:1 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:2 row_mask:0xf bank_mask:0xf")
                  BSW_DPP3("row_shr:4 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:8 row_mask:0xf bank_mask:0xf")
                  BSW_DPP3("row_bcast:15 row_mask:0xa bank_mask:0xf") BSW_DPP3("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
                  : [a] "+v"(a), [b] "+v"(b), [c] "+v"(c));
@@ -91,13 +93,16 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     __shared__ uint64_t lds_t[4][2][BSW_L2_TCHUNK][64];             /* [wave][seed][word][lane] */
     /* per-base match words of both queries: NQ4 quads of four words + NR single words per (wave, seed, base, lane) */
     constexpr int NQ4 = NW / 4, NR = NW % 4;
-    __shared__ uint4 lds_m4[4][2][4][NQ4][64];
+    __shared__ uint4 lds_m4[4][2][4][NQ4 ? NQ4 : 1][64];
     __shared__ uint32_t lds_m1[4][2][4][NR ? NR : 1][64];
     __shared__ uint32_t lds_wn[4][NC][64];                          /* N planes of both seeds, 16 columns per half */
-    __shared__ uint4 lds_k4[NQ4][L::KEEP_NONE + 1];                 /* keep-mask table (match_words), same split */
+    __shared__ uint4 lds_k4[NQ4 ? NQ4 : 1][L::KEEP_NONE + 1];                 /* keep-mask table (match_words), same split */
     __shared__ uint32_t lds_k1[NR ? NR : 1][L::KEEP_NONE + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t w0 = (blockIdx.x * 4u + (uint32_t)wv) * 128u + (uint32_t)lane;
+#ifdef BSW_L2_STAMP
+    const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();      /* 100 MHz, the same on every CU: the wave's life span */
+#endif
     for (int b = (int)threadIdx.x; b <= L::KEEP_NONE; b += 256) {
 #pragma unroll
         for (int q4 = 0; q4 < NQ4; ++q4)
@@ -191,9 +196,17 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
 
 #ifdef BSW_L2_STAMP
     if (lane == 0) { for (int q = 0; q < 8; ++q) l2_acc[wv][q] = 0; l2_last[wv] = __builtin_amdgcn_s_memtime(); }
+    const unsigned long long wl_t1 = __builtin_amdgcn_s_memrealtime();      /* the row loop starts */
+#endif
+#ifdef BSW_L2_SKEW
+    /* experiment: the two waves of a SIMD start a launch's first round in the same row phase and stay there */
+    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (0 << 11)) & 1u) __builtin_amdgcn_s_sleep(BSW_L2_SKEW);
 #endif
     for (int i = 0;; ++i) {
         l2::rowv r;
+#ifdef BSW_L2_PRIO
+        __builtin_amdgcn_s_setprio(BSW_L2_PRIO);
+#endif
         L::row_begin(S, i, r);
         if (__builtin_amdgcn_ballot_w64(r.act[0] || r.act[1]) == 0) break;
         L2_STAMP(0);
@@ -251,7 +264,11 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         e.gscore = s.gscore; e.max_off = s.max_off; e.aw = P.w; e.cells = s.cells;
 #ifdef BSW_L2_STAMP
         e.score = (int)(l2_acc[wv][0] >> 4); e.qle = (int)(l2_acc[wv][1] >> 4); e.tle = (int)(l2_acc[wv][2] >> 4);
-        e.gtle = (int)(l2_acc[wv][3] >> 4); e.gscore = (int)(l2_acc[wv][4] >> 4);
+        e.gtle = (int)(l2_acc[wv][3] >> 4); e.gscore = (int)(wl_t1 - wl_t0);      /* (gscore: the prologue, 10 ns ticks) */
+        /* wave log (tools/wave_timeline.py): start / end in 10 ns ticks and where the wave ran (HW_ID: wave, SIMD, CU, SE, XCC) */
+        e.max_off = (int)(wl_t0 & 0x7fffffffu); e.aw = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffffu);
+        e.cells = ((unsigned)__builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | (15 << 11)) & 0xffffu) |
+                  ((unsigned)__builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | (3 << 11)) << 16);
 #endif
         if (side == 0) out[ti[x]].left = e; else out[ti[x]].right = e;
     });
@@ -268,16 +285,24 @@ bool lane2_params_ok(const bsw_dparams &P, int variant)
     return a > 0 && pb >= 0 && pn >= 0 && pb >= pn && a + pb < 256 && P.o_del + P.e_del < 256 && P.o_ins + P.e_ins < 256;
 }
 
-hipError_t launch_lane2(const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
+hipError_t launch_lane2(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
                         uint32_t n, bsw_result *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins, vm = variant == BSW_VARIANT_M;
     const dim3 grid((n + 511u) / 512u), block(256);
-    if (!vm && sym) hipLaunchKernelGGL((bsw_lane2_kernel<17, 2, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
-    else if (!vm) hipLaunchKernelGGL((bsw_lane2_kernel<17, 2, false, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
-    else if (sym) hipLaunchKernelGGL((bsw_lane2_kernel<17, 2, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
-    else hipLaunchKernelGGL((bsw_lane2_kernel<17, 2, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);
+#define BSW_L2_GO(QB, WPS)                                                                                                    \
+    do {                                                                                                                      \
+        if (!vm && sym) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);   \
+        else if (!vm) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, false, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);    \
+        else if (sym) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);      \
+        else hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);              \
+    } while (0)
+    /* 72 columns: 72 row registers + the working set = 168 VGPRs, three waves per SIMD (the spills the compiler takes at
+     * that bound sit in the prologue and in the cold target-staging / query-N code, none in the row loop: tests/test_isa_audit.py) */
+    if (qb == 9) BSW_L2_GO(9, 3);
+    else BSW_L2_GO(17, 2);
+#undef BSW_L2_GO
     return hipGetLastError();
 }
 

@@ -56,7 +56,9 @@ __device__ __forceinline__ int wave_max2l(int x)
 __device__ __forceinline__ void wave_max3(int &a, int &b, int &c)
 {
 #define BSW_DPP3(ctl) "v_max_i32_dpp %[a], %[a], %[a] " ctl "\n\tv_max_i32_dpp %[b], %[b], %[b] " ctl "\n\tv_max_i32_dpp %[c], %[c], %[c] " ctl "\n\t"
-    asm volatile(BSW_DPP3("row_shr:1 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:2 row_mask:0xf bank_mask:0xf")
+    /* (s_nop 1 first: a DPP read of a VGPR needs two wait states behind the VALU write of it, and the hazard recogniser does
+     * not look inside an asm statement — a, b, c are computed just before it) */
+    asm volatile("s_nop 1\n\t" BSW_DPP3("row_shr:1 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:2 row_mask:0xf bank_mask:0xf")
                  BSW_DPP3("row_shr:4 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:8 row_mask:0xf bank_mask:0xf")
                  BSW_DPP3("row_bcast:15 row_mask:0xa bank_mask:0xf") BSW_DPP3("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
                  : [a] "+v"(a), [b] "+v"(b), [c] "+v"(c));
@@ -89,7 +91,8 @@ struct acc_row {
                      "v_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\t"
                      "s_set_gpr_idx_off\n\ts_nop 0"
                      : "=v"(T[0]), "=v"(T[1]), "=v"(T[2]), "=v"(T[3]), "=v"(T[4]), "=v"(T[5]), "=v"(T[6]), "=v"(T[7])
-                     : "s"(8 * b));
+                     : "s"(8 * b)
+                     : "m0");                      /* s_set_gpr_idx_on overwrites M0 */
     }
     __device__ __forceinline__ void store8(int b, const uint32_t (&T)[8])
     {
@@ -98,7 +101,8 @@ struct acc_row {
                      "v_accvgpr_write_b32 a4, %4\n\tv_accvgpr_write_b32 a5, %5\n\tv_accvgpr_write_b32 a6, %6\n\tv_accvgpr_write_b32 a7, %7\n\t"
                      "s_set_gpr_idx_off\n\ts_nop 0"
                      :
-                     : "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]), "v"(T[5]), "v"(T[6]), "v"(T[7]), "s"(8 * b));
+                     : "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]), "v"(T[5]), "v"(T[6]), "v"(T[7]), "s"(8 * b)
+                     : "m0");
     }
     /* Block b's columns out, block b+1's columns and match bytes in, under one index-mode window: the index serves the
      * writes as destination offset, then (mode switched) the reads, which name a8..a15, as source offset; the match words
@@ -127,7 +131,7 @@ struct acc_row {
                      : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7]),
                        [wa] "=&v"(wa), [wb] "=&v"(wb), [Wc] "=v"(Wc), [st] "=&s"(st), [sel] "=&s"(sel)
                      : [i8] "s"(8 * b), [b1] "s"(b + 1), [RMA] "i"(RM), [RMB] "i"(RM + NW)
-                     : "scc");
+                     : "scc", "m0");
     }
     __device__ __forceinline__ void load8w(int b, uint32_t (&T)[8], uint32_t &Wc) const
     {
@@ -149,7 +153,7 @@ struct acc_row {
                      : "=&v"(T[0]), "=&v"(T[1]), "=&v"(T[2]), "=&v"(T[3]), "=&v"(T[4]), "=&v"(T[5]), "=&v"(T[6]), "=&v"(T[7]),
                        [wa] "=&v"(wa), [wb] "=&v"(wb), [Wc] "=v"(Wc), [st] "=&s"(st), [sel] "=&s"(sel)
                      : [i8] "s"(8 * b), [b0] "s"(b), [RMA] "i"(RM), [RMB] "i"(RM + NW)
-                     : "scc");
+                     : "scc", "m0");
     }
     template <int WD>
     __device__ __forceinline__ void put_rm_s(uint32_t a, uint32_t b)
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
 
 /* the 232-column class (250 bp reads) at one wave per SIMD; BSW_LANE2L_NARROW=1 also routes the 136-column class here
  * (experiments: the unrolled kernel is faster there) */
-hipError_t launch_lane2l(int cls, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
+hipError_t launch_lane2l(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
                          const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
@@ -376,7 +380,7 @@ hipError_t launch_lane2l(int cls, const bsw_dparams &P, int variant, int side, c
         else if (sym) hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);      \
         else hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);              \
     } while (0)
-    if (cls == 0) BSW_L2L_GO(17, 1);
+    if (qb == 17) BSW_L2L_GO(17, 1);
     else BSW_L2L_GO(29, 1);
 #undef BSW_L2L_GO
     return hipGetLastError();

@@ -410,39 +410,56 @@ hipError_t launch_lane_c2(BSW_LANE_ARGS) { return launch_lane_qb<17, false, 2>(v
 #endif
 
 #if BSW_LANE_TU < 0
-struct lane_class_t { int bits, qb; };
-/* A narrower class (72 columns) was measured and dropped: the unrolled blocks beyond a wave's live range are skipped
- * by scalar branches anyway, and one launch per side has one tail instead of two (+8 % on the mixed-bin workload). */
-static const lane_class_t kLaneClasses[] = {{8, 17}, {8, 29}, {16, 17}};   /* = launch_lane_c0..c2 */
+/* lane classes, narrowest first (a side takes the first class of its value width that holds it).  `kind` names the kernel
+ * that serves the class when the scoring parameters allow the two-seeds-per-lane formulation (lane2_params_ok); `fb` is the
+ * one-seed-per-lane kernel (launch_lane_c0..c2) that serves it otherwise. */
+enum { K_LANE2_9, K_LANE2_17, K_LANE2L_29, K_LANE16 };
+struct lane_class_t { int bits, qb, kind, fb; };
+/* The 72-column class (round 4): a 72-register row + the working set fit 168 VGPRs = THREE waves per SIMD (the 136-column
+ * kernel holds two), issue ceiling 2.69 instead of 3.05 cycles per VALU instruction and SIMD (profiles/r3/ubench_fetch_align.txt)
+ * and one more wave to hide the serial row head / tail.  Each reference PE serves any qlen <= 255 at one cell per clock
+ * (sw_pe_array_sw_extend.v:101-102,144-148); here the short sides — half of the sides of a PE mixed-bin batch — get the
+ * occupancy their narrow rows allow.  (Round 1 measured a 72-column class of the ONE-seed-per-lane kernel and dropped it:
+ * that kernel gained no occupancy from it.)  BSW_NO_NARROW=1 removes the class (measurements). */
+static const lane_class_t kLaneClassesAll[] = {{8, 9, K_LANE2_9, 0}, {8, 17, K_LANE2_17, 0}, {8, 29, K_LANE2L_29, 1}, {16, 17, K_LANE16, 2}};
+static const lane_class_t *lane_classes(int *n)
+{
+    static const bool no_narrow = getenv("BSW_NO_NARROW") != nullptr;
+    *n = no_narrow ? 3 : 4;
+    return kLaneClassesAll + (no_narrow ? 1 : 0);
+}
 
-int lane_class_count() { return (int)(sizeof(kLaneClasses) / sizeof(kLaneClasses[0])); }
-int lane_class_cols(int cls) { return kLaneClasses[cls].qb * 8; }
-int lane_class_bits(int cls) { return kLaneClasses[cls].bits; }
+int lane_class_count() { int n; lane_classes(&n); return n; }
+int lane_class_cols(int cls) { int n; return lane_classes(&n)[cls].qb * 8; }
+int lane_class_bits(int cls) { int n; return lane_classes(&n)[cls].bits; }
 
-/* bsw_lane2_kernel.hip: two seeds per lane, packed 16-bit math — takes the 8-bit 136-column class whenever the
- * scoring parameters allow its formulation */
+/* bsw_lane2_kernel.hip: two seeds per lane, packed 16-bit math, unrolled blocks — the 72-column class at three waves per
+ * SIMD, the 136-column class at two; bsw_lane2l_kernel.hip: the same arithmetic with the blocks walked by a loop and the
+ * row in AccVGPRs (232 columns, one wave per SIMD) */
 bool lane2_params_ok(const bsw_dparams &P, int variant);
-hipError_t launch_lane2(const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
+hipError_t launch_lane2(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
                         uint32_t n, bsw_result *out, hipStream_t s);
-hipError_t launch_lane2l(int cls, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
+hipError_t launch_lane2l(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
                          const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
 
 hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
                        const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    {
-        /* the 232-column 8-bit class: two seeds per lane with the blocks walked by a loop and the row in AccVGPRs
-         * (bsw_lane2l_kernel.hip; the unrolled kernel instantiated for 232 columns is instruction-cache bound at one wave
-         * per SIMD: profiles/r3/lane2_wide_*).  BSW_NO_LANE2L=1 selects round 1's one-seed-per-lane kernel instead,
-         * BSW_LANE2L_NARROW=1 sends the 136-column class through the looped kernel too (measurements). */
+    int ncls;
+    const lane_class_t &C = lane_classes(&ncls)[cls];
+    if (C.kind != K_LANE16 && lane2_params_ok(P, variant)) {
+        /* BSW_NO_LANE2L=1 selects round 1's one-seed-per-lane kernel for the 232-column class, BSW_LANE2L_NARROW=1 sends the
+         * 136-column class through the looped kernel too (measurements; the unrolled kernel instantiated for 232 columns is
+         * instruction-cache bound at one wave per SIMD: profiles/r3/lane2_wide_*) */
         static const bool nol = getenv("BSW_NO_LANE2L") != nullptr, narrow = getenv("BSW_LANE2L_NARROW") != nullptr;
-        if (!nol && (cls == 1 || (cls == 0 && narrow)) && lane2_params_ok(P, variant))
-            return launch_lane2l(cls, P, variant, side, seq, tasks, order, n, out, s);
+        if (C.kind == K_LANE2L_29) {
+            if (!nol) return launch_lane2l(29, P, variant, side, seq, tasks, order, n, out, s);
+        } else if (C.kind == K_LANE2_17 && narrow) return launch_lane2l(17, P, variant, side, seq, tasks, order, n, out, s);
+        else return launch_lane2(C.qb, P, variant, side, seq, tasks, order, n, out, s);
     }
-    if (cls == 0 && lane2_params_ok(P, variant)) return launch_lane2(P, variant, side, seq, tasks, order, n, out, s);
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins;
-    switch (cls) {
+    switch (C.fb) {
     case 0: return launch_lane_c0(variant, sym, P, side, seq, tasks, order, n, out, s);
     case 1: return launch_lane_c1(variant, sym, P, side, seq, tasks, order, n, out, s);
     default: return launch_lane_c2(variant, sym, P, side, seq, tasks, order, n, out, s);

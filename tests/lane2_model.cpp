@@ -150,22 +150,31 @@ struct wave_model {
     }
 };
 
-// One band try of one side of tasks[order[0..n)] exactly as bsw_lane2_kernel<17> would run it: 128 seeds per wave.
+// One band try of one side of tasks[order[0..n)] exactly as bsw_lane2_kernel<QB> would run it: 128 seeds per wave; qb = 17 (the
+// 136-column class) or 9 (the 72-column class that runs at three waves per SIMD).
 // h0s: optional per-task h0 override (the score after the left extension); out is indexed by task.
-extern "C" int lane2_model_run(const bsw_params *p, const bsw_task *tasks, int side, const uint32_t *order, size_t n,
-                               const int32_t *h0s, bsw_ext *out)
+extern "C" int lane2_model_run_qb(const bsw_params *p, const bsw_task *tasks, int side, const uint32_t *order, size_t n,
+                                  const int32_t *h0s, bsw_ext *out, int qb)
 {
     if (!p || !tasks || !order || !out) return -1;
     if (p->mat[1] > 0 || p->mat[24] > 0 || -p->mat[1] < -p->mat[24]) return -2;      /* lane2_params_ok */
     if (p->o_del + p->e_del > 255 || p->o_ins + p->e_ins > 255 || p->mat[0] - p->mat[1] > 255) return -2;
     const bool sym = p->o_del == p->o_ins && p->e_del == p->e_ins, vm = p->variant == BSW_VARIANT_M;
     for (size_t w0 = 0; w0 < n; w0 += 128) {
-        if (!vm && sym) wave_model<17, false, true, false>::run(p, tasks, side, order, n, w0, h0s, out);
-        else if (!vm) wave_model<17, false, false, false>::run(p, tasks, side, order, n, w0, h0s, out);
-        else if (sym) wave_model<17, true, true, false>::run(p, tasks, side, order, n, w0, h0s, out);
-        else wave_model<17, true, false, false>::run(p, tasks, side, order, n, w0, h0s, out);
+#define RUNU(QB) do { \
+        if (!vm && sym) wave_model<QB, false, true, false>::run(p, tasks, side, order, n, w0, h0s, out); \
+        else if (!vm) wave_model<QB, false, false, false>::run(p, tasks, side, order, n, w0, h0s, out); \
+        else if (sym) wave_model<QB, true, true, false>::run(p, tasks, side, order, n, w0, h0s, out); \
+        else wave_model<QB, true, false, false>::run(p, tasks, side, order, n, w0, h0s, out); } while (0)
+        if (qb == 17) RUNU(17); else if (qb == 9) RUNU(9); else return -3;
+#undef RUNU
     }
     return 0;
+}
+extern "C" int lane2_model_run(const bsw_params *p, const bsw_task *tasks, int side, const uint32_t *order, size_t n,
+                               const int32_t *h0s, bsw_ext *out)
+{
+    return lane2_model_run_qb(p, tasks, side, order, n, h0s, out, 17);
 }
 
 // The looped kernel (bsw_lane2l_kernel<QB>: blocks walked by a run-time loop, row behind an accessor), qb = 17 or 29.

@@ -150,7 +150,7 @@ def test_batch_plan_bins(host):
     tasks, arena = host.make_tasks(seeds)
     n = len(tasks)
     p = host.default_params()
-    lane_cols = [(8, 136), (8, 232), (16, 136)]
+    lane_cols = [(8, 72), (8, 136), (8, 232), (16, 136)]      # narrowest first: a side takes the first class of its width that holds it
     for kernel in (host.KERNEL_AUTO, host.KERNEL_LANE, host.KERNEL_WAVE):
         order, seg, words = host.plan_batch(p, tasks, kernel=kernel, pack_threads=3)
         exp_words = int((((tasks["lqlen"] + 15) // 16 + (tasks["ltlen"] + 15) // 16) * (tasks["lqlen"] > 0)
@@ -183,6 +183,9 @@ def test_batch_plan_bins(host):
                 hn = _gen.query_has_n(tasks, arena, side)[order[seg[base + c]:seg[base + c + 1]]]
                 key = (~hn).astype(np.int64) * 1000 - q.astype(np.int64)
                 assert (np.diff(key) >= 0).all() and (q + 1 <= ncol).all()        # queries with an N first, each part longest first
+                folded = c == 1 and seg[base + 1] == seg[base]                    # the 72-column class folded into the 136-column one
+                if c > 0 and lane_cols[c - 1][0] == bits and not folded:
+                    assert (q + 1 > lane_cols[c - 1][1]).all()                    # ... and not in a narrower class of the same width
                 tt = t["h0"].astype(np.int64) + t["lqlen"] + t["rqlen"]
                 # 8-bit classes need h0 + qlen*a + b <= 255 (b = 4: the packed kernel forms H + a + b in 8 bits)
                 assert ((tt + 4 <= 255) if bits == 8 else (tt + 4 > 255) | (np.maximum(t["lqlen"], t["rqlen"]) + 1 > 232)).all()
@@ -216,3 +219,31 @@ def test_bsw_bench_cli_without_a_gpu(host, tmp_path):
     open(f2, "wb").write(b"garbage")
     r = subprocess.run([exe, "--load", f2, "--pageable"], capture_output=True, text=True)
     assert r.returncode == 1 and "cannot load" in r.stderr
+
+
+def test_narrow_lane_class_is_a_per_chunk_decision(host):
+    """The 72-column class (three waves per SIMD) is used when the short sides are most of a chunk's lane work and folded
+    into the 136-column class otherwise (one launch per side packs better than two): bsw_plan_batch shows the decision."""
+    import _gen
+    rng = np.random.default_rng(8)
+    p = host.default_params()
+
+    def plan(qmax_list):
+        seeds = []
+        for qm in qmax_list:
+            seeds += _gen.random_seeds(rng, 1500, qmax=qm, h0max=40)
+        tasks, arena = host.make_tasks(seeds)
+        order, seg, words = host.plan_batch(p, tasks, kernel=host.KERNEL_LANE)
+        return tasks, order, seg
+
+    def eight_bit(tasks):                                                 # (the 16-bit class takes the wide scores)
+        return tasks["h0"].astype(np.int64) + tasks["lqlen"] + tasks["rqlen"] + 4 <= 255
+
+    tasks, order, seg = plan([60])                                        # every side fits 72 columns
+    for base, qf in ((9, "lqlen"), (17, "rqlen")):
+        assert seg[base + 1] - seg[base] == int(((tasks[qf] > 0) & eight_bit(tasks)).sum()) and seg[base + 2] == seg[base + 1]
+    tasks, order, seg = plan([60, 130, 130])                              # mostly long sides: folded, the narrow lists are empty
+    for base, qf in ((9, "lqlen"), (17, "rqlen")):
+        assert seg[base + 1] == seg[base]
+        t = tasks[order[seg[base + 1]:seg[base + 2]]]
+        assert len(t) == int(((tasks[qf] > 0) & eight_bit(tasks)).sum()) and (t[qf] < 72).any() and (t[qf] >= 72).any()

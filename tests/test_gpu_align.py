@@ -155,3 +155,60 @@ def test_drop_in_ksw_align2(host, oracle):
         r = L.ksw_align(len(q), q.ctypes.data, len(t), t.ctypes.data, 5, m.ctypes.data, 5, 2, x, None)
         w = oracle.align2(q, t, m, 5, 2, 5, 2, x)
         assert [getattr(r, f) for f in FIELDS] == [w[f] for f in FIELDS]
+
+
+def test_one_over_limit_call_does_not_fail_the_other_threads(host, oracle):
+    """Concurrent ksw_align2 / ksw_global2 calls share a device batch; a batch API rejects the whole batch on its first bad
+    task.  One thread's over-limit query (2 000 bases > BSW_ALIGN_MAX_QLEN) must come back as ITS failure only."""
+    import threading
+    L = host.lib()
+
+    class KSWR(C.Structure):
+        _fields_ = [(f, C.c_int) for f in FIELDS]
+    L.ksw_align2.restype = KSWR
+    L.ksw_align2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    L.ksw_global2.restype = C.c_int
+    L.ksw_global2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(66)
+    m = host.bwa_matrix()
+    x = XB | XSUBO | XSTART | 19
+    nthr, rounds = 12, 6
+    work = []
+    for k in range(nthr):
+        t = rng.integers(0, 4, 300).astype(np.uint8)
+        q = _gen.mutate(rng, t[20:170], 120, 0.03, 0.01)
+        work.append((q, t))
+    bigq = rng.integers(0, 4, 2000).astype(np.uint8)
+    bigt = rng.integers(0, 4, 2500).astype(np.uint8)
+    got = [[None] * rounds for _ in range(nthr)]
+    gsc = [[None] * rounds for _ in range(nthr)]
+    bad = [None] * rounds
+    gate = threading.Barrier(nthr + 1)
+
+    def worker(k):
+        q, t = work[k]
+        for r in range(rounds):
+            gate.wait()
+            res = L.ksw_align2(len(q), q.ctypes.data, len(t), t.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, x, None)
+            got[k][r] = [getattr(res, f) for f in FIELDS]
+            gsc[k][r] = L.ksw_global2(len(q), q.ctypes.data, len(q), t.ctypes.data + 20, 5, m.ctypes.data, 6, 1, 6, 1, 30, None, None)
+
+    def offender():
+        for r in range(rounds):
+            gate.wait()
+            res = L.ksw_align2(len(bigq), bigq.ctypes.data, len(bigt), bigt.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, x, None)
+            bad[r] = res.score
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(nthr)] + [threading.Thread(target=offender)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert all(b == -1 for b in bad)                                    # the over-limit call fails ...
+    for k in range(nthr):                                               # ... and nobody else does
+        q, t = work[k]
+        w = oracle.align2(q, t, m, 6, 1, 6, 1, x)
+        g = oracle.global2(q, t[20:20 + len(q)], m, 6, 1, 6, 1, 30, want_cigar=False)["score"]
+        for r in range(rounds):
+            assert got[k][r] == [w[f] for f in FIELDS], (k, r)
+            assert gsc[k][r] == g, (k, r)

@@ -209,3 +209,37 @@ def test_ragged_last_wave_and_tiny_batches(host, oracle, lctx):
     want = oracle.pair_batch(p, tasks, nthreads=4)
     for n in (1, 2, 63, 64, 65, 255, 256, 257, 1000):
         assert_same(lctx.extend_pairs(p, tasks[:n]), want[:n], tasks[:n])
+
+
+NARROW_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import __graft_entry__ as g
+host, orc = g.load_package().host, g.load_oracle()
+from test_gpu_parity import assert_same
+for variant, gaps in ((0, {}), (1, dict(o_del=5, e_del=2, o_ins=7, e_ins=1))):
+    p = host.default_params(variant=variant, **gaps)
+    tasks, arena = host.synth_tasks(40000, seed=77 + variant, seed_len_min=19, seed_len_max=60, seed_at_start=0, sub_rate=0.02,
+                                    indel_rate=0.01, junk_frac=0.1, n_rate=0.001)
+    with host.BswContext(device=0, kernel=host.KERNEL_LANE) as c:
+        b = c.upload(p, tasks); c.run(b); c.sync()
+        got, launches = c.download(b), b.info()["launches"]
+        b.free()
+    assert launches == 6, launches              # left + right x (72-column class, 136-column class) + finalize + redo list
+    assert_same(got, orc.pair_batch(p, tasks, nthreads=8), tasks)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("fork", ["0", "1"])
+def test_narrow_class_beside_the_wide_one(fork):
+    """The 72-column class forced on (BSW_NARROW_SHARE=0) in a chunk that also holds wider sides — by default such a chunk
+    folds it away — with the classes of a side one after the other and side by side on forked streams (BSW_FORK=1): a right
+    side waits for exactly the left launches that hold its seeds.  The switches are read once per process: own process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BSW_NARROW_SHARE="0")
+    if fork == "1":
+        env["BSW_FORK"] = "1"
+    out = subprocess.run([sys.executable, "-c", NARROW_SNIPPET % dict(root=root)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
