@@ -40,9 +40,10 @@ WORKLOADS = {
 VALU_OPS_PER_CELL = 15          # integer VALU ops of one DP cell
 # The binding roof is VALU issue (integer max/add DP: ~0.02 B per cell, nothing is a contraction).
 # Peak from MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector = 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
-# (a wave64 op at the full rate holds its SIMD for 2 cycles).  The opcodes a DP cell needs (v_max*, VOP3, SDWA, packed
-# VOP3P) issue at half that rate on gfx950 (measured: profiles/r1/ubench_*, profiles/r2/ubench3.txt), which is what
-# `peak_opcode_weighted` prices.
+# (a wave64 op at the full rate holds its SIMD for 2 cycles).  Measured on gfx950 (profiles/r3/ubench_fetch_align.txt):
+# every VALU opcode the DP cell needs — packed 16-bit ones included — issues at 2 + 2.1 / W cycles per instruction and SIMD
+# with W waves resident, so 2 cycles is the many-wave limit; `roofline.issue_ceiling` prices the kernel against what ITS
+# occupancy (two waves for a 136-register row) can issue.
 PEAK_VALU_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # rocprofv3 --pmc summary of this same command
@@ -243,17 +244,34 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def issue_ceiling(pmc, cells, kavg_ms):
-    """What two waves per SIMD can issue at all: a stream of independent VALU instructions runs at 2 + 2.1 / W cycles per
-    instruction and SIMD with W waves resident (tools/ubench/fetch_align.hip, profiles/r3/ubench_fetch_align.txt: 4.18 /
-    3.05 / 2.69 / 2.52 cycles at W = 1 / 2 / 3 / 4) — the guide's 2 cycles need many waves, the row registers allow two.
+def issue_ceiling(pmc, cells, kavg_ms, waves=2):
+    """What W waves per SIMD can issue at all: a stream of independent VALU instructions — packed 16-bit and 32-bit alike —
+    runs at 2 + 2.1 / W cycles per instruction and SIMD with W waves resident (tools/ubench/fetch_align.hip,
+    profiles/r3/ubench_fetch_align.txt: 4.18 / 3.05 / 2.69 / 2.52 cycles at W = 1 / 2 / 3 / 4) — the guide's 2 cycles (the
+    `peak`) need many waves; a 136-register row allows two, a 72-register row three, a 232-register row one.
     The kernel's own figure from the counters of the same kernel sources (None without them)."""
     if not pmc.get("valu_lane_insts_per_cell") or not pmc.get("clock_ghz"):
         return None
     per_simd = cells * pmc["valu_lane_insts_per_cell"] / 64.0 / (kavg_ms * 1e-3) / 1024.0        # VALU instructions / s / SIMD
     cyc = pmc["clock_ghz"] * 1e9 / per_simd
-    return {"waves_per_simd": 2, "ceiling_cycles_per_valu_inst": 3.05, "kernel_cycles_per_valu_inst": round(cyc, 3),
-            "frac_of_ceiling": round(3.05 / cyc, 3), "source": "tools/ubench/fetch_align.hip"}
+    ceil = 2.0 + 2.1 / waves
+    return {"waves_per_simd": waves, "ceiling_cycles_per_valu_inst": round(ceil, 2), "kernel_cycles_per_valu_inst": round(cyc, 3),
+            "frac_of_ceiling": round(ceil / cyc, 3), "law": "2 + 2.1 / W cycles per VALU instruction and SIMD", "source": "tools/ubench/fetch_align.hip"}
+
+
+def cpu_list_str(cpus):
+    """[0,1,2,3,8,9] -> '0-3,8-9'"""
+    if not cpus:
+        return None
+    out, lo, prev = [], cpus[0], cpus[0]
+    for c in list(cpus[1:]) + [None]:
+        if c is not None and c == prev + 1:
+            prev = c
+            continue
+        out.append(str(lo) if lo == prev else "%d-%d" % (lo, prev))
+        if c is not None:
+            lo = prev = c
+    return ",".join(out)
 
 
 def pmc_summary(workload, tasks):
@@ -286,6 +304,7 @@ def main():
     ap.add_argument("--tasks", type=int, default=1_000_000, help="seeds per GPU per step (weak scaling)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--pool", type=int, default=8_000_000, help="--scaling strong: seeds in the one pool all ranks share (BASELINE configs[3]: 100000000)")
+    ap.add_argument("--gen-threads", type=int, default=0, help="--scaling strong: threads that generate this rank's chunks (0 = the rank's CPU set, at most 32)")
     ap.add_argument("--resident-chunks", type=int, default=32, help="--scaling strong: 128Ki-seed chunks per resident batch")
     ap.add_argument("--workload", default="150bp_w100_single_bin", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0)
@@ -372,27 +391,53 @@ def main():
         mine = [c for c in range(nchunks) if c % world == rank]
         groups = [mine[i:i + args.resident_chunks] for i in range(0, len(mine), args.resident_chunks)]
         gb = args.resident_chunks * host.synth_arena_bound(chunk, **spec) + 4096
-        harena = host.HostArena(gb)
-        batches, n_local, gstats = [], 0, []
-        for grp in groups:
+        # Every chunk has its own generator seed, so the chunks of a group are generated side by side on this rank's CPUs
+        # (bsw_synth_generate is 4.25 us per mixed-bin seed on one core: 100 M seeds would be 7 minutes of it), and group g+1
+        # is generated into a second arena while group g is uploaded (validate + lay out on the host, pack + bin on the GPU).
+        from concurrent.futures import ThreadPoolExecutor
+        gen_threads = max(1, min(args.gen_threads or len(cpu_affinity or [0]), 32))
+        arenas = [host.HostArena(gb) for _ in range(2 if len(groups) > 1 else 1)]
+        harena = arenas[0]
+        pool = ThreadPoolExecutor(max_workers=gen_threads)
+
+        def generate(gi):
+            grp = groups[gi]
+            ar = arenas[gi % len(arenas)]
             sizes = [min(chunk, args.pool - c * chunk) for c in grp]
             tg = np.zeros(int(sum(sizes)), dtype=host.TASK)
-            off = k = 0
-            for c, sz in zip(grp, sizes):                                   # every chunk has its own generator seed
-                t, _ = host.synth_tasks(sz, arena=harena.u8[off:], seed=5000 + c, **spec)
+            offs = np.concatenate([[0], np.cumsum([host.synth_arena_bound(sz, **spec) for sz in sizes])]).astype(np.int64)
+            starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+            def one(k):
+                c, sz = grp[k], sizes[k]
+                t, _ = host.synth_tasks(sz, arena=ar.u8[int(offs[k]):], seed=5000 + c, **spec)      # (ctypes releases the GIL)
                 t["tag"] = np.arange(c * chunk, c * chunk + sz, dtype=np.uint32)
-                tg[k:k + sz] = t
-                k += sz
-                off += host.synth_arena_bound(sz, **spec)
+                tg[int(starts[k]):int(starts[k]) + sz] = t
+            return tg, [pool.submit(one, k) for k in range(len(grp))]
+
+        batches, n_local, gstats = [], 0, []
+        t_gen0 = time.perf_counter()
+        nxt = generate(0) if groups else None
+        for gi in range(len(groups)):
+            tg, futs = nxt
+            for f in futs:
+                f.result()
+            nxt = generate(gi + 1) if gi + 1 < len(groups) else None     # ... overlaps this group's upload
             batches.append(ctx.upload(params, tg))                          # inputs resident in HBM before the timed region
             n_local += len(tg)
             gstats.append((int((tg["lqlen"] > 0).sum() + (tg["rqlen"] > 0).sum()),
                            int((tg["lqlen"].astype(np.int64) * tg["ltlen"]).sum() + (tg["rqlen"].astype(np.int64) * tg["rtlen"]).sum())))
             if rank == 0 and len(groups) > 1:
-                print("bench.py: rank 0 resident batch %d/%d (%d seeds)" % (len(batches), len(groups), len(tg)), file=sys.stderr, flush=True)
+                print("bench.py: rank 0 resident batch %d/%d (%d seeds, %.1f s)" % (len(batches), len(groups), len(tg), time.perf_counter() - t_gen0),
+                      file=sys.stderr, flush=True)
+        pool.shutdown()
+        setup_s = time.perf_counter() - t_gen0
+        for ar in arenas[1:]:
+            ar.free()
         tasks = tg if len(groups) == 1 else None                            # e2e legs only when the rank's share is one batch
         hout = host.HostArena(max(n_local if tasks is not None else 1, 1) * host.RESULT.itemsize)
     else:
+        setup_s = None
         n_local = args.tasks
         harena = host.HostArena(host.synth_arena_bound(max(n_local, 1), **spec) + 4096)
         hout = host.HostArena(max(n_local, 1) * host.RESULT.itemsize)
@@ -576,18 +621,21 @@ def main():
         traffic = int((2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in pmc else None
         tops = cells * VALU_OPS_PER_CELL / (kavg_ms * 1e-3) / 1e12
         out = {
-            "metric": "GCUPS (seed-extension DP cells/s, 150 bp PE)", "value": round(gcups, 3), "unit": "GCUPS",
+            "metric": "GCUPS (seed-extension DP cells/s, %d bp reads, w=%d)" % (spec["read_len"], spec["w"]), "value": round(gcups, 3), "unit": "GCUPS",
             "n_gpus": world, "world_size": (dist.get_world_size() if dist is not None else 1),
             "collective_backend": (("rccl" if args.backend == "nccl" else args.backend) if dist is not None else None),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_all / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "int32 ALU on host-range-checked u8 rows (16-bit rows / int32 for wider scores)",
+            "vs_baseline": None,
+            "dtype": "u8 scores in packed u16 VALU ops (v_pk_*_u16: two seeds per lane), range-checked per seed; wider scores run 16-bit rows / int32",
             "data": "synthetic",
             "config": {"workload": args.workload, "seeds_per_gpu": n_local if args.scaling == "weak" else None,
                        "pool_seeds": args.pool if args.scaling == "strong" else None, "read_len": spec["read_len"],
                        "band_w": spec["w"], "zdrop": args.zdrop, "variant": "H" if args.variant == 0 else "M", "gaps": args.gaps or "6,1,6,1",
                        "sharding": "per-read task shard (chunk c -> rank c mod N), no collective" if world > 1 else "single GPU",
-                       "kernel_launches_per_step": info["launches"], "resident_batches_per_rank": len(batches), "preset": args.preset},
+                       "kernel_launches_per_step": info["launches"], "resident_batches_per_rank": len(batches), "preset": args.preset,
+                       "cpu_affinity": cpu_list_str(cpu_affinity), "rank_cpus_pinned": bool(os.environ.get("BSW_RANK_CPUS")),
+                       "setup_s": round(setup_s, 1) if args.scaling == "strong" else None},
             "extensions_per_s": round(ext_all * args.steps / dt_all, 1),
             "seeds_per_s": round(tasks_all * args.steps / dt_all, 1),
             "cells_per_step": cells_all,
@@ -596,11 +644,10 @@ def main():
                 "bound": "valu", "ops_per_cell": VALU_OPS_PER_CELL,
                 "achieved": round(tops, 4), "peak": round(PEAK_VALU_TOPS, 2), "unit": "T lane-ops/s",
                 "frac": round(tops / PEAK_VALU_TOPS, 5),
-                "peak_opcode_weighted": pmc.get("peak_opcode_weighted_tops"),
                 "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"), "valu_issue_busy": pmc.get("valu_issue_busy"),
                 "traffic": traffic, "traffic_kernels": pmc.get("traffic_kernels"),
                 "counters_source": pmc_src,
-                "issue_ceiling": issue_ceiling(pmc, cells, kavg_ms),
+                "issue_ceiling": issue_ceiling(pmc, cells, kavg_ms, 1 if spec["read_len"] > 150 else 2),
                 "kernel_ms_avg": round(kavg_ms, 4),
                 "note": "integer max/add DP at ~0.02 B/cell: VALU issue binds, not HBM and not MFMA; see roofline_hbm",
             },
@@ -709,7 +756,9 @@ def main():
             ctx.sync()
             ms = float(np.mean(ctx.run_history()))
             r2 = ctx.download(b2)
-            extra[wl] = {"gcups": round(cells_of(r2) / (ms * 1e-3) / 1e9, 1), "ms_per_step": round(ms, 3), "seeds": args.tasks}
+            g2 = cells_of(r2) / (ms * 1e-3) / 1e9
+            extra[wl] = {"gcups": round(g2, 1), "ms_per_step": round(ms, 3), "seeds": args.tasks,
+                         "roofline_frac": round(g2 * 1e9 * VALU_OPS_PER_CELL / 1e12 / PEAK_VALU_TOPS, 4), "kernel_launches_per_step": b2.info()["launches"]}
             b2.free()
         out["other_workloads"] = extra
         out["other_paths"] = side_paths(host, local_rank)

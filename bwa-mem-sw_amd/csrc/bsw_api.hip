@@ -607,7 +607,7 @@ static bool lane_matrix_ok(const bsw_params *p)
     return true;
 }
 
-static size_t order_capacity(size_t n) { return 4 * n + 16; }   /* upper bound of plan.order_len + 1 */
+static size_t order_capacity(size_t n) { return 4 * n + 16; }   /* upper bound of plan.order_len + the 2 + BSW_MAX_WAVE_CLASSES counters behind it */
 
 /* ---- host pass over a chunk: validate, lay out, count per class ------------------------------ */
 struct chunk_info {
@@ -961,15 +961,17 @@ static int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint6
                          const fork_t *fk = nullptr)
 {
     const int nc = bsw::wave_class_count();
+    /* device words behind the order lists: [0] the redo list's length, [1 + c] the work counter of wave class c's launch,
+     * [1 + BSW_MAX_WAVE_CLASSES] the redo launch's — zeroed here, on the stream, before anything counts in them */
+    uint32_t *redo_cnt = d_order + pl.order_len;
+    HIPCHK(e, hipMemsetAsync(redo_cnt, 0, (2 + BSW_MAX_WAVE_CLASSES) * sizeof(uint32_t), s));
     for (int c = 0; c < nc; ++c) {
         const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
         if (!cnt) continue;
-        HIPCHK(e, bsw::launch_wave(c, variant, P, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, d_out, s));
+        HIPCHK(e, bsw::launch_wave(c, variant, P, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, redo_cnt + 1 + c, d_out, s));
         if (launches) ++*launches;
     }
     if (pl.lane_all_cnt) {
-        uint32_t *redo_cnt = d_order + pl.order_len;
-        HIPCHK(e, hipMemsetAsync(redo_cnt, 0, sizeof(uint32_t), s));
         const int nlc = bsw::lane_class_count();
         /* The classes of a side side by side: the k-th non-empty class of a side (widest first: its waves run longest) goes
          * to stream k — the slot stream, then the auxiliary ones.  A right-side launch waits for exactly the left-side
@@ -1012,7 +1014,7 @@ static int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint6
                                        d_order + pl.redo_off, redo_cnt, s));
         /* seeds whose first band try was not final: recompute from scratch, one wavefront each */
         HIPCHK(e, bsw::launch_wave(pl.redo_cls, variant, P, d_seq, d_tasks, d_order + pl.redo_off, pl.lane_all_cnt,
-                                   redo_cnt, d_out, s));
+                                   redo_cnt, redo_cnt + 1 + BSW_MAX_WAVE_CLASSES, d_out, s));
         if (launches) *launches += 2;
     }
     return BSW_OK;
@@ -2216,7 +2218,8 @@ extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
      * while the others are on the GPU (the reference's manager keeps its four TBB/RBB pairs busy the same way,
      * batch_manager.v:418,745-773). */
     dev_state &dev = ctx->devs[0];
-    const size_t grp_env = REFBATCH_GROUP;
+    static const size_t grp_tune = getenv("BSW_REFBATCH_GROUP") ? (size_t)std::max(1, atoi(getenv("BSW_REFBATCH_GROUP"))) : (size_t)REFBATCH_GROUP;   /* (measurements) */
+    const size_t grp_env = grp_tune;
     const size_t NS = std::max<size_t>(1, std::min<size_t>(REFBATCH_SLOTS, dev.slots.size()));
     const size_t slot_of[REFBATCH_SLOTS] = {0, 1, 2, 3};
     struct flight { bool active = false; size_t q0 = 0, q1 = 0, n = 0; } fl[REFBATCH_SLOTS];

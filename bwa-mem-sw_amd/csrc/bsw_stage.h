@@ -22,7 +22,7 @@ namespace bsw {
 int wave_class_count();
 int wave_class_cols(int cls);
 hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
-                       const uint32_t *order, uint32_t n, const uint32_t *n_dev, bsw_result *out, hipStream_t s);
+                       const uint32_t *order, uint32_t n, const uint32_t *n_dev, uint32_t *next_slot, bsw_result *out, hipStream_t s);
 int lane_class_count();
 int lane_class_cols(int cls);
 int lane_class_bits(int cls);

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "bsw_device.h"
 
@@ -299,6 +300,9 @@ __global__ __launch_bounds__(256) void bsw_wave_kernel(const bsw_dparams P, cons
     }
 }
 
+hipError_t launch_quad(int cols, int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
+                       const uint32_t *order, uint32_t n, const uint32_t *n_dev, uint32_t *next_slot, bsw_result *out, hipStream_t s);
+
 static const int kWaveClasses[] = {1, 2, 3, 4, 8, 16};
 
 int wave_class_count() { return (int)(sizeof(kWaveClasses) / sizeof(kWaveClasses[0])); }
@@ -318,11 +322,16 @@ static hipError_t launch_c(int variant, const bsw_dparams &P, const uint64_t *se
     return hipGetLastError();
 }
 
-/* n = seed count (or an upper bound of *n_dev when n_dev != NULL) */
+/* n = seed count (or an upper bound of *n_dev when n_dev != NULL); next_slot = a zeroed device word for the four-seeds-per-
+ * wavefront kernel's work counter (NULL: the one-wavefront-per-seed kernel runs the class) */
 hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
-                       const uint32_t *order, uint32_t n, const uint32_t *n_dev, bsw_result *out, hipStream_t s)
+                       const uint32_t *order, uint32_t n, const uint32_t *n_dev, uint32_t *next_slot, bsw_result *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
+    /* queries up to 255 bases: four seeds per wavefront, one 16-lane DPP row each (bsw_quad_kernel.hip); this file's
+     * one-wavefront-per-seed kernel keeps the long queries (and everything with BSW_NO_QUAD=1: measurements) */
+    static const bool noquad = getenv("BSW_NO_QUAD") != nullptr;
+    if (!noquad && next_slot && kWaveClasses[cls] * 64 <= 256) return launch_quad(kWaveClasses[cls] * 64, variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
     switch (kWaveClasses[cls]) {
     case 1: return launch_c<1>(variant, P, seq, tasks, order, n, n_dev, out, s);
     case 2: return launch_c<2>(variant, P, seq, tasks, order, n, n_dev, out, s);
