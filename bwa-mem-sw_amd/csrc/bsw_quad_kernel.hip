@@ -15,13 +15,16 @@
  * Mapping.  A seed owns a DPP row (16 lanes): every cross-lane step of the recurrence — the F prefix scan (row_shr
  * 1/2/4/8), H(i,j-1) (row_shr:1), the row maximum with arg-max, the first / last non-zero eh[] entry (row_ror 8/4/2/1
  * butterflies), the carries between stripes (row_newbcast:15) — stays inside the row, so four seeds share a wavefront
- * and need no wave-wide scan at all.  Columns are STRIPED: lane l owns eh[] entries j = 16 c + l, stripe c = 0 .. C-1, in
- * VGPRs for the whole extension (the RTL's 256x16b eh_arr BRAM, sw_pe_array_sw_extend_eh_arr.v).  A row then costs only
- * the stripes between the smallest `beg` and the largest `end` of the wavefront's seeds (a wave-uniform loop over
- * statically addressed registers) — work follows the live band, not the query length.
- *   - F(i,j) inside a stripe is an exclusive prefix max of B_l = max(base_l - oe_ins, 0) + l*e_ins; the value entering
- *     the stripe is carried as Bm1 = f(16c) - e_ins, so f_l = max(Bm1, P_{l-1}) - (l-1)*e_ins with one formula for every
- *     lane (valid because o_ins >= 0: f - oe_ins never beats f - e_ins);
+ * and need no wave-wide scan at all.  Columns are STRIPED, two per lane: lane l owns eh[] entries j = 32 c + 2 l and
+ * 32 c + 2 l + 1 of stripe c = 0 .. S-1, in VGPRs for the whole extension (the RTL's 256x16b eh_arr BRAM,
+ * sw_pe_array_sw_extend_eh_arr.v).  A row then costs only the stripes between the smallest `beg` and the largest `end` of
+ * the wavefront's seeds (a wave-uniform dispatch over statically addressed registers) — work follows the live band, not
+ * the query length — and one scan serves 32 columns.
+ *   - F(i,j): with A_j = max(base_j - oe_ins, 0) a lane's pair offers D_l = max(A_j0 - e_ins, A_j1) to the columns right
+ *     of it; f entering a lane's first column is an exclusive prefix max of B_l = D_l + 2 l e_ins; the value entering the
+ *     stripe is carried as Bm1 = f(32c) - 2 e_ins, so f_l = max(Bm1, P_{l-1}) - 2 (l-1) e_ins with one formula for every
+ *     lane, and the lane's second column takes max(f - e_ins, A_j0) (valid because o_ins >= 0: f - oe_ins never beats
+ *     f - e_ins);
  *   - writes are masked to [beg, end] so stale eh[] entries survive exactly as on the CPU;
  *   - the seeds of a wavefront walk their OWN rows (row index, target base, range are per-lane values, equal inside a
  *     row): a seed that ends a band try or a side re-initialises under its own lanes while the others wait.
@@ -105,14 +108,14 @@ struct qside {
 
 }  // namespace
 
-/* C = stripes of 16 columns a seed may use (cols = 16 C >= qlen + 1) */
-/* waves per SIMD the register budget is set for: the row loop itself needs ~95 + 4 C VGPRs; what the (rare, marked unlikely)
+/* S = stripes of 32 columns a seed may use (cols = 32 S >= qlen + 1) */
+/* waves per SIMD the register budget is set for: the row loop itself needs ~95 + 8 S VGPRs; what the (rare, marked unlikely)
  * try / side bookkeeping would like on top of that is spilled there rather than taken from every wave's occupancy */
-template <int C>
-constexpr int quad_wps() { return C <= 4 ? 4 : C <= 12 ? 3 : 2; }
+template <int S>
+constexpr int quad_wps() { return S <= 2 ? 4 : S <= 6 ? 3 : 2; }
 
-template <int C, int VAR>
-__global__ __launch_bounds__(256, quad_wps<C>()) void bsw_quad_kernel(const bsw_dparams P, const uint64_t *__restrict__ seq,
+template <int S, int VAR>
+__global__ __launch_bounds__(256, quad_wps<S>()) void bsw_quad_kernel(const bsw_dparams P, const uint64_t *__restrict__ seq,
                                                        const bsw_dtask *__restrict__ tasks,
                                                        const uint32_t *__restrict__ order, const uint32_t n_host,
                                                        const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ next_slot,
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, quad_wps<C>()) void bsw_quad_kernel(const bsw_
     const uint32_t n = n_dev ? *n_dev : n_host;
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    const int e16 = 16 * e_ins;
+    const int e2 = 2 * e_ins, e32 = 32 * e_ins;
     const int tries = P.max_band_try > 0 ? P.max_band_try : 1;
     /* the score matrix by query base (K6: sw_pe_array_sw_extend.v:1915-1940): four target bases packed per word + the N row */
     /* (five scalars each, not arrays: an array indexed from inside the stripe lambdas ends up as a lookup table in LDS) */
@@ -148,10 +151,10 @@ __global__ __launch_bounds__(256, quad_wps<C>()) void bsw_quad_kernel(const bsw_
         unsigned cells = 0;
         uint32_t twl = 0, twh = 0;
         int refill = -1;                             /* the row at which the seed's next 256 target bases must be fetched */
-        int X[C], E[C], phi[C];
-        uint32_t plo[C];
+        int Xa[S], Xb[S], Ea[S], Eb[S], pha[S], phb[S];   /* a / b: the lane's first / second column of a stripe */
+        uint32_t pla[S], plb[S];
 #pragma unroll
-        for (int c = 0; c < C; ++c) { X[c] = 0; E[c] = 0; phi[c] = 0; plo[c] = 0; }
+        for (int c = 0; c < S; ++c) { Xa[c] = Xb[c] = 0; Ea[c] = Eb[c] = 0; pha[c] = phb[c] = 0; pla[c] = plb[c] = 0; }
         int truesc = 0, qb = 0, rb = 0, qe = 0, re = 0, sc0 = 0, awL = P.w, awR = P.w;
 
         for (;;) {
@@ -243,30 +246,41 @@ __global__ __launch_bounds__(256, quad_wps<C>()) void bsw_quad_kernel(const bsw_
                      * words = 256 bases cover every class); stripe c's word is then a broadcast from lane c of the row */
                     const uint64_t qw = (startS && 16 * lq < qlen) ? seq[q_off + (uint32_t)lq] : 0ull;
                     const int qwl = (int)(uint32_t)qw, qwh = (int)(uint32_t)(qw >> 32);
-                    qfor<C>([&](auto ci) {
+                    qfor<S>([&](auto ci) {
                         constexpr int c = decltype(ci)::value;
-                        const int j = 16 * c + lq;
-                        const uint32_t wl = (uint32_t)qdpp<0x150 + c>(0, qwl), wh = (uint32_t)qdpp<0x150 + c>(0, qwh);
-                        int b = (int)(((lq < 8 ? wl : wh) >> ((lq & 7) * 4)) & 7u);
-                        b = (j < qlen && b < 4) ? b : 4;
-                        /* (masks, not a select chain: the compiler turns the chain into a lookup table in scratch memory) */
-                        const uint32_t m0 = 0u - (uint32_t)(b == 0), m1 = 0u - (uint32_t)(b == 1), m2 = 0u - (uint32_t)(b == 2), m3 = 0u - (uint32_t)(b == 3), m4 = 0u - (uint32_t)(b == 4);
-                        const uint32_t lo = (cpl0 & m0) | (cpl1 & m1) | (cpl2 & m2) | (cpl3 & m3) | (cpl4 & m4);
-                        const int hi = (int)(((uint32_t)cph0 & m0) | ((uint32_t)cph1 & m1) | ((uint32_t)cph2 & m2) | ((uint32_t)cph3 & m3) | ((uint32_t)cph4 & m4));
-                        plo[c] = startS ? lo : plo[c];
-                        phi[c] = startS ? hi : phi[c];
+                        /* columns 32c + 2l, + 1: lanes 0-7 read packed word 2c, lanes 8-15 word 2c + 1; nibbles 2 (l & 7), + 1 */
+                        const int j0 = 32 * c + 2 * lq;
+                        const uint32_t al = (uint32_t)qdpp<0x150 + 2 * c>(0, qwl), ah = (uint32_t)qdpp<0x150 + 2 * c>(0, qwh);
+                        const uint32_t bl = (uint32_t)qdpp<0x150 + 2 * c + 1>(0, qwl), bh = (uint32_t)qdpp<0x150 + 2 * c + 1>(0, qwh);
+                        const uint32_t lo32 = lq < 8 ? al : bl, hi32 = lq < 8 ? ah : bh;
+                        const uint32_t half = (lq & 4) ? hi32 : lo32;
+                        const uint32_t two = half >> ((lq & 3) * 8);
+                        const auto prof = [&](int b, int j, uint32_t &lo, int &hi) {
+                            b = (j < qlen && b < 4) ? b : 4;
+                            /* (masks, not a select chain: the compiler turns the chain into a lookup table in scratch memory) */
+                            const uint32_t m0 = 0u - (uint32_t)(b == 0), m1 = 0u - (uint32_t)(b == 1), m2 = 0u - (uint32_t)(b == 2), m3 = 0u - (uint32_t)(b == 3), m4 = 0u - (uint32_t)(b == 4);
+                            lo = (cpl0 & m0) | (cpl1 & m1) | (cpl2 & m2) | (cpl3 & m3) | (cpl4 & m4);
+                            hi = (int)(((uint32_t)cph0 & m0) | ((uint32_t)cph1 & m1) | ((uint32_t)cph2 & m2) | ((uint32_t)cph3 & m3) | ((uint32_t)cph4 & m4));
+                        };
+                        uint32_t lo0, lo1;
+                        int hi0, hi1;
+                        prof((int)(two & 7u), j0, lo0, hi0);
+                        prof((int)((two >> 4) & 7u), j0 + 1, lo1, hi1);
+                        pla[c] = startS ? lo0 : pla[c]; pha[c] = startS ? hi0 : pha[c];
+                        plb[c] = startS ? lo1 : plb[c]; phb[c] = startS ? hi1 : phb[c];
                         __builtin_amdgcn_sched_barrier(0);      /* one stripe at a time: this rare code must not set the kernel's register count */
                     });
                 }
                 /* a band try starts: K2 first row, closed form (:1979,1957,1974,1818-1821) */
                 aw = startT ? P.w << k : aw;
                 w = startT ? min(aw, wlim) : w;
-                qfor<C>([&](auto ci) {
+                qfor<S>([&](auto ci) {
                     constexpr int c = decltype(ci)::value;
-                    const int j = 16 * c + lq;
-                    const int x0 = j == 0 ? h0 : max(h0 - oe_ins - (j - 1) * e_ins, 0);
-                    X[c] = startT ? x0 : X[c];
-                    E[c] = startT ? 0 : E[c];
+                    const int j0 = 32 * c + 2 * lq;
+                    const int x0 = j0 == 0 ? h0 : max(h0 - oe_ins - (j0 - 1) * e_ins, 0);
+                    const int x1 = max(h0 - oe_ins - j0 * e_ins, 0);
+                    Xa[c] = startT ? x0 : Xa[c]; Xb[c] = startT ? x1 : Xb[c];
+                    Ea[c] = startT ? 0 : Ea[c]; Eb[c] = startT ? 0 : Eb[c];
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 mx = startT ? h0 : mx;
@@ -295,18 +309,18 @@ __global__ __launch_bounds__(256, quad_wps<C>()) void bsw_quad_kernel(const bsw_
              * scratch and RELOADED in every row) */
             int tid = (int)threadIdx.x;
             asm volatile("" : "+v"(tid));
-            const int l = tid & 15, lE = l * e_ins, lE1 = lE - e_ins;
+            const int l = tid & 15, l2 = 2 * l, lE2 = l2 * e_ins, lE21 = lE2 - e2;
             /* target base of this row: lane l holds packed word l of the seed's current 256-base chunk */
             const uint32_t tw = (uint32_t)__builtin_amdgcn_ds_bpermute(((tid & 48) | ((i >> 4) & 15)) << 2, (int)((i & 8) ? twh : twl));
             /* K3 band clamp (:1803,1894-1897,1842,1898) */
             beg = max(beg, i - w);
             end = min(min(end, i + w + 1), qlen);
             /* Which stripes this row touches, over the live seeds of the wavefront: stripes cmin .. cmax hold some seed's
-             * [beg, end]; stripes imin .. imax lie strictly inside EVERY live seed's range (beg < 16 c, 16 c + 16 <= end) and
+             * [beg, end]; stripes imin .. imax lie strictly inside EVERY live seed's range (beg < 32 c, 32 c + 32 <= end) and
              * run the body without masks.  Two packed 16-bit minima / maxima across the four rows, then one bit mask per body. */
             uint32_t m_int, m_edge;
             {
-                const uint32_t cb = (uint32_t)(beg >> 4), ce = (uint32_t)max(end, 0) >> 4;
+                const uint32_t cb = (uint32_t)(beg >> 5), ce = (uint32_t)max(end, 0) >> 5;
                 uint32_t mn = alive ? (cb | (ce << 16)) : 0x001f001fu;     /* min: first stripe | last stripe for the interior */
                 uint32_t mxv = alive ? (ce | (cb << 16)) : 0u;              /* max: last stripe | first stripe for the interior */
                 uint32_t t;
@@ -339,73 +353,86 @@ __global__ __launch_bounds__(256, quad_wps<C>()) void bsw_quad_kernel(const bsw_
             /* K4 column 0, CPU semantics (:1795-1796,1835; Q4 avoided) */
             const int h1_init = beg == 0 ? max(h0 - (o_del + __mul24(e_del, i + 1)), 0) : 0;   /* (e_del <= 4096, i < 65536) */
             cells += (unsigned)max(end - beg, 0);
-            const int rel = l - beg, span_e = end - beg;
+            const int rel = l2 - beg, span_e = end - beg;
             const unsigned span_in = (unsigned)max(span_e, 0), span_wr = (unsigned)max(span_e + 1, 0);
 
-            int Bm1 = NEGQ;                           /* f entering the stripe, minus e_ins; nothing enters the first one */
-            int h15 = 0;                              /* H(i, 16c - 1): the previous stripe's last column */
-            int bestv = -1, bestc = 0, hl = -1;
-            uint32_t nzb = 0;                         /* bit c: this lane's eh[] entry of stripe c is non-zero (inside [beg, end]) */
+            int Bm1 = NEGQ;                           /* f entering the stripe, minus 2 e_ins; nothing enters the first one */
+            int h31 = 0;                              /* H(i, 32c - 1): the previous stripe's last column */
+            int bestv = -1, bestk = 0, hl = -1;       /* bestk = 2 c + (second column) */
+            uint32_t nzb = 0;                         /* bit 2 c + k: this lane's eh[] entry of stripe c, column k, is non-zero (inside [beg, end]) */
             /* one stripe.  INT: every column of the stripe lies strictly inside every live seed's range — no masks.
              * TNV: some live seed's target base is an N this row (its scores come from the matrix's N row). */
             const auto stripe = [&](auto ci, auto intv, auto tnv) {
                 constexpr int c = decltype(ci)::value;
                 constexpr bool INT = decltype(intv)::value, TNV = decltype(tnv)::value;
-                const int u = rel + 16 * c;           /* j - beg */
-                const bool inr = INT || (unsigned)u < span_in, wr = INT || (unsigned)u < span_wr;
-                int s = (int)__builtin_amdgcn_sbfe((int)plo[c], sh, 8u);
-                if (TNV) s = tn ? phi[c] : s;
-                int M = X[c] + s;                     /* variant H (:1797) */
-                if (VAR == BSW_VARIANT_M) M = X[c] ? M : 0;
-                const int ht = max(M, E[c]);          /* (:1798) */
-                const int bs = VAR == BSW_VARIANT_M ? M : ht;
-                int B = max(bs - oe_ins, 0) + lE;
-                if (!INT) B = inr ? B : NEGQ;
-                const int Pm = row_scan_max(B);       /* inclusive prefix max over the stripe (F recurrence, :1863,1780-1781) */
-                const int f = shr1_max(Pm, Bm1) - lE1;
-                const int hv = max(ht, f);            /* (:1809,1944) */
-                Bm1 = bcast15_max(Pm, Bm1) - e16;
-                const int bs2 = VAR == BSW_VARIANT_M ? M : hv;
-                const int en = max(max(E[c] - e_del, bs2 - oe_del), 0);   /* (:1866,1770-1771) */
-                /* row maximum, ties -> later j (:1808,1816): stripes ascend, so >= keeps the later one */
-                const bool take = inr && hv >= bestv;
-                bestv = take ? hv : bestv;
-                bestc = take ? c : bestc;
-                /* eh[j].h <- H(i,j-1) for j in [beg,end]; eh[end].e <- 0 (:1776,1775) */
-                const int hp = qdpp<0x111>(h15, hv);
-                h15 = qdpp<0x15F>(0, hv);
-                int xnew, enew;
-                if (INT) { xnew = hp; enew = en; }
+                const int u0 = rel + 32 * c, u1 = u0 + 1;     /* j - beg of the lane's two columns */
+                const bool inr0 = INT || (unsigned)u0 < span_in, inr1 = INT || (unsigned)u1 < span_in;
+                const bool wr0 = INT || (unsigned)u0 < span_wr, wr1 = INT || (unsigned)u1 < span_wr;
+                int s0 = (int)__builtin_amdgcn_sbfe((int)pla[c], sh, 8u), s1 = (int)__builtin_amdgcn_sbfe((int)plb[c], sh, 8u);
+                if (TNV) { s0 = tn ? pha[c] : s0; s1 = tn ? phb[c] : s1; }
+                int M0 = Xa[c] + s0, M1 = Xb[c] + s1;          /* variant H (:1797) */
+                if (VAR == BSW_VARIANT_M) { M0 = Xa[c] ? M0 : 0; M1 = Xb[c] ? M1 : 0; }
+                const int ht0 = max(M0, Ea[c]), ht1 = max(M1, Eb[c]);   /* (:1798) */
+                int A0 = max((VAR == BSW_VARIANT_M ? M0 : ht0) - oe_ins, 0), A1 = max((VAR == BSW_VARIANT_M ? M1 : ht1) - oe_ins, 0);
+                if (!INT) { A0 = inr0 ? A0 : NEGQ; A1 = inr1 ? A1 : NEGQ; }
+                /* what the pair offers the columns right of it, scanned over the row's lanes (F recurrence, :1863,1780-1781) */
+                const int Pm = row_scan_max(max(A0 - e_ins, A1) + lE2);
+                const int f0 = shr1_max(Pm, Bm1) - lE21;
+                const int hv0 = max(ht0, f0);         /* (:1809,1944) */
+                const int f1 = max(f0 - e_ins, A0);
+                const int hv1 = max(ht1, f1);
+                Bm1 = bcast15_max(Pm, Bm1) - e32;
+                const int en0 = max(max(Ea[c] - e_del, (VAR == BSW_VARIANT_M ? M0 : hv0) - oe_del), 0);   /* (:1866,1770-1771) */
+                const int en1 = max(max(Eb[c] - e_del, (VAR == BSW_VARIANT_M ? M1 : hv1) - oe_del), 0);
+                /* row maximum, ties -> later j (:1808,1816): columns ascend, so >= keeps the later one */
+                const bool take0 = inr0 && hv0 >= bestv;
+                bestv = take0 ? hv0 : bestv;
+                bestk = take0 ? 2 * c : bestk;
+                const bool take1 = inr1 && hv1 >= bestv;
+                bestv = take1 ? hv1 : bestv;
+                bestk = take1 ? 2 * c + 1 : bestk;
+                /* eh[j].h <- H(i,j-1) for j in [beg,end]; eh[end].e <- 0 (:1776,1775): the first column takes the lane to the
+                 * left's second one (lane 0: the previous stripe's last), the second column the lane's own first */
+                const int hp0 = qdpp<0x111>(h31, hv1);
+                h31 = qdpp<0x15F>(0, hv1);
+                int xa, xb, ea, eb;
+                if (INT) { xa = hp0; xb = hv0; ea = en0; eb = en1; }
                 else {
-                    const int xn = u == 0 ? h1_init : hp;
-                    const bool jend = u == span_e;
-                    xnew = wr ? xn : X[c];
-                    enew = inr ? en : E[c];
-                    enew = jend ? 0 : enew;
-                    hl = jend ? xnew : hl;
+                    const int xn0 = u0 == 0 ? h1_init : hp0, xn1 = u1 == 0 ? h1_init : hv0;
+                    const bool jend0 = u0 == span_e, jend1 = u1 == span_e;
+                    xa = wr0 ? xn0 : Xa[c];
+                    xb = wr1 ? xn1 : Xb[c];
+                    ea = inr0 ? en0 : Ea[c];
+                    eb = inr1 ? en1 : Eb[c];
+                    ea = jend0 ? 0 : ea;
+                    eb = jend1 ? 0 : eb;
+                    hl = jend0 ? xa : hl;
+                    hl = jend1 ? xb : hl;
                 }
-                X[c] = xnew; E[c] = enew;
-                const bool nz = wr && ((xnew | enew) != 0);
-                nzb |= nz ? (1u << c) : 0u;
+                Xa[c] = xa; Xb[c] = xb; Ea[c] = ea; Eb[c] = eb;
+                const bool nz0 = wr0 && ((xa | ea) != 0), nz1 = wr1 && ((xb | eb) != 0);
+                nzb |= (nz0 ? (1u << (2 * c)) : 0u) | (nz1 ? (2u << (2 * c)) : 0u);
             };
             using no_t = std::integral_constant<bool, false>;
             using yes_t = std::integral_constant<bool, true>;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(tn && alive) != 0, 0)) {
-                qfor<C>([&](auto ci) {
+                qfor<S>([&](auto ci) {
                     constexpr int c = decltype(ci)::value;
                     if ((m_int >> c) & 1u) stripe(ci, yes_t{}, yes_t{});
                     if ((m_edge >> c) & 1u) stripe(ci, no_t{}, yes_t{});
                 });
             } else {
-                qfor<C>([&](auto ci) {
+                qfor<S>([&](auto ci) {
                     constexpr int c = decltype(ci)::value;
                     if ((m_int >> c) & 1u) stripe(ci, yes_t{}, no_t{});
                     if ((m_edge >> c) & 1u) stripe(ci, no_t{}, no_t{});
                 });
             }
-            int key = bestv < 0 ? -1 : ((bestv << BSW_KEY_BITS) | (bestc * 16 + l));
-            int nfz = nzb ? -(__builtin_ctz(nzb) * 16 + l) : INT_MIN;
-            int lz = nzb ? (31 - __builtin_clz(nzb)) * 16 + l : -1;
+            /* column of code k = 2 c + (second column): 32 c + 2 l + (k & 1) = 16 k - 15 (k & 1) + 2 l */
+            const auto col_of = [&](int kcode) { return 16 * kcode - 15 * (kcode & 1) + l2; };
+            int key = bestv < 0 ? -1 : ((bestv << BSW_KEY_BITS) | col_of(bestk));
+            int nfz = nzb ? -col_of(__builtin_ctz(nzb)) : INT_MIN;
+            int lz = nzb ? col_of(31 - __builtin_clz(nzb)) : -1;
             row_max4(key, nfz, lz, hl);
             const int mrow = key < 0 ? 0 : (key >> BSW_KEY_BITS);
             const int mj = key < 0 ? -1 : (key & ((1 << BSW_KEY_BITS) - 1));
@@ -436,7 +463,7 @@ __global__ __launch_bounds__(256, quad_wps<C>()) void bsw_quad_kernel(const bsw_
     }
 }
 
-template <int C>
+template <int S>
 static hipError_t launch_qc(int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
                             const uint32_t *order, uint32_t n, const uint32_t *n_dev, uint32_t *next_slot, bsw_result *out, hipStream_t s)
 {
@@ -446,9 +473,9 @@ static hipError_t launch_qc(int variant, const bsw_dparams &P, const uint64_t *s
     if (blocks > 2048u) blocks = 2048u;
     const dim3 grid(blocks), block(256);
     if (variant == BSW_VARIANT_M)
-        hipLaunchKernelGGL((bsw_quad_kernel<C, BSW_VARIANT_M>), grid, block, 0, s, P, seq, tasks, order, n, n_dev, next_slot, out);
+        hipLaunchKernelGGL((bsw_quad_kernel<S, BSW_VARIANT_M>), grid, block, 0, s, P, seq, tasks, order, n, n_dev, next_slot, out);
     else
-        hipLaunchKernelGGL((bsw_quad_kernel<C, BSW_VARIANT_H>), grid, block, 0, s, P, seq, tasks, order, n, n_dev, next_slot, out);
+        hipLaunchKernelGGL((bsw_quad_kernel<S, BSW_VARIANT_H>), grid, block, 0, s, P, seq, tasks, order, n, n_dev, next_slot, out);
     return hipGetLastError();
 }
 
@@ -458,10 +485,10 @@ hipError_t launch_quad(int cols, int variant, const bsw_dparams &P, const uint64
                        const uint32_t *order, uint32_t n, const uint32_t *n_dev, uint32_t *next_slot, bsw_result *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    if (cols <= 64) return launch_qc<4>(variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
-    if (cols <= 128) return launch_qc<8>(variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
-    if (cols <= 192) return launch_qc<12>(variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
-    return launch_qc<16>(variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
+    if (cols <= 64) return launch_qc<2>(variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
+    if (cols <= 128) return launch_qc<4>(variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
+    if (cols <= 192) return launch_qc<6>(variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
+    return launch_qc<8>(variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
 }
 
 }  // namespace bsw

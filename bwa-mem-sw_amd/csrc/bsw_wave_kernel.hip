@@ -328,10 +328,17 @@ hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_
                        const uint32_t *order, uint32_t n, const uint32_t *n_dev, uint32_t *next_slot, bsw_result *out, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    /* queries up to 255 bases: four seeds per wavefront, one 16-lane DPP row each (bsw_quad_kernel.hip); this file's
-     * one-wavefront-per-seed kernel keeps the long queries (and everything with BSW_NO_QUAD=1: measurements) */
-    static const bool noquad = getenv("BSW_NO_QUAD") != nullptr;
-    if (!noquad && next_slot && kWaveClasses[cls] * 64 <= 256) return launch_quad(kWaveClasses[cls] * 64, variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
+    /* Four seeds per wavefront, one 16-lane DPP row each (bsw_quad_kernel.hip), where it is the faster of the two general
+     * kernels: classes of 192 / 256 columns (queries of 128 - 255 bases) from 8 192 seeds up.  Measured, device-resident
+     * (gpurun_out/r4r, r4s2): 131 x 257 seeds 1.23x at 8 k, 1.43x at 16 k, 1.53x at 128 k seeds — but a lone four-seed wave
+     * walks a row in 1.15 us where a one-seed wave needs 0.5, so below ~6 k seeds (the GPU not full) this file's kernel
+     * wins; and on PE mixed bins (sides of 1 - 131 bases, most of them one 64-column wave class wide) the four-seed rows'
+     * fixed cost per row leaves no gain at any size (0.41x at 1 k ... 0.96x at 128 k seeds).  BSW_QUAD=1 sends every class
+     * up to 256 columns through it whatever the size (tests, measurements), BSW_QUAD=0 none. */
+    static const int quad_mode = getenv("BSW_QUAD") ? atoi(getenv("BSW_QUAD")) : -1;
+    const int cols = kWaveClasses[cls] * 64;
+    const bool quad = next_slot && cols <= 256 && (quad_mode == 1 || (quad_mode < 0 && cols >= 192 && !n_dev && n >= 8192u));
+    if (quad) return launch_quad(cols, variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
     switch (kWaveClasses[cls]) {
     case 1: return launch_c<1>(variant, P, seq, tasks, order, n, n_dev, out, s);
     case 2: return launch_c<2>(variant, P, seq, tasks, order, n, n_dev, out, s);

@@ -5,9 +5,9 @@ OUT=$R/gpurun_out/$1; mkdir -p $OUT
 cd $R
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/gputest.log 2>&1; tail -3 $OUT/gputest.log
 python3 tools/crossover.py > $OUT/cross_quad.json 2>/dev/null
-BSW_NO_QUAD=1 python3 tools/crossover.py > $OUT/cross_wave.json 2>/dev/null
+BSW_QUAD=0 python3 tools/crossover.py > $OUT/cross_wave.json 2>/dev/null
 python3 tools/side_rates.py wire 2>/dev/null | tail -1 > $OUT/wire_quad.json
-BSW_NO_QUAD=1 python3 tools/side_rates.py wire 2>/dev/null | tail -1 > $OUT/wire_wave.json
+BSW_QUAD=0 python3 tools/side_rates.py wire 2>/dev/null | tail -1 > $OUT/wire_wave.json
 python3 - $OUT <<PY
 import json, sys
 o = sys.argv[1]
