@@ -32,10 +32,19 @@ struct bsw_ref {
     int64_t l_pac = 0;
 };
 
-/* BSW_KERNEL_AUTO: a lane launch costs one wave's full duration (~1.3 ms for 150 bp seeds) however few seeds it
- * holds, the wave-per-task kernel scales with the seed count; measured crossover 17.4k seeds (a lone wave runs the headline bin's side in 1.00 ms since the bit-mask block dispatch, 1.37 ms before; tools/crossover.py,
- * profiles/r3/crossover_wave_vs_lane.json) */
-#define LANE_AUTO_MIN 17500
+/* BSW_KERNEL_AUTO: a lane launch costs one wave's full duration (1.0 ms for a 131-column side) however few seeds it
+ * holds, and a chunk with both sides pays it twice; the general kernels scale with the seed count.  Measured crossovers,
+ * device-resident (profiles/r4/crossover_general_kernels.json): one-sided 131 x 257 seeds 27 k (17.4 k before the
+ * four-seeds-per-wavefront kernel took the long classes), PE mixed bins ~50 k (two lane launches of 1.05 ms against 36 ns
+ * per seed).  So: lane bins from LANE_AUTO_MIN eligible seeds PER LAUNCHED SIDE. */
+#define LANE_AUTO_MIN 26000
+static bool lane_bins_pay(uint32_t n_lane, const uint32_t *cl, const uint32_t *cr)
+{
+    uint32_t l = 0, r = 0;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { l += cl[c]; r += cr[c]; }
+    const uint32_t sides = (l ? 1u : 0u) + (r ? 1u : 0u);
+    return n_lane >= (uint32_t)LANE_AUTO_MIN * (sides ? sides : 1u);
+}
 #define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
 #define RAW_FRONT 32                 /* ... and in front of the first one (reversed left queries) */
 
@@ -138,6 +147,7 @@ struct stage_t {
     dbuf<bsw_rawoff> d_roff;
     dbuf<uint32_t> d_order, d_bins;
     dbuf<bsw_result> d_out;
+    dbuf<bsw_pair> d_pair;            /* BSW_RESULT_PAIR: the dense 32-byte records that cross PCIe */
     dbuf<bsw_refx> d_desc;
     dbuf<bsw_wireoff> d_woff;
     void set_pinned(bool on) { h_raw.pinned = h_tasks.pinned = h_roff.pinned = h_out.pinned = h_desc.pinned = h_woff.pinned = on; }
@@ -147,7 +157,7 @@ struct stage_t {
     {
         release_host();
         release_transient_dev();
-        d_seq.release(); d_tasks.release(); d_order.release(); d_out.release();
+        d_seq.release(); d_tasks.release(); d_order.release(); d_out.release(); d_pair.release();
     }
 };
 
@@ -347,6 +357,7 @@ extern "C" void bsw_default_config(bsw_config *c)
     c->chunk_tasks = 131072;
     c->n_devices = 0;
     c->timeout_ms = 120000;
+    c->result_format = BSW_RESULT_FULL;
 }
 
 extern "C" int bsw_device_count(void)
@@ -407,6 +418,7 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
     if (c.timeout_ms <= 0) c.timeout_ms = 120000;
     if (const char *t = getenv("BSW_TIMEOUT_MS")) { if (atoi(t) > 0) c.timeout_ms = atoi(t); }
     if (c.n_devices < 0 || c.n_devices > BSW_MAX_DEVICES) return BSW_E_INVAL;
+    if (c.result_format != BSW_RESULT_FULL && c.result_format != BSW_RESULT_PAIR) return BSW_E_INVAL;
     if (c.n_devices == 0) { c.n_devices = 1; c.devices[0] = c.device; }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -823,7 +835,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     }
     if (acc >= (1ull << 32)) return fail(e, BSW_E_LIMIT, "batch sequence arena beyond 2^32 words; split the batch");
     if (accb >= (1ull << 32) - RAW_SLACK) return fail(e, BSW_E_LIMIT, "batch holds more than 4 GiB of bases; split the batch");
-    if (kern == BSW_KERNEL_AUTO && n_lane < LANE_AUTO_MIN) bp.lane_on = 0;
+    if (kern == BSW_KERNEL_AUTO && !lane_bins_pay(n_lane, cl, cr)) bp.lane_on = 0;
     if (bp.lane_on && narrow_foldable(bp)) {
         uint64_t all8 = 0;
         for (int c = 0; c < bp.n_lane; ++c) if (bp.lane_bits[c] == bp.lane_bits[0]) all8 += lane_work[c];
@@ -958,7 +970,7 @@ static const fork_t *fork_for(const bsw_ctx *ctx, hipStream_t s)
 
 static int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
                          uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches,
-                         const fork_t *fk = nullptr)
+                         const fork_t *fk = nullptr, bsw_pair *d_pair = nullptr)
 {
     const int nc = bsw::wave_class_count();
     /* device words behind the order lists: [0] the redo list's length, [1 + c] the work counter of wave class c's launch,
@@ -969,6 +981,7 @@ static int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint6
         const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
         if (!cnt) continue;
         HIPCHK(e, bsw::launch_wave(c, variant, P, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, redo_cnt + 1 + c, d_out, s));
+        if (d_pair) HIPCHK(e, bsw::launch_pairs_from_results(d_order + pl.wave_start[c], cnt, nullptr, d_out, d_pair, s));
         if (launches) ++*launches;
     }
     if (pl.lane_all_cnt) {
@@ -1011,10 +1024,11 @@ static int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint6
             }
         }
         HIPCHK(e, bsw::launch_finalize(P, d_tasks, d_order + pl.lane_all_off, pl.lane_all_cnt, d_out,
-                                       d_order + pl.redo_off, redo_cnt, s));
+                                       d_order + pl.redo_off, redo_cnt, d_pair, s));
         /* seeds whose first band try was not final: recompute from scratch, one wavefront each */
         HIPCHK(e, bsw::launch_wave(pl.redo_cls, variant, P, d_seq, d_tasks, d_order + pl.redo_off, pl.lane_all_cnt,
                                    redo_cnt, redo_cnt + 1 + BSW_MAX_WAVE_CLASSES, d_out, s));
+        if (d_pair) HIPCHK(e, bsw::launch_pairs_from_results(d_order + pl.redo_off, pl.lane_all_cnt, redo_cnt, d_out, d_pair, s));
         if (launches) *launches += 2;
     }
     return BSW_OK;
@@ -1452,16 +1466,20 @@ static int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent
     const double t_c = dbg ? tnow() : 0;
     rc = stage_device(e, st, s, ci, n, false, nullptr, nullptr, turn);
     if (rc) return rc;
-    rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, s, nullptr, fork_for(ctx, s));
+    /* BSW_RESULT_PAIR: `out` addresses bsw_pair[n]; the dense 32-byte records come from their own device array */
+    const bool pairs = ctx->cfg.result_format == BSW_RESULT_PAIR;
+    const size_t rec = pairs ? sizeof(bsw_pair) : sizeof(bsw_result);
+    if (pairs && (he = st.d_pair.reserve(n + 1)) != hipSuccess) return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, s, nullptr, fork_for(ctx, s), pairs ? st.d_pair.p : nullptr);
     if (rc) return rc;
-    const bool out_direct = is_registered(out, n * sizeof(bsw_result));
+    const bool out_direct = is_registered(out, n * rec);
     if (!out_direct && (he = st.h_out.reserve(n)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
-    HIPCHK(e, hipMemcpyAsync(out_direct ? out : st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipMemcpyAsync(out_direct ? (void *)out : (void *)st.h_out.p, pairs ? (const void *)st.d_pair.p : (const void *)st.d_out.p, n * rec, hipMemcpyDeviceToHost, s));
     const double t_d = dbg ? tnow() : 0;
     rc = sync_stream(ctx, e, s, ev);
     if (rc) return rc;
     const double t_e = dbg ? tnow() : 0;
-    if (!out_direct) memcpy(out, st.h_out.p, n * sizeof(bsw_result));
+    if (!out_direct) memcpy((void *)out, st.h_out.p, n * rec);
     if (dbg) fprintf(stderr, "[bsw] chunk n=%zu %s: prepare %.3f ms, gather %.3f, enqueue %.3f, gpu wait %.3f, copy-out %.3f (t0=%.3f)\n", n,
                      ci.direct ? "direct" : "gather", t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, tnow() - t_e, t_a);
     return BSW_OK;
@@ -1487,7 +1505,7 @@ static std::vector<std::vector<chunk_span>> plan_chunks(size_t n, size_t chunk, 
     for (size_t base = 0; base < n; base += per, ++c) {
         const size_t cnt = std::min(per, n - base);
         std::vector<chunk_span> &v = out[c % G];
-        if (v.empty() && cnt >= 3 * (size_t)LANE_AUTO_MIN + 1024) {
+        if (v.empty() && cnt >= 6 * (size_t)LANE_AUTO_MIN + 1024) {     /* (either part still far above the lane kernels' minimum, both sides launched) */
             const size_t h = ((cnt / 3) + 255) & ~(size_t)255;
             v.push_back(chunk_span{base, h});
             v.push_back(chunk_span{base + h, cnt - h});
@@ -1514,7 +1532,11 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
     const size_t S = dev.slots.size();
     stage_t &st = dev.slots[s];
     hipStream_t stream = dev.streams[s];
-    struct { bool active = false; size_t n = 0; bsw_result *out = nullptr; bool direct = false, copied = false; } pend;
+    struct { bool active = false; size_t n = 0; char *out = nullptr; bool direct = false, copied = false; } pend;
+    /* BSW_RESULT_PAIR: `out` addresses bsw_pair[n]; the dense 32-byte records come from their own device array */
+    const bool pairs = ctx->cfg.result_format == BSW_RESULT_PAIR;
+    const size_t rec = pairs ? sizeof(bsw_pair) : sizeof(bsw_result);
+    auto d_res = [&]() -> const void * { return pairs ? (const void *)st.d_pair.p : (const void *)st.d_out.p; };
     bool queued = false;                            /* some async op of the current chunk may be on the stream (set before the first one) */
     auto bail = [&](int rc) {                       /* wake the slots waiting for their DMA turn; leave nothing in flight */
         abort_flag = 1;
@@ -1535,12 +1557,12 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         if (!pend.copied) {                         /* kernels done -> result DMA -> done */
             rc = wait_event(ctx, e, dev.events[s]);
             if (rc) return rc;
-            const hipError_t ce = hipMemcpyAsync(pend.direct ? pend.out : st.h_out.p, st.d_out.p, pend.n * sizeof(bsw_result), hipMemcpyDeviceToHost, stream);
+            const hipError_t ce = hipMemcpyAsync(pend.direct ? (void *)pend.out : (void *)st.h_out.p, d_res(), pend.n * rec, hipMemcpyDeviceToHost, stream);
             if (ce != hipSuccess) return fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(ce));
         }
         rc = sync_stream(ctx, e, stream, dev.events[s]);
         if (rc) return rc;
-        if (!pend.direct) memcpy(pend.out, st.h_out.p, pend.n * sizeof(bsw_result));
+        if (!pend.direct) memcpy(pend.out, st.h_out.p, pend.n * rec);
         return BSW_OK;
     };
     for (size_t k = s; k < chunks.size() && !abort_flag; k += S) {            /* k-th chunk of this device */
@@ -1590,10 +1612,11 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         turn.gate = &gate; turn.seq = k; turn.ev = dev.h2d_done[s]; turn.abort_flag = &abort_flag;
         queued = true;
         rc = stage_device(e, st, stream, ci, n, rtasks != nullptr, ref, nullptr, &turn, d);
-        if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr, fork_for(ctx, stream));
+        if (!rc && pairs && (he = st.d_pair.reserve(n + 1)) != hipSuccess) rc = fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+        if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr, fork_for(ctx, stream), pairs ? st.d_pair.p : nullptr);
         if (rc) return bail(rc);
-        bsw_result *co = out + chunks[k].base;
-        pend.direct = is_registered(co, n * sizeof(bsw_result));
+        char *co = (char *)out + chunks[k].base * rec;
+        pend.direct = is_registered(co, n * rec);
         if (!pend.direct && (he = st.h_out.reserve(n)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
         /* A result copy queued behind its kernels sits at the head of its DMA engine's ring until they finish and holds up
          * the copies queued to that engine after it (profiles/r2/wire_submit_timeline.txt).  With the reference on the
@@ -1601,7 +1624,7 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
          * result DMA itself once the kernels are done); with 448 B per seed of input the link is busy anyway and the
          * extra host round trip per chunk costs more than it saves (-6 %), so there the copy is queued right away. */
         const bool late = rtasks != nullptr;
-        if (!late) he = hipMemcpyAsync(pend.direct ? co : st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, stream);
+        if (!late) he = hipMemcpyAsync(pend.direct ? (void *)co : (void *)st.h_out.p, d_res(), n * rec, hipMemcpyDeviceToHost, stream);
         else he = hipEventRecord(dev.events[s], stream);
         if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(he)));
         pend.copied = !late;
@@ -2130,7 +2153,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
         for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { cl[c] += pt.cl[c]; cr[c] += pt.cr[c]; }
         n_lane += pt.n_lane;
     }
-    if (ctx->cfg.kernel == BSW_KERNEL_AUTO && n_lane < LANE_AUTO_MIN) bp.lane_on = 0;
+    if (ctx->cfg.kernel == BSW_KERNEL_AUTO && !lane_bins_pay(n_lane, cl, cr)) bp.lane_on = 0;
     if (bp.lane_on && narrow_foldable(bp)) narrow_fold(bp, cl, cr, nullptr);     /* (wire-format groups: one launch per side) */
     if (!bp.lane_on) { memcpy(cw, cw_all, sizeof(cw)); memset(cl, 0, sizeof(cl)); memset(cr, 0, sizeof(cr)); n_lane = 0; }
     batch_plan &pl = ci.plan;

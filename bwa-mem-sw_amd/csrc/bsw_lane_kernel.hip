@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane_kernel(const bsw_dparams P,
 __global__ __launch_bounds__(256) void bsw_pair_finalize(const bsw_dparams P, const bsw_dtask *__restrict__ tasks,
                                                          const uint32_t *__restrict__ order, const uint32_t n,
                                                          bsw_result *__restrict__ out,
-                                                         uint32_t *__restrict__ redo, uint32_t *__restrict__ redo_cnt)
+                                                         uint32_t *__restrict__ redo, uint32_t *__restrict__ redo_cnt,
+                                                         bsw_pair *__restrict__ pairs)
 {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     if (slot >= n) return;
@@ -368,7 +369,30 @@ __global__ __launch_bounds__(256) void bsw_pair_finalize(const bsw_dparams P, co
         return;
     }
     r.tag = T.tag; r.qb = qb; r.qe = qe; r.rb = rb; r.re = re; r.score = score; r.truesc = truesc; r.w = P.w;
-    out[ti] = r;
+    if (pairs) {
+        /* BSW_RESULT_PAIR: the RTL's 5-word record alone (sw_pe_array_proc_element.v:1662-1665), 32 bytes into the dense
+         * array that crosses PCIe; the per-side records stay where the lane kernels left them */
+        bsw_pair pr;
+        pr.tag = r.tag; pr.qb = r.qb; pr.qe = r.qe; pr.rb = r.rb; pr.re = r.re; pr.score = r.score; pr.truesc = r.truesc; pr.w = r.w;
+        pairs[ti] = pr;
+    } else
+        out[ti] = r;
+}
+
+/* BSW_RESULT_PAIR: the seeds the general kernels computed (their lists in `order`; n_dev != NULL: the redo list, counted on
+ * the device) leave full records in `out`; their pair-level fields are copied into the dense array */
+__global__ __launch_bounds__(256) void bsw_pairs_from_results(const uint32_t *__restrict__ order, const uint32_t n_host,
+                                                              const uint32_t *__restrict__ n_dev,
+                                                              const bsw_result *__restrict__ out, bsw_pair *__restrict__ pairs)
+{
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < n; slot += gridDim.x * 256u) {
+        const uint32_t ti = order[slot];
+        const bsw_result *r = out + ti;
+        bsw_pair pr;
+        pr.tag = r->tag; pr.qb = r->qb; pr.qe = r->qe; pr.rb = r->rb; pr.re = r->re; pr.score = r->score; pr.truesc = r->truesc; pr.w = r->w;
+        pairs[ti] = pr;
+    }
 }
 #endif
 
@@ -467,10 +491,19 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
 }
 
 hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
-                           bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, hipStream_t s)
+                           bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, bsw_pair *pairs, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(bsw_pair_finalize, dim3((n + 255u) / 256u), dim3(256), 0, s, P, tasks, order, n, out, redo, redo_cnt);
+    hipLaunchKernelGGL(bsw_pair_finalize, dim3((n + 255u) / 256u), dim3(256), 0, s, P, tasks, order, n, out, redo, redo_cnt, pairs);
+    return hipGetLastError();
+}
+
+hipError_t launch_pairs_from_results(const uint32_t *order, uint32_t n, const uint32_t *n_dev, const bsw_result *out, bsw_pair *pairs, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    uint32_t blocks = (n + 255u) / 256u;
+    if (n_dev && blocks > 256u) blocks = 256u;          /* the redo list is short: stride over it */
+    hipLaunchKernelGGL(bsw_pairs_from_results, dim3(blocks), dim3(256), 0, s, order, n, n_dev, out, pairs);
     return hipGetLastError();
 }
 #endif

@@ -28,8 +28,10 @@ int lane_class_cols(int cls);
 int lane_class_bits(int cls);
 hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
                        const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
+/* pairs != NULL (BSW_RESULT_PAIR): the pair-level record goes to pairs[task], 32 bytes, instead of back into out[task] */
 hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
-                           bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, hipStream_t s);
+                           bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, bsw_pair *pairs, hipStream_t s);
+hipError_t launch_pairs_from_results(const uint32_t *order, uint32_t n, const uint32_t *n_dev, const bsw_result *out, bsw_pair *pairs, hipStream_t s);
 /* raw byte of a sequence = raw[roff - bias] (uint32 arithmetic).  pac != NULL: the targets are not in raw, they are
  * fetched from the resident reference at refx[] */
 hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t bias, uint32_t n, int rev_left,

@@ -43,14 +43,17 @@ REF_TASK = np.dtype([("query", "<u8"), ("l_query", "<i4"), ("init_score", "<i4")
 MAX_DEVICES = 16
 CONFIG = np.dtype([("device", "<i4"), ("kernel", "<i4"), ("streams", "<i4"), ("pack_threads", "<i4"),
                    ("chunk_tasks", "<u8"), ("n_devices", "<i4"), ("devices", "<i4", (MAX_DEVICES,)),
-                   ("timeout_ms", "<i4")])
+                   ("timeout_ms", "<i4"), ("result_format", "<i4"), ("_pad", "<i4")])
+PAIR = np.dtype([("tag", "<u4"), ("qb", "<i4"), ("qe", "<i4"), ("rb", "<i4"), ("re", "<i4"),
+                 ("score", "<i4"), ("truesc", "<i4"), ("w", "<i4")])       # the RTL's 5-word record: the first 32 bytes of RESULT
+RESULT_FULL, RESULT_PAIR = 0, 1
 assert PARAMS.itemsize == 68 and TASK.itemsize == 72 and EXT.itemsize == 32 and RESULT.itemsize == 96
 assert ATASK.itemsize == 32 and KSWR.itemsize == 28
-assert EXT_TASK.itemsize == 40 and SYNTH.itemsize == 72 and CONFIG.itemsize == 96 and REF_TASK.itemsize == 56
+assert EXT_TASK.itemsize == 40 and SYNTH.itemsize == 72 and CONFIG.itemsize == 104 and PAIR.itemsize == 32 and REF_TASK.itemsize == 56
 
 REFBATCH_IN_WORDS, REFBATCH_OUT_WORDS, REFBATCH_MAX_TASKS = 65536, 4096, 819
 KERNEL_AUTO, KERNEL_WAVE, KERNEL_LANE = 0, 1, 2
-LANE_AUTO_MIN = 17500          # BSW_KERNEL_AUTO uses lane bins only above this many eligible seeds (bsw_api.hip)
+LANE_AUTO_MIN = 26000          # BSW_KERNEL_AUTO uses lane bins only from this many eligible seeds PER LAUNCHED SIDE (bsw_api.hip)
 VARIANT_H, VARIANT_M = 0, 1
 
 ERRORS = {0: "BSW_OK", -1: "BSW_E_NODEVICE", -2: "BSW_E_INVAL", -3: "BSW_E_LIMIT", -4: "BSW_E_HIP",
@@ -283,7 +286,7 @@ class BswContext:
     """One GPU context = one of the reference's PE arrays behind its batch manager."""
 
     def __init__(self, device=0, kernel=KERNEL_AUTO, streams=4, pack_threads=4, chunk_tasks=131072, devices=None,
-                 timeout_ms=0):
+                 timeout_ms=0, result_format=RESULT_FULL):
         cfg = np.zeros(1, dtype=CONFIG)
         lib().bsw_default_config(cfg.ctypes.data)
         cfg["device"], cfg["kernel"], cfg["streams"] = device, kernel, streams
@@ -293,6 +296,8 @@ class BswContext:
             cfg["devices"][0, :len(devices)] = devices
         if timeout_ms:
             cfg["timeout_ms"] = timeout_ms
+        cfg["result_format"] = result_format
+        self.out_dtype = PAIR if result_format == RESULT_PAIR else RESULT      # what the submit calls hand back
         h = C.c_void_p()
         rc = lib().bsw_create(cfg.ctypes.data, C.byref(h))
         if rc:
@@ -318,8 +323,8 @@ class BswContext:
     # streaming path: host buffers in, host buffers out
     def submit(self, params, tasks, out=None):
         if out is None:
-            out = np.zeros(len(tasks), dtype=RESULT)
-        assert out.dtype == RESULT and len(out) >= len(tasks)
+            out = np.zeros(len(tasks), dtype=self.out_dtype)
+        assert out.dtype == self.out_dtype and len(out) >= len(tasks)
         self._keep = (params, tasks, out)
         self._chk(lib().bsw_submit(self.handle, params.ctypes.data, tasks.ctypes.data, len(tasks), out.ctypes.data), "bsw_submit")
         return out
@@ -331,8 +336,8 @@ class BswContext:
     def submit_packed(self, params, ptasks, out=None):
         """bsw_submit_packed: `ptasks` from pack_tasks() (sequence pointers address 4-bit packed words)."""
         if out is None:
-            out = np.zeros(len(ptasks), dtype=RESULT)
-        assert out.dtype == RESULT and len(out) >= len(ptasks)
+            out = np.zeros(len(ptasks), dtype=self.out_dtype)
+        assert out.dtype == self.out_dtype and len(out) >= len(ptasks)
         self._keep = (params, ptasks, out)
         self._chk(lib().bsw_submit_packed(self.handle, params.ctypes.data, ptasks.ctypes.data, len(ptasks), out.ctypes.data), "bsw_submit_packed")
         return out
@@ -438,7 +443,8 @@ class BswContext:
     def submit_ref(self, params, ref, rtasks, out=None):
         """Streaming form of extend_ref (finish with wait()): only the reads cross PCIe."""
         if out is None:
-            out = np.zeros(len(rtasks), dtype=RESULT)
+            out = np.zeros(len(rtasks), dtype=self.out_dtype)
+        assert out.dtype == self.out_dtype and len(out) >= len(rtasks)
         self._keep = (params, rtasks, out)
         self._chk(lib().bsw_submit_ref(self.handle, params.ctypes.data, ref, rtasks.ctypes.data, len(rtasks), out.ctypes.data), "bsw_submit_ref")
         return out

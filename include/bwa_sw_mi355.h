@@ -108,6 +108,16 @@ typedef struct bsw_result {
     bsw_ext  left, right;   /* not in the RTL record; for parity checking        */
 } bsw_result;
 
+/* The pair-level record alone: exactly the information of the RTL's 5-word result record R0..R4
+ * (sw_pe_array_proc_element.v:1662-1665,1190-1199) — the first 32 bytes of bsw_result.  A context created with
+ * bsw_config.result_format = BSW_RESULT_PAIR hands THESE back from bsw_submit / bsw_submit_packed / bsw_submit_ref
+ * (the `out` argument then addresses bsw_pair[n], cast to bsw_result *): a third of the bytes over PCIe and out of
+ * the finalize kernel; the per-side bsw_ext records stay in device scratch. */
+typedef struct bsw_pair {
+    uint32_t tag;
+    int32_t  qb, qe, rb, re, score, truesc, w;
+} bsw_pair;
+
 /* One plain ksw_extend2 call (no band retry), for batched single extensions. */
 typedef struct bsw_ext_task {
     const uint8_t *query, *target;
@@ -131,7 +141,11 @@ typedef struct bsw_config {
     int32_t devices[BSW_MAX_DEVICES];
     int32_t timeout_ms;     /* watchdog on every wait for the GPU (def 120000); on expiry the call fails
                                with BSW_E_HIP and the context is dead (every later call fails fast)  */
+    int32_t result_format;  /* BSW_RESULT_FULL (def): bsw_result[n]; BSW_RESULT_PAIR: bsw_pair[n] from the bsw_submit* calls */
 } bsw_config;
+
+#define BSW_RESULT_FULL  0
+#define BSW_RESULT_PAIR  1
 
 #define BSW_KERNEL_AUTO  0  /* per-bin choice (batch manager)                    */
 #define BSW_KERNEL_WAVE  1  /* one wavefront per task, row-synchronous           */

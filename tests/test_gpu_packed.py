@@ -103,3 +103,33 @@ def test_padding_nibbles_of_the_last_word_are_ignored(host, oracle, kernel):
         w[idx] = (w[idx] & keep) | (junk & ~keep)
     with host.BswContext(device=0, kernel=kernel, chunk_tasks=16384) as c:
         assert_same(c.extend_pairs_packed(p, pt), want, tasks)
+
+
+PAIR_FIELDS = ("tag", "qb", "qe", "rb", "re", "score", "truesc", "w")
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_pair_record_format(host, oracle, kernel):
+    """bsw_config.result_format = BSW_RESULT_PAIR: the submit calls hand back the RTL's 5-word record alone (32 of the 96
+    bytes, sw_pe_array_proc_element.v:1662-1665) — the same eight fields, bit for bit, as the full-record run; bytes,
+    packed and device-reference input, registered and pageable result arrays, lane bins with band retries (redo list)
+    and general-kernel classes."""
+    tasks, arena = host.synth_tasks(40000, seed=71, indel_rate=0.02, **{k: v for k, v in MIXED.items() if k != "indel_rate"})
+    long_seeds = _gen.random_seeds(np.random.default_rng(3), 300, qmin=140, qmax=250, h0max=400)       # general-kernel classes
+    lt, la = host.make_tasks(long_seeds)
+    for p in (host.default_params(), host.default_params(w=8, zdrop=0)):                              # w = 8: many band retries
+        want = oracle.pair_batch(p, tasks, nthreads=8)
+        pt, words = host.pack_tasks(tasks)
+        hout = host.HostArena(len(tasks) * host.PAIR.itemsize)
+        with host.BswContext(device=0, kernel=kernel, chunk_tasks=8192, streams=3, result_format=host.RESULT_PAIR) as c:
+            got = c.extend_pairs(p, tasks)
+            assert got.dtype == host.PAIR
+            for f in PAIR_FIELDS:
+                assert (got[f] == want[f]).all(), f
+            gp = c.extend_pairs_packed(p, pt, out=hout.view(host.PAIR, len(tasks)))                   # registered result array: direct DMA
+            assert gp.tobytes() == got.tobytes()
+            gl = c.extend_pairs(p, lt)
+            wl = oracle.pair_batch(p, lt, nthreads=8)
+            for f in PAIR_FIELDS:
+                assert (gl[f] == wl[f]).all(), f
+        hout.free()

@@ -31,7 +31,7 @@ def rebase(tasks, arena, dst_u8, content=None):
 def test_device_binning_matches_the_plan(host, kernel):
     """bsw_bin_* on the GPU must produce the lists bsw_plan_batch promises: same segments, every list a
     permutation of the host replay's, lane sides sorted by (query holds an N, query length descending)."""
-    n = host.LANE_AUTO_MIN + 7000
+    n = 2 * host.LANE_AUTO_MIN + 7000           # both sides are launched: the threshold counts per side
     tasks, arena = host.synth_tasks(n, seed=5, read_len=250, seed_len_min=19, seed_len_max=120, seed_at_start=0,
                                     junk_frac=0.1, n_rate=0.001)
     tasks["h0"][::7] = 300                     # some seeds outside the 8-bit score range
