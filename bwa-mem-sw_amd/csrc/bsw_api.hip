@@ -148,11 +148,13 @@ struct stage_t {
     dbuf<uint32_t> d_order, d_bins;
     dbuf<bsw_result> d_out;
     dbuf<bsw_pair> d_pair;            /* BSW_RESULT_PAIR: the dense 32-byte records that cross PCIe */
+    hbuf<uint64_t> h_blob;            /* small batches: packed sequences | task records | order lists + counters, one DMA */
+    dbuf<uint64_t> d_blob;
     dbuf<bsw_refx> d_desc;
     dbuf<bsw_wireoff> d_woff;
-    void set_pinned(bool on) { h_raw.pinned = h_tasks.pinned = h_roff.pinned = h_out.pinned = h_desc.pinned = h_woff.pinned = on; }
-    void release_host() { h_raw.release(); h_tasks.release(); h_roff.release(); h_out.release(); h_desc.release(); h_woff.release(); }
-    void release_transient_dev() { d_raw.release(); d_roff.release(); d_bins.release(); d_desc.release(); d_woff.release(); }
+    void set_pinned(bool on) { h_raw.pinned = h_tasks.pinned = h_roff.pinned = h_out.pinned = h_desc.pinned = h_woff.pinned = h_blob.pinned = on; }
+    void release_host() { h_raw.release(); h_tasks.release(); h_roff.release(); h_out.release(); h_desc.release(); h_woff.release(); h_blob.release(); }
+    void release_transient_dev() { d_raw.release(); d_roff.release(); d_bins.release(); d_desc.release(); d_woff.release(); d_blob.release(); }
     void release()
     {
         release_host();
@@ -1443,11 +1445,70 @@ extern "C" int bsw_batch_order(bsw_ctx *ctx, const bsw_dev_batch *b, uint32_t *o
     return BSW_OK;
 }
 
+/* ---- a HANDFUL of seeds (the scalar ksw_extend2 entry points, tiny batches): no device-side staging at all.
+ * The batch path's pack kernel, two memsets and three binning kernels are seven launches of ~6 us each in front of the DP
+ * kernel (profiles/r3/scalar_call_timeline.txt: 58 us before the extension starts).  For up to SMALL_BATCH seeds the host
+ * packs the bases (a few hundred bytes), sorts the seeds into their general-kernel classes, and ONE DMA carries
+ * sequences, task records, order lists and zeroed counters; then the DP kernel(s), then the result copy. ---- */
+#define SMALL_BATCH 256
+static int run_small(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params &p, const bsw_dparams &dp,
+                     const bsw_task *tasks, size_t n, bsw_result *out)
+{
+    std::vector<bsw_dtask> dt(n);
+    std::vector<bsw_rawoff> ro(n);
+    chunk_info ci;
+    int rc = prepare_chunk(e, &p, BSW_KERNEL_WAVE, tasks, n, false, dt.data(), ro.data(), ci);   /* validation, word offsets, class counts */
+    if (rc) return rc;
+    const batch_plan &pl = ci.plan;
+    const size_t n_ctr = 2 + BSW_MAX_WAVE_CLASSES;
+    const size_t w_seq = ci.words + 4, w_tasks = (n * sizeof(bsw_dtask) + 7) / 8, w_order = ((pl.order_len + n_ctr) * sizeof(uint32_t) + 7) / 8;
+    const size_t total = w_seq + w_tasks + w_order;
+    hipError_t he;
+    if ((he = st.h_blob.reserve(total)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    if ((he = st.d_blob.reserve(total)) != hipSuccess || (he = st.d_out.reserve(n + 1)) != hipSuccess) return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    uint64_t *hb = st.h_blob.p;
+    memset(hb, 0, total * sizeof(uint64_t));
+    for (size_t i = 0; i < n; ++i) {                 /* the device sequence format, packed here */
+        const bsw_task &t = tasks[i];
+        const bsw_dtask &d = dt[i];
+        if (t.lqlen) { bsw_pack_bases(t.lquery, t.lqlen, hb + d.lq_off); if (t.ltlen) bsw_pack_bases(t.ltarget, t.ltlen, hb + d.lt_off); }
+        if (t.rqlen) { bsw_pack_bases(t.rquery, t.rqlen, hb + d.rq_off); if (t.rtlen) bsw_pack_bases(t.rtarget, t.rtlen, hb + d.rt_off); }
+    }
+    memcpy(hb + w_seq, dt.data(), n * sizeof(bsw_dtask));
+    uint32_t *ho = (uint32_t *)(hb + w_seq + w_tasks);
+    {
+        uint32_t cur[BSW_MAX_WAVE_CLASSES];
+        for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) cur[c] = pl.wave_start[c];
+        for (size_t i = 0; i < n; ++i) ho[cur[bsw_wave_class_of(&ci.bp, std::max(tasks[i].lqlen, tasks[i].rqlen))]++] = (uint32_t)i;
+    }
+    HIPCHK(e, hipMemcpyAsync(st.d_blob.p, hb, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    const uint64_t *d_seq = st.d_blob.p;
+    const bsw_dtask *d_tasks = (const bsw_dtask *)(st.d_blob.p + w_seq);
+    uint32_t *d_order = (uint32_t *)(st.d_blob.p + w_seq + w_tasks), *ctr = d_order + pl.order_len;   /* (zero: copied that way) */
+    const int nc = bsw::wave_class_count();
+    for (int c = 0; c < nc; ++c) {
+        const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
+        if (cnt) HIPCHK(e, bsw::launch_wave(c, p.variant, dp, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, ctr + 1 + c, st.d_out.p, s));
+    }
+    const bool out_direct = is_registered(out, n * sizeof(bsw_result));
+    if (!out_direct && (he = st.h_out.reserve(n)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    HIPCHK(e, hipMemcpyAsync(out_direct ? out : st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
+    rc = sync_stream(ctx, e, s, ev);
+    if (rc) return rc;
+    if (!out_direct) memcpy(out, st.h_out.p, n * sizeof(bsw_result));
+    return BSW_OK;
+}
+
 /* ---- one synchronous chunk through a staging slot (small batches; the streaming workers use the same steps) ---- */
 static int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params &p, const bsw_dparams &dp,
                      const bsw_task *tasks, size_t n, bsw_result *out, int gather_threads, const gate_turn *turn = nullptr, bool packed = false)
 {
     if (n == 0) return BSW_OK;
+    {
+        static const bool nosmall = getenv("BSW_NO_SMALL") != nullptr;     /* (measurements) */
+        if (!nosmall && n <= SMALL_BATCH && !packed && !turn && ctx->cfg.kernel != BSW_KERNEL_LANE && ctx->cfg.result_format == BSW_RESULT_FULL)
+            return run_small(ctx, e, st, s, ev, p, dp, tasks, n, out);
+    }
     static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = dbg ? tnow() : 0;
