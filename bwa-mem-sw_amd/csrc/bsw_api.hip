@@ -1465,7 +1465,7 @@ static int run_small(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent
     const size_t total = w_seq + w_tasks + w_order;
     hipError_t he;
     if ((he = st.h_blob.reserve(total)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
-    if ((he = st.d_blob.reserve(total)) != hipSuccess || (he = st.d_out.reserve(n + 1)) != hipSuccess) return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    if ((he = st.d_blob.reserve(total)) != hipSuccess) return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
     uint64_t *hb = st.h_blob.p;
     memset(hb, 0, total * sizeof(uint64_t));
     for (size_t i = 0; i < n; ++i) {                 /* the device sequence format, packed here */
@@ -1485,14 +1485,16 @@ static int run_small(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent
     const uint64_t *d_seq = st.d_blob.p;
     const bsw_dtask *d_tasks = (const bsw_dtask *)(st.d_blob.p + w_seq);
     uint32_t *d_order = (uint32_t *)(st.d_blob.p + w_seq + w_tasks), *ctr = d_order + pl.order_len;   /* (zero: copied that way) */
+    /* the result records go straight to pinned (device-visible) host memory: a few 96-byte stores over the link instead of
+     * a device buffer, a copy and its launch */
+    const bool out_direct = is_registered(out, n * sizeof(bsw_result));
+    if (!out_direct && (he = st.h_out.reserve(n)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    bsw_result *res = out_direct ? out : st.h_out.p;
     const int nc = bsw::wave_class_count();
     for (int c = 0; c < nc; ++c) {
         const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
-        if (cnt) HIPCHK(e, bsw::launch_wave(c, p.variant, dp, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, ctr + 1 + c, st.d_out.p, s));
+        if (cnt) HIPCHK(e, bsw::launch_wave(c, p.variant, dp, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, ctr + 1 + c, res, s));
     }
-    const bool out_direct = is_registered(out, n * sizeof(bsw_result));
-    if (!out_direct && (he = st.h_out.reserve(n)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
-    HIPCHK(e, hipMemcpyAsync(out_direct ? out : st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
     rc = sync_stream(ctx, e, s, ev);
     if (rc) return rc;
     if (!out_direct) memcpy(out, st.h_out.p, n * sizeof(bsw_result));
@@ -1566,7 +1568,7 @@ static std::vector<std::vector<chunk_span>> plan_chunks(size_t n, size_t chunk, 
     for (size_t base = 0; base < n; base += per, ++c) {
         const size_t cnt = std::min(per, n - base);
         std::vector<chunk_span> &v = out[c % G];
-        if (v.empty() && cnt >= 6 * (size_t)LANE_AUTO_MIN + 1024) {     /* (either part still far above the lane kernels' minimum, both sides launched) */
+        if (v.empty() && cnt >= 3 * (size_t)LANE_AUTO_MIN + 1024) {     /* (the smaller part still holds a lane launch's worth of one-sided seeds; two-sided ones take the general kernels there, at the same cost) */
             const size_t h = ((cnt / 3) + 255) & ~(size_t)255;
             v.push_back(chunk_span{base, h});
             v.push_back(chunk_span{base + h, cnt - h});
