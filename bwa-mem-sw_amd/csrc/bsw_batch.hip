@@ -1,0 +1,1169 @@
+/*
+ * bsw_batch.hip — the batch manager: host pass over a chunk (validate, lay out, count per kernel class), device staging (DMA, pack, bin), kernel launches, batch plan export, device-resident batches and reference, the small-batch path, the streaming slot pipeline behind bsw_submit / bsw_submit_packed / bsw_submit_ref (batch_manager.v:358-739, tbb.v, rbb.v)
+ * (part of the host side of libbwasw_mi355.so; shared types and the functions that cross files: bsw_internal.h)
+ */
+#include "bsw_internal.h"
+
+/* lane kernel needs a bwa-style matrix (bwa_fill_scmat): a on the diagonal, one mismatch score off it,
+ * one score for every pair that involves an N */
+static bool lane_matrix_ok(const bsw_params *p)
+{
+    const int a = p->mat[0], nb = p->mat[1], nn = p->mat[24];
+    if (a <= 0 || nb > 0 || nn > a) return false;
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 5; ++j)
+            if (p->mat[i * 5 + j] != ((i == 4 || j == 4) ? nn : (i == j ? a : nb))) return false;
+    return true;
+}
+
+BSW_LOCAL size_t order_capacity(size_t n) { return 4 * n + 16; }   /* upper bound of plan.order_len + the 2 + BSW_MAX_WAVE_CLASSES counters behind it */
+
+/* ---- host pass over a chunk: validate, lay out, count per class ------------------------------ */
+
+
+BSW_LOCAL int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams &bp)
+{
+    memset(&bp, 0, sizeof(bp));
+    bp.a = p->mat[0];
+    bp.b = p->mat[1] < 0 ? -p->mat[1] : 0;
+    bp.n_wave = bsw::wave_class_count();
+    bp.n_lane = bsw::lane_class_count();
+    if (bp.n_wave > BSW_MAX_WAVE_CLASSES || bp.n_lane > BSW_MAX_LANE_CLASSES) return fail(e, BSW_E_LIMIT, "class table too large");
+    for (int c = 0; c < bp.n_wave; ++c) bp.wave_cols[c] = bsw::wave_class_cols(c);
+    for (int c = 0; c < bp.n_lane; ++c) {
+        bp.lane_cols[c] = bsw::lane_class_cols(c);
+        bp.lane_bits[c] = bsw::lane_class_bits(c);
+        if (bp.lane_cols[c] > BSW_LANE_QBINS) return fail(e, BSW_E_LIMIT, "lane class %d has %d columns (> %d)", c, bp.lane_cols[c], BSW_LANE_QBINS);
+        if (bp.lane_bits[c] == 8) bp.cols8 = std::max(bp.cols8, bp.lane_cols[c]);
+        else bp.cols16 = std::max(bp.cols16, bp.lane_cols[c]);
+    }
+    bp.lane_on = kern != BSW_KERNEL_WAVE && lane_matrix_ok(p);
+    return BSW_OK;
+}
+
+/* The narrow lane class (72 columns, three waves per SIMD) is its own launch per side.  It pays where a chunk holds NO
+ * wider 8-bit sides — reads with long exact seeds, whose flanks are all short: the 72 / 64 / 40 / 16-column single bins run
+ * 12 / 13 / 16 / 24 % faster there (gpurun_out/r4b, r4d).  Beside wider sides it LOSES, whatever their share: one launch
+ * per class means the short waves no longer fill the tail of the long ones (longest-first order inside ONE launch is what
+ * packs a side onto the wave slots; every launch has a floor of one wave's whole lifetime), and a 72-column wave next to a
+ * 136-column one gets no third wave (256 + 168 registers).  Synthetic PE mixed bins (42 % of the lane work in short
+ * sides): 2 350 -> 2 080 GCUPS with the launches one after the other, 2 190 on forked streams with priorities; still
+ * -15 % with 97 % of the work in short sides (gpurun_out/r4c, r4h, r4i).  So the host decides per chunk: the class is
+ * used when its sides hold at least NARROW_MIN_SHARE of the chunk's 8-bit lane work (work of a side ~ its query length:
+ * rows ~ 2 qlen, live band ~ constant), otherwise it is folded into the next class (lane_cols = 0: the device's
+ * bsw_side_lane_class skips it).  BSW_NARROW_SHARE overrides the threshold (0: always, 2: never). */
+#define NARROW_MIN_SHARE 1.0
+BSW_LOCAL bool narrow_foldable(const bsw_binparams &bp)
+{
+    return bp.n_lane >= 2 && bp.lane_bits[0] == bp.lane_bits[1] && bp.lane_cols[0] > 0 && bp.lane_cols[0] < bp.lane_cols[1];
+}
+static double narrow_min_share()
+{
+    static const double v = getenv("BSW_NARROW_SHARE") ? atof(getenv("BSW_NARROW_SHARE")) : NARROW_MIN_SHARE;
+    return v;
+}
+/* fold class 0 into class 1: counts, dependency bits, and the class table the device sorts with */
+BSW_LOCAL void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_t *dep)
+{
+    cl[1] += cl[0]; cr[1] += cr[0]; cl[0] = cr[0] = 0;
+    if (dep) {
+        for (int lc = 0; lc < BSW_MAX_LANE_CLASSES; ++lc)
+            if (dep[lc] & 1u) dep[lc] = (uint8_t)((dep[lc] & ~1u) | 2u);
+        dep[1] |= dep[0];
+        dep[0] = 0;
+    }
+    bp.lane_cols[0] = 0;
+}
+
+/* tasks[0..n) -> dt[0..n) (device task records), ro[0..n) (gather layout of the raw bytes), class counts -> plan */
+/* One pass over the seeds of a chunk: validate, lay the 4-bit arena out, count the kernel classes.  `src(i, tmp, rc)`
+ * hands out seed i as a bsw_task (a pointer into the caller's array, or `tmp` filled on the fly — bsw_submit_ref never
+ * materialises its tasks); NULL = error rc.  rawoff gets the low 32 bits of every host pointer: when the chunk goes
+ * out by direct DMA the pack kernel subtracts raw_bias, otherwise gather_offsets() replaces them. */
+template <class Src>
+static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, size_t n, bool dev_targets,
+                           bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left, bool packed = false)
+{
+    ci.packed = packed;
+    const int mx = mat_max(p->mat);
+    int rc = fill_binparams(e, p, kern, ci.bp);
+    if (rc) return rc;
+    bsw_binparams &bp = ci.bp;
+    uint64_t acc = 0, accb = 0;
+    const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
+    uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0};
+    uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0;
+    uint8_t dep[BSW_MAX_LANE_CLASSES] = {0};
+    uint64_t lane_work[BSW_MAX_LANE_CLASSES] = {0};          /* sum of query lengths per lane class (narrow_fold) */
+    auto span = [&](const uint8_t *s, int len) {
+        if (len > 0) { if (s < lo) lo = s; if (s + len > hi) hi = s + len; }
+    };
+    bsw_task tmp;
+    /* H5/H6 per query length, computed once per length and chunk (two integer divisions each: with them per seed they were
+     * most of this pass) */
+    std::vector<uint16_t> gl5((size_t)BSW_MAX_QLEN + 1, 0), gl3((size_t)BSW_MAX_QLEN + 1, 0);
+    const auto glim = [&](std::vector<uint16_t> &tab, int qlen, int clip) -> uint16_t {
+        uint16_t &v = tab[(size_t)qlen];
+        if (!v) v = (uint16_t)gap_limit(p, mx, qlen, clip);       /* >= 1: zero means not computed yet */
+        return v;
+    };
+    /* packed input: whether the words can be DMA'd as they lie (registered, compact arena) decides the word offsets, and
+     * the staging records are write-combined memory that must not be read back — so the arena span is found first */
+    bool packed_direct = false;
+    const uint8_t *plo = nullptr;
+    if (packed) {
+        const uint8_t *l0 = (const uint8_t *)UINTPTR_MAX, *h0 = nullptr;
+        uint64_t sum = 0;
+        auto sp = [&](const uint8_t *s, int len) {
+            if (len > 0 && s) { const size_t nb = 8 * nwords(len); sum += nb; if (s < l0) l0 = s; if (s + nb > h0) h0 = s + nb; }
+        };
+        for (size_t i = 0; i < n; ++i) {
+            const bsw_task *tp = src(i, tmp, rc);
+            if (!tp) return rc;
+            if (tp->lqlen > 0) { sp(tp->lquery, tp->lqlen); sp(tp->ltarget, tp->ltlen); }
+            if (tp->rqlen > 0) { sp(tp->rquery, tp->rqlen); sp(tp->rtarget, tp->rtlen); }
+        }
+        const size_t spb = h0 ? (size_t)(h0 - l0) : 0;
+        packed_direct = spb > 0 && spb < (1ull << 32) - RAW_SLACK && spb <= 2 * sum + (1u << 20) && is_registered(l0, spb);
+        plo = l0;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_task *tp = src(i, tmp, rc);
+        if (!tp) return rc;
+        const bsw_task &t = *tp;
+        if (t.lqlen < 0 || t.rqlen < 0 || t.ltlen < 0 || t.rtlen < 0)
+            return fail(e, BSW_E_INVAL, "task %zu: negative length", i);
+        if (t.lqlen > BSW_MAX_QLEN || t.rqlen > BSW_MAX_QLEN || t.ltlen > BSW_MAX_TLEN || t.rtlen > BSW_MAX_TLEN)
+            return fail(e, BSW_E_LIMIT, "task %zu: length beyond BSW_MAX_QLEN/BSW_MAX_TLEN", i);
+        if (t.h0 <= 0) return fail(e, BSW_E_INVAL, "task %zu: h0 must be > 0", i);
+        if ((int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * mx >= BSW_MAX_SCORE)
+            return fail(e, BSW_E_LIMIT, "task %zu: score range beyond BSW_MAX_SCORE", i);
+        if ((t.lqlen && (!t.lquery || (t.ltlen && !t.ltarget && !dev_targets))) ||
+            (t.rqlen && (!t.rquery || (t.rtlen && !t.rtarget && !dev_targets))))
+            return fail(e, BSW_E_INVAL, "task %zu: NULL sequence pointer", i);
+        if (t.wlim_l < 0 || t.wlim_r < 0) return fail(e, BSW_E_INVAL, "task %zu: negative wlim", i);
+        bsw_dtask d;                                /* built here, stored once: dt[] is write-combined staging */
+        bsw_rawoff r;
+        memset(&d, 0, sizeof(d));
+        memset(&r, 0, sizeof(r));
+        if (packed) {
+            /* 16 bases per uint64 already (base k in bits [4k, 4k+3], codes 0-3 = ACGT, 4-7 = N), every sequence on an
+             * 8-byte boundary: the spans are whole words, rawoff keeps the pointers' low bits until the arena base is known */
+            if ((t.lqlen && (((uintptr_t)t.lquery | (t.ltlen ? (uintptr_t)t.ltarget : 0)) & 7)) ||
+                (t.rqlen && (((uintptr_t)t.rquery | (t.rtlen ? (uintptr_t)t.rtarget : 0)) & 7)))
+                return fail(e, BSW_E_INVAL, "task %zu: packed sequences must start on 8-byte boundaries", i);
+            /* direct: the registered arena IS the device's seq buffer, word offsets relative to its lowest word (an empty
+             * target takes its query's offset: word 0 of a target may be read even when no row is) */
+            if (t.lqlen) {
+                d.lq_off = packed_direct ? (uint32_t)((t.lquery - plo) >> 3) : (uint32_t)acc;
+                acc += nwords(t.lqlen);
+                d.lt_off = packed_direct ? (uint32_t)(((t.ltlen ? t.ltarget : t.lquery) - plo) >> 3) : (uint32_t)acc;
+                acc += nwords(t.ltlen);
+                accb += 8ull * (nwords(t.lqlen) + nwords(t.ltlen));
+                span(t.lquery, 8 * (int)nwords(t.lqlen)); span(t.ltarget, 8 * (int)nwords(t.ltlen));
+            }
+            if (t.rqlen) {
+                d.rq_off = packed_direct ? (uint32_t)((t.rquery - plo) >> 3) : (uint32_t)acc;
+                acc += nwords(t.rqlen);
+                d.rt_off = packed_direct ? (uint32_t)(((t.rtlen ? t.rtarget : t.rquery) - plo) >> 3) : (uint32_t)acc;
+                acc += nwords(t.rtlen);
+                accb += 8ull * (nwords(t.rqlen) + nwords(t.rtlen));
+                span(t.rquery, 8 * (int)nwords(t.rqlen)); span(t.rtarget, 8 * (int)nwords(t.rtlen));
+            }
+        } else {
+        if (t.lqlen) {
+            d.lq_off = (uint32_t)acc; acc += nwords(t.lqlen);
+            d.lt_off = (uint32_t)acc; acc += nwords(t.ltlen);
+            r.lq = (uint32_t)(uintptr_t)t.lquery; accb += (uint64_t)t.lqlen;
+            span(rev_left ? t.lquery - (t.lqlen - 1) : t.lquery, t.lqlen);    /* rev_left: lquery points at the LAST base, read backwards */
+            if (!dev_targets) { r.lt = (uint32_t)(uintptr_t)t.ltarget; accb += (uint64_t)t.ltlen; span(t.ltarget, t.ltlen); }
+        }
+        if (t.rqlen) {
+            d.rq_off = (uint32_t)acc; acc += nwords(t.rqlen);
+            d.rt_off = (uint32_t)acc; acc += nwords(t.rtlen);
+            r.rq = (uint32_t)(uintptr_t)t.rquery; accb += (uint64_t)t.rqlen;
+            span(t.rquery, t.rqlen);
+            if (!dev_targets) { r.rt = (uint32_t)(uintptr_t)t.rtarget; accb += (uint64_t)t.rtlen; span(t.rtarget, t.rtlen); }
+        }
+        }
+        d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
+        d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
+        /* H5/H6: host-supplied band limits win over the library's formula (proc_element.v:925,933) */
+        d.wlim_l = (uint16_t)(t.wlim_l > 0 ? std::min(t.wlim_l, 65535) : glim(gl5, t.lqlen, p->pen_clip5));
+        d.wlim_r = (uint16_t)(t.wlim_r > 0 ? std::min(t.wlim_r, 65535) : glim(gl3, t.rqlen, p->pen_clip3));
+        d.h0 = t.h0; d.init_score = t.init_score; d.qbeg = t.qbeg; d.tag = t.tag;
+        dt[i] = d;
+        if (!packed) ro[i] = r;                     /* (packed input has no byte offsets) */
+        /* class counts (the device sorts with the same functions) */
+        const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
+        const int wc = bsw_wave_class_of(&bp, qm);
+        if (wc < 0) return fail(e, BSW_E_LIMIT, "task %zu: no kernel class", i);
+        ++cw_all[wc];
+        const int bits = bsw_seed_lane_bits(&bp, t.lqlen, t.rqlen, t.h0);
+        if (!bits) ++cw[wc];
+        else {
+            ++n_lane;
+            int lc = -1;
+            if (t.lqlen) {
+                const int c = lc = bsw_side_lane_class(&bp, bits, t.lqlen);
+                if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i);
+                ++cl[c];
+                lane_work[c] += (uint64_t)t.lqlen;
+            }
+            if (t.rqlen) {
+                const int c = bsw_side_lane_class(&bp, bits, t.rqlen);
+                if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i);
+                ++cr[c];
+                lane_work[c] += (uint64_t)t.rqlen;
+                if (lc >= 0) dep[lc] |= (uint8_t)(1u << c);
+            }
+        }
+    }
+    if (acc >= (1ull << 32)) return fail(e, BSW_E_LIMIT, "batch sequence arena beyond 2^32 words; split the batch");
+    if (accb >= (1ull << 32) - RAW_SLACK) return fail(e, BSW_E_LIMIT, "batch holds more than 4 GiB of bases; split the batch");
+    if (kern == BSW_KERNEL_AUTO && !lane_bins_pay(n_lane, cl, cr)) bp.lane_on = 0;
+    if (bp.lane_on && narrow_foldable(bp)) {
+        uint64_t all8 = 0;
+        for (int c = 0; c < bp.n_lane; ++c) if (bp.lane_bits[c] == bp.lane_bits[0]) all8 += lane_work[c];
+        if ((double)lane_work[0] < narrow_min_share() * (double)all8) narrow_fold(bp, cl, cr, dep);
+    }
+    if (!bp.lane_on) {
+        memcpy(cw, cw_all, sizeof(cw));
+        memset(cl, 0, sizeof(cl));
+        memset(cr, 0, sizeof(cr));
+        n_lane = 0;
+    }
+    batch_plan &pl = ci.plan;
+    pl = batch_plan();
+    for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) pl.wave_start[c + 1] = pl.wave_start[c] + cw[c];
+    uint32_t cur = pl.wave_start[BSW_MAX_WAVE_CLASSES];
+    pl.lane_all_off = cur;
+    pl.lane_all_cnt = n_lane;
+    cur += n_lane;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { pl.laneL_off[c] = cur; cur += cl[c]; }
+    pl.laneL_off[BSW_MAX_LANE_CLASSES] = cur;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { pl.laneR_off[c] = cur; cur += cr[c]; }
+    pl.laneR_off[BSW_MAX_LANE_CLASSES] = cur;
+    pl.redo_off = cur;
+    pl.order_len = cur + n_lane;
+    pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
+    memcpy(pl.dep, dep, sizeof(pl.dep));
+    memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
+    bp.lane_all_off = pl.lane_all_off;
+    memcpy(bp.laneL_off, pl.laneL_off, sizeof(bp.laneL_off));
+    memcpy(bp.laneR_off, pl.laneR_off, sizeof(bp.laneR_off));
+    ci.words = (size_t)acc;
+    ci.sum_len = (size_t)accb;
+    ci.lo = hi ? lo : nullptr;
+    ci.hi = hi;
+    /* DMA the caller's arena as it is when it is registered memory and not much larger than what it holds */
+    const size_t spanb = hi ? (size_t)(hi - lo) : 0;
+    ci.direct = spanb > 0 && spanb < (1ull << 32) - RAW_SLACK && spanb <= 2 * ci.sum_len + (1u << 20) && is_registered(lo, spanb);
+    ci.rev_left = rev_left && ci.direct;            /* the gather path mirrors the left queries while copying */
+    ci.raw_bias = ci.direct ? (uint32_t)(uintptr_t)lo : 0u;
+    {
+        static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+        if (dbg) fprintf(stderr, "[bsw] chunk n=%zu: %s%s, span %zu B for %zu B referenced\n", n, packed ? "packed " : "", ci.direct ? "direct DMA" : "gather", spanb, ci.sum_len);
+    }
+    if (packed) {
+        ci.direct = packed_direct;
+        if (packed_direct) ci.words = spanb >> 3;
+    }
+    return BSW_OK;
+}
+
+/* the gather path: rawoff = where gather_raw puts each sequence in the pinned staging arena (back to back) */
+static void gather_offsets(const bsw_task *tasks, size_t n, bool dev_targets, bsw_rawoff *ro)
+{
+    uint64_t accb = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_task &t = tasks[i];
+        bsw_rawoff &r = ro[i];
+        memset(&r, 0, sizeof(r));
+        if (t.lqlen) {
+            r.lq = (uint32_t)accb; accb += (uint64_t)t.lqlen;
+            if (!dev_targets) { r.lt = (uint32_t)accb; accb += (uint64_t)t.ltlen; }
+        }
+        if (t.rqlen) {
+            r.rq = (uint32_t)accb; accb += (uint64_t)t.rqlen;
+            if (!dev_targets) { r.rt = (uint32_t)accb; accb += (uint64_t)t.rtlen; }
+        }
+    }
+}
+
+static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task *tasks, size_t n, bool dev_targets,
+                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left = false, bool packed = false)
+{
+    int rc = prepare_chunk_t(e, p, kern, [tasks](size_t i, bsw_task &, int &) { return tasks + i; }, n, dev_targets, dt, ro, ci, rev_left, packed);
+    if (!rc && !ci.direct && !packed) gather_offsets(tasks, n, dev_targets, ro);
+    return rc;
+}
+
+/* packed sequences that are not in registered memory: their words go to the pinned staging arena in seq layout */
+static void gather_packed(const bsw_task *tasks, const bsw_dtask *dt, size_t n, uint64_t *dst)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const bsw_task &t = tasks[i];
+        const bsw_dtask &d = dt[i];
+        if (t.lqlen) {
+            memcpy(dst + d.lq_off, t.lquery, 8 * nwords(t.lqlen));
+            if (t.ltlen) memcpy(dst + d.lt_off, t.ltarget, 8 * nwords(t.ltlen));
+        }
+        if (t.rqlen) {
+            memcpy(dst + d.rq_off, t.rquery, 8 * nwords(t.rqlen));
+            if (t.rtlen) memcpy(dst + d.rt_off, t.rtarget, 8 * nwords(t.rtlen));
+        }
+    }
+}
+
+/* copy the sequences of tasks[0..n) into the pinned staging arena laid out by prepare_chunk */
+static void gather_raw(const bsw_task *tasks, const bsw_rawoff *ro, size_t n, bool dev_targets, uint8_t *dst, int threads, bool rev_left = false)
+{
+    auto work = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const bsw_task &t = tasks[i];
+            const bsw_rawoff &r = ro[i];
+            if (t.lqlen) {
+                if (rev_left) for (int k = 0; k < t.lqlen; ++k) dst[r.lq + (uint32_t)k] = *(t.lquery - k);
+                else memcpy(dst + r.lq, t.lquery, (size_t)t.lqlen);
+                if (!dev_targets && t.ltlen) memcpy(dst + r.lt, t.ltarget, (size_t)t.ltlen);
+            }
+            if (t.rqlen) {
+                memcpy(dst + r.rq, t.rquery, (size_t)t.rqlen);
+                if (!dev_targets && t.rtlen) memcpy(dst + r.rt, t.rtarget, (size_t)t.rtlen);
+            }
+        }
+    };
+    if (threads <= 1 || n < 4096) { work(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+    for (int k = 1; k < threads; ++k) {
+        const size_t lo = per * (size_t)k, hi = std::min(n, lo + per);
+        if (lo < hi) th.emplace_back(work, lo, hi);
+    }
+    work(0, std::min(n, per));
+    for (auto &t : th) t.join();
+}
+
+/* ---- device side of a chunk: DMA, pack, (fetch), bin, and optionally the DP kernels ---------- */
+BSW_LOCAL const fork_t *fork_for(const bsw_ctx *ctx, hipStream_t s)
+{
+    for (const dev_state &d : ctx->devs)
+        for (size_t k = 0; k < d.streams.size(); ++k)
+            if (d.streams[k] == s) return k < d.forks.size() && d.forks[k].ok ? &d.forks[k] : nullptr;
+    return nullptr;
+}
+
+BSW_LOCAL int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
+                         uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches,
+                         const fork_t *fk, bsw_pair *d_pair)
+{
+    const int nc = bsw::wave_class_count();
+    /* device words behind the order lists: [0] the redo list's length, [1 + c] the work counter of wave class c's launch,
+     * [1 + BSW_MAX_WAVE_CLASSES] the redo launch's — zeroed here, on the stream, before anything counts in them */
+    uint32_t *redo_cnt = d_order + pl.order_len;
+    HIPCHK(e, hipMemsetAsync(redo_cnt, 0, (2 + BSW_MAX_WAVE_CLASSES) * sizeof(uint32_t), s));
+    for (int c = 0; c < nc; ++c) {
+        const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
+        if (!cnt) continue;
+        HIPCHK(e, bsw::launch_wave(c, variant, P, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, redo_cnt + 1 + c, d_out, s));
+        if (d_pair) HIPCHK(e, bsw::launch_pairs_from_results(d_order + pl.wave_start[c], cnt, nullptr, d_out, d_pair, s));
+        if (launches) ++*launches;
+    }
+    if (pl.lane_all_cnt) {
+        const int nlc = bsw::lane_class_count();
+        /* The classes of a side side by side: the k-th non-empty class of a side (widest first: its waves run longest) goes
+         * to stream k — the slot stream, then the auxiliary ones.  A right-side launch waits for exactly the left-side
+         * launches that hold one of its seeds (plan.dep); streams are in-order, so only other streams' launches need an event. */
+        hipStream_t lstream[BSW_MAX_LANE_CLASSES] = {nullptr}, rstream[BSW_MAX_LANE_CLASSES] = {nullptr};
+        int nl = 0, nr = 0;
+        for (int c = nlc - 1; c >= 0; --c) {
+            if (pl.laneL_off[c + 1] - pl.laneL_off[c]) { lstream[c] = (fk && nl > 0 && nl <= BSW_FORK_AUX) ? fk->aux[nl - 1] : s; ++nl; }
+            if (pl.laneR_off[c + 1] - pl.laneR_off[c]) { rstream[c] = (fk && nr > 0 && nr <= BSW_FORK_AUX) ? fk->aux[nr - 1] : s; ++nr; }
+        }
+        const bool forked = fk && (nl > 1 || nr > 1);
+        if (forked) {
+            HIPCHK(e, hipEventRecord(fk->ev_fork, s));                 /* everything queued on s so far (input DMAs, pack, bins) */
+            for (int a = 0; a < BSW_FORK_AUX; ++a) HIPCHK(e, hipStreamWaitEvent(fk->aux[a], fk->ev_fork, 0));
+        }
+        for (int c = nlc - 1; c >= 0; --c) {
+            const uint32_t cnt = pl.laneL_off[c + 1] - pl.laneL_off[c];
+            if (!cnt) continue;
+            HIPCHK(e, bsw::launch_lane(c, variant, P, 0, d_seq, d_tasks, d_order + pl.laneL_off[c], cnt, d_out, lstream[c]));
+            if (forked) HIPCHK(e, hipEventRecord(fk->ev_left[c], lstream[c]));
+            if (launches) ++*launches;
+        }
+        for (int c = nlc - 1; c >= 0; --c) {
+            const uint32_t cnt = pl.laneR_off[c + 1] - pl.laneR_off[c];
+            if (!cnt) continue;
+            if (forked)
+                for (int lc = 0; lc < nlc; ++lc)
+                    if (lstream[lc] && lstream[lc] != rstream[c] && ((pl.dep[lc] >> c) & 1)) HIPCHK(e, hipStreamWaitEvent(rstream[c], fk->ev_left[lc], 0));
+            HIPCHK(e, bsw::launch_lane(c, variant, P, 1, d_seq, d_tasks, d_order + pl.laneR_off[c], cnt, d_out, rstream[c]));
+            if (forked && rstream[c] != s) HIPCHK(e, hipEventRecord(fk->ev_right[c], rstream[c]));
+            if (launches) ++*launches;
+        }
+        if (forked) {                                                   /* join: the slot stream waits for whatever ran elsewhere */
+            for (int c = 0; c < nlc; ++c) {
+                if (lstream[c] && lstream[c] != s) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_left[c], 0));
+                if (rstream[c] && rstream[c] != s) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_right[c], 0));
+            }
+        }
+        HIPCHK(e, bsw::launch_finalize(P, d_tasks, d_order + pl.lane_all_off, pl.lane_all_cnt, d_out,
+                                       d_order + pl.redo_off, redo_cnt, d_pair, s));
+        /* seeds whose first band try was not final: recompute from scratch, one wavefront each */
+        HIPCHK(e, bsw::launch_wave(pl.redo_cls, variant, P, d_seq, d_tasks, d_order + pl.redo_off, pl.lane_all_cnt,
+                                   redo_cnt, redo_cnt + 1 + BSW_MAX_WAVE_CLASSES, d_out, s));
+        if (d_pair) HIPCHK(e, bsw::launch_pairs_from_results(d_order + pl.redo_off, pl.lane_all_cnt, redo_cnt, d_out, d_pair, s));
+        if (launches) *launches += 2;
+    }
+    return BSW_OK;
+}
+
+/* the raw bytes and the task records are in st.h_* (or the caller's registered arena): move them, pack, bin */
+
+
+static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &ci, size_t n, bool dev_targets,
+                        const bsw_ref *ref, uint64_t *h2d_bytes, const gate_turn *turn = nullptr, size_t dev_index = 0)
+{
+    const size_t n_desc = ref ? n : 0;              /* st.h_desc: one bsw_refx per seed */
+    const size_t rawb = ci.packed ? 0 : (ci.direct ? (size_t)(ci.hi - ci.lo) : ci.sum_len);
+    hipError_t he;
+    if ((he = st.d_raw.reserve(rawb + RAW_FRONT + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve(ci.words + 4)) != hipSuccess ||
+        (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_roff.reserve(n + 1)) != hipSuccess ||
+        (he = st.d_order.reserve(order_capacity(n))) != hipSuccess || (he = st.d_bins.reserve(BSW_BIN_WORDS)) != hipSuccess ||
+        (he = st.d_out.reserve(n + 1)) != hipSuccess || (n_desc && (he = st.d_desc.reserve(n_desc)) != hipSuccess))
+        return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    {
+        std::unique_lock<std::mutex> lk;
+        if (turn) {
+            lk = std::unique_lock<std::mutex>(turn->gate->mu);
+            turn->gate->cv.wait(lk, [&]() { return turn->gate->next == turn->seq || *turn->abort_flag; });
+            if (*turn->abort_flag) return fail(e, BSW_E_HIP, "aborted: another chunk failed");
+            if (turn->gate->last) HIPCHK(e, hipStreamWaitEvent(s, turn->gate->last, 0));
+        }
+        hipError_t ce = hipSuccess;
+        if (ci.packed) {               /* the words are the device layout already: they land in `seq`, nothing is packed */
+            if (ci.words) ce = hipMemcpyAsync(st.d_seq.p, ci.direct ? (const void *)ci.lo : (const void *)st.h_raw.p, ci.words * 8, hipMemcpyHostToDevice, s);
+        } else if (rawb) ce = hipMemcpyAsync(st.d_raw.p + RAW_FRONT, ci.direct ? ci.lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s);
+        if (ce == hipSuccess && !ci.packed) ce = hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s);
+        if (ce == hipSuccess && n_desc) ce = hipMemcpyAsync(st.d_desc.p, st.h_desc.p, n_desc * sizeof(bsw_refx), hipMemcpyHostToDevice, s);
+        if (turn) {
+            if (ce == hipSuccess) ce = hipEventRecord(turn->ev, s);
+            if (ce == hipSuccess) turn->gate->last = turn->ev;
+            turn->gate->next = turn->seq + 1;          /* pass the turn on even on failure: nobody may wait forever */
+            turn->gate->cv.notify_all();
+        }
+        if (ce != hipSuccess) return fail(e, BSW_E_HIP, "input DMA: %s", hipGetErrorString(ce));
+    }
+    (void)dev_targets;
+    if (!ci.packed)
+        HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, ci.raw_bias, (uint32_t)n, ci.rev_left ? 1 : 0,
+                                   ref ? ref->d_pac[dev_index] : nullptr, ref ? ref->l_pac : 0, ref ? st.d_desc.p : nullptr, st.d_seq.p, s));
+    HIPCHK(e, bsw::launch_bin(ci.bp, st.d_seq.p, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
+    if (h2d_bytes) *h2d_bytes = (ci.packed ? ci.words * 8 : rawb + n * sizeof(bsw_rawoff)) + n * sizeof(bsw_dtask) + n_desc * sizeof(bsw_refx);
+    return BSW_OK;
+}
+
+/* ---- batch plan export (host only) ---------------------------------------------------------- */
+static void plan_segments(const batch_plan &pl, uint32_t *seg)
+{
+    int k = 0;
+    for (int c = 0; c < 8; ++c) seg[k++] = pl.wave_start[c];
+    seg[k++] = pl.lane_all_off;                    /* 8 */
+    for (int c = 0; c < 8; ++c) seg[k++] = pl.laneL_off[std::min(c, BSW_MAX_LANE_CLASSES)];    /* 9..16 */
+    for (int c = 0; c < 8; ++c) seg[k++] = pl.laneR_off[std::min(c, BSW_MAX_LANE_CLASSES)];    /* 17..24 */
+    seg[k++] = pl.redo_off;                        /* 25 */
+    seg[k++] = pl.order_len;                       /* 26 */
+}
+
+extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, size_t n, int kernel, int pack_threads,
+                                  uint32_t *order, uint32_t *seg)
+{
+    (void)pack_threads;
+    if (!p || (!tasks && n) || !seg) return BSW_E_INVAL;
+    errs e;
+    bsw_dparams dp;
+    int rc = check_params(e, p, &dp);
+    if (rc) return rc;
+    std::vector<bsw_dtask> dt(n ? n : 1);
+    std::vector<bsw_rawoff> ro(n ? n : 1);
+    chunk_info ci;
+    rc = prepare_chunk(e, p, kernel, tasks, n, false, dt.data(), ro.data(), ci);
+    if (rc) return rc;
+    plan_segments(ci.plan, seg);
+    if (order) {
+        /* the device's rules (bsw_bin_count/scan/scatter) replayed on the host: lists by class, lane sides by
+         * (class, query with / without an N, query length descending); the order inside one query length is task
+         * order here, arbitrary there */
+        const bsw_binparams &bp = ci.bp;
+        std::vector<uint32_t> cur(BSW_BIN_WORDS, 0), hist(BSW_BIN_WAVE0, 0);
+        auto has_n = [](const uint8_t *q, int len) {
+            for (int j = 0; j < len; ++j)
+                if (q[j] >= 4) return 1;
+            return 0;
+        };
+        auto keys = [&](size_t i, int &k0, int &k1, int &k2) {
+            const bsw_dtask &T = dt[i];
+            k1 = k2 = -1;
+            const int bits = bsw_seed_lane_bits(&bp, T.lqlen, T.rqlen, T.h0);
+            if (!bits) { k0 = BSW_BIN_WAVE0 + bsw_wave_class_of(&bp, std::max(T.lqlen, T.rqlen)); return; }
+            k0 = BSW_BIN_LANEALL;
+            if (T.lqlen) k1 = BSW_BIN_SIDE(0, bsw_side_lane_class(&bp, bits, T.lqlen), has_n(tasks[i].lquery, T.lqlen), T.lqlen);
+            if (T.rqlen) k2 = BSW_BIN_SIDE(1, bsw_side_lane_class(&bp, bits, T.rqlen), has_n(tasks[i].rquery, T.rqlen), T.rqlen);
+        };
+        for (size_t i = 0; i < n; ++i) {
+            int k0, k1, k2;
+            keys(i, k0, k1, k2);
+            if (k1 >= 0) ++hist[(size_t)k1];
+            if (k2 >= 0) ++hist[(size_t)k2];
+        }
+        for (int side = 0; side < 2; ++side)
+            for (int c = 0; c < bp.n_lane; ++c) {
+                uint32_t run = side ? bp.laneR_off[c] : bp.laneL_off[c];
+                for (int hn = 1; hn >= 0; --hn)
+                    for (int q = BSW_LANE_QBINS - 1; q >= 0; --q) {
+                        const size_t idx = (size_t)BSW_BIN_SIDE(side, c, hn, q);
+                        cur[idx] = run;
+                        run += hist[idx];
+                    }
+            }
+        for (int c = 0; c < bp.n_wave; ++c) cur[(size_t)(BSW_BIN_WAVE0 + c)] = bp.wave_start[c];
+        cur[BSW_BIN_LANEALL] = bp.lane_all_off;
+        for (size_t i = 0; i < n; ++i) {
+            int k0, k1, k2;
+            keys(i, k0, k1, k2);
+            order[cur[(size_t)k0]++] = (uint32_t)i;
+            if (k1 >= 0) order[cur[(size_t)k1]++] = (uint32_t)i;
+            if (k2 >= 0) order[cur[(size_t)k2]++] = (uint32_t)i;
+        }
+    }
+    return (int64_t)ci.words;
+}
+
+/* ---- device-resident batches ------------------------------------------------ */
+extern "C" void bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b)
+{
+    if (!b) return;
+    if (ctx) (void)hipSetDevice(ctx->device0());
+    b->st.release();
+    delete b;
+}
+
+static void fill_refx(const bsw_ref_task *rt, size_t n, bsw_refx *x);
+
+static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out,
+                         const bsw_ref *ref /* NULL: targets come from the host */, const bsw_ref_task *rtasks, bool packed = false)
+{
+    *out = nullptr;
+    errs &e = ctx->err;
+    if (n >= (1ull << 32)) return fail(e, BSW_E_LIMIT, "more than 2^32-1 tasks in one batch");
+    bsw_dparams dp;
+    int rc = check_params(e, p, &dp);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(ctx->device0()));
+    bsw_dev_batch *b = new bsw_dev_batch();
+    stage_t &st = b->st;
+    st.set_pinned(false);               /* one-shot upload: plain host staging, synchronous copies */
+    chunk_info ci;
+    if (st.h_tasks.reserve(n + 1) != hipSuccess || st.h_roff.reserve(n + 1) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
+    rc = prepare_chunk(e, p, ctx->cfg.kernel, tasks, n, ref != nullptr, st.h_tasks.p, st.h_roff.p, ci, false, packed);
+    if (rc) { bsw_free_batch(ctx, b); return rc; }
+    if (!ci.direct) {
+        if (st.h_raw.reserve(ci.sum_len + RAW_SLACK) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
+        if (packed) gather_packed(tasks, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
+        else gather_raw(tasks, st.h_roff.p, n, ref != nullptr, st.h_raw.p, ctx->cfg.pack_threads);
+    }
+    if (ref) {
+        if (st.h_desc.reserve(n + 1) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
+        fill_refx(rtasks, n, st.h_desc.p);
+    }
+    b->n = n; b->P = dp; b->variant = p->variant; b->seq_words = ci.words; b->plan = ci.plan;
+    hipStream_t s = ctx->stream0();
+    rc = stage_device(e, st, s, ci, n, ref != nullptr, ref, &b->h2d_bytes);
+    if (!rc && n) {
+        hipError_t he = hipMemsetAsync(st.d_out.p, 0xff, n * sizeof(bsw_result), s);
+        if (he != hipSuccess) rc = fail(e, BSW_E_HIP, "memset: %s", hipGetErrorString(he));
+    }
+    if (!rc) rc = sync_stream(ctx, e, s, ctx->devs[0].events[0]);
+    if (rc) { bsw_free_batch(ctx, b); return rc; }
+    st.release_host();
+    st.release_transient_dev();
+    *out = b;
+    return BSW_OK;
+}
+
+extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!out || (!tasks && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_upload: NULL argument");
+    int rc = busy_check(ctx, "bsw_upload");
+    if (rc) return rc;
+    return upload_common(ctx, p, tasks, n, out, nullptr, nullptr);
+}
+
+/* bsw_upload for sequences that are 4-bit packed already (see bsw_submit_packed) */
+extern "C" int bsw_upload_packed(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!out || (!tasks && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_upload_packed: NULL argument");
+    int rc = busy_check(ctx, "bsw_upload_packed");
+    if (rc) return rc;
+    return upload_common(ctx, p, tasks, n, out, nullptr, nullptr, true);
+}
+
+/* ---- device-resident reference (F3) ------------------------------------------------ */
+extern "C" void bsw_ref_free(bsw_ctx *ctx, bsw_ref *ref);
+
+extern "C" int bsw_ref_upload(bsw_ctx *ctx, const uint8_t *pac, int64_t l_pac, bsw_ref **out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!pac || !out || l_pac <= 0) return fail(e, BSW_E_INVAL, "bsw_ref_upload: bad argument");
+    *out = nullptr;
+    bsw_ref *r = new bsw_ref();
+    r->l_pac = l_pac;
+    r->d_pac.assign(ctx->devs.size(), nullptr);
+    const size_t bytes = (size_t)((l_pac + 3) >> 2);
+    for (size_t d = 0; d < ctx->devs.size(); ++d) {               /* every GPU of the context keeps its own copy */
+        hipError_t he = hipSetDevice(ctx->devs[d].device);
+        if (he == hipSuccess) he = hipMalloc((void **)&r->d_pac[d], bytes + 8);
+        if (he == hipSuccess) he = hipMemcpy(r->d_pac[d], pac, bytes, hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            bsw_ref_free(ctx, r);
+            return fail(e, BSW_E_HIP, "pac upload to device %d: %s", ctx->devs[d].device, hipGetErrorString(he));
+        }
+    }
+    (void)hipSetDevice(ctx->device0());
+    *out = r;
+    return BSW_OK;
+}
+
+extern "C" void bsw_ref_free(bsw_ctx *ctx, bsw_ref *ref)
+{
+    if (!ref) return;
+    for (size_t d = 0; d < ref->d_pac.size(); ++d) {
+        if (!ref->d_pac[d]) continue;
+        if (ctx && d < ctx->devs.size()) (void)hipSetDevice(ctx->devs[d].device);
+        (void)hipFree(ref->d_pac[d]);
+    }
+    if (ctx) (void)hipSetDevice(ctx->device0());
+    delete ref;
+}
+
+/* mem_chain2aln's task extraction minus the target bases, which stay on the device: one seed of a
+ * read -> one task.  rev_left: the left query is NOT copied reversed; lquery points at its last base (query[qbeg-1]). */
+BSW_LOCAL int ref_to_task(errs &e, const bsw_params *p, int64_t l_pac, const bsw_ref_task &r, size_t i, bool rev_left,
+                       uint8_t *scratch, size_t &so, bsw_task &t)
+{
+    const bsw_seed &sd = r.seed;
+    const int64_t two = l_pac << 1;
+    if (!r.query || r.l_query < 1 || sd.qbeg < 0 || sd.len < 1 || sd.qbeg + sd.len > r.l_query)
+        return fail(e, BSW_E_INVAL, "ref task %zu: bad seed / read", i);
+    if (r.rmax0 < 0 || r.rmax1 > two || r.rmax0 > sd.rbeg || r.rmax1 < sd.rbeg + sd.len || (r.rmax0 < l_pac && l_pac < r.rmax1))
+        return fail(e, BSW_E_INVAL, "ref task %zu: window outside the reference or bridging the strands", i);
+    const int64_t lt = sd.rbeg - r.rmax0, rtl = r.rmax1 - (sd.rbeg + sd.len);
+    if (lt > BSW_MAX_TLEN || rtl > BSW_MAX_TLEN) return fail(e, BSW_E_LIMIT, "ref task %zu: window beyond BSW_MAX_TLEN", i);
+    memset(&t, 0, sizeof(t));
+    if (sd.qbeg > 0) {
+        if (rev_left) t.lquery = r.query + sd.qbeg - 1;
+        else {
+            for (int k = 0; k < sd.qbeg; ++k) scratch[so + (size_t)k] = r.query[sd.qbeg - 1 - k];
+            t.lquery = scratch + so;
+            so += (size_t)sd.qbeg;
+        }
+        t.lqlen = sd.qbeg; t.ltlen = (int32_t)lt;
+    }
+    if (sd.qbeg + sd.len != r.l_query) {
+        t.rquery = r.query + sd.qbeg + sd.len; t.rqlen = r.l_query - (sd.qbeg + sd.len); t.rtlen = (int32_t)rtl;
+    }
+    t.h0 = sd.len * p->mat[0]; t.init_score = r.init_score; t.qbeg = sd.qbeg; t.tag = r.tag;
+    return BSW_OK;
+}
+
+/* where the device finds the two targets of every seed in the resident pac */
+static void fill_refx(const bsw_ref_task *rt, size_t n, bsw_refx *x)
+{
+    for (size_t i = 0; i < n; ++i) x[i] = bsw_refx{rt[i].seed.rbeg - 1, rt[i].seed.rbeg + rt[i].seed.len};
+}
+
+extern "C" int bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rt, size_t n, bsw_dev_batch **out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!p || !ref || !out || (!rt && n)) return fail(e, BSW_E_INVAL, "bsw_upload_ref: NULL argument");
+    int rc = busy_check(ctx, "bsw_upload_ref");
+    if (rc) return rc;
+    std::vector<bsw_task> tasks(n ? n : 1);
+    size_t scratch_len = 0;
+    for (size_t i = 0; i < n; ++i) scratch_len += (size_t)(rt[i].seed.qbeg > 0 ? rt[i].seed.qbeg : 0);
+    std::vector<uint8_t> scratch(scratch_len + 1);
+    size_t so = 0;
+    for (size_t i = 0; i < n; ++i) {
+        rc = ref_to_task(e, p, ref->l_pac, rt[i], i, false, scratch.data(), so, tasks[i]);
+        if (rc) return rc;
+    }
+    return upload_common(ctx, p, tasks.data(), n, out, ref, rt);
+}
+
+extern "C" int bsw_extend_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rt, size_t n, bsw_result *out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!out && n) return fail(ctx->err, BSW_E_INVAL, "bsw_extend_ref: NULL argument");
+    bsw_dev_batch *b = nullptr;
+    int rc = bsw_upload_ref(ctx, p, ref, rt, n, &b);
+    if (rc) return rc;
+    rc = bsw_run(ctx, b);
+    if (!rc) rc = bsw_download(ctx, b, out);
+    bsw_free_batch(ctx, b);
+    return rc;
+}
+
+extern "C" int bsw_run(bsw_ctx *ctx, bsw_dev_batch *b)
+{
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!b) return fail(e, BSW_E_INVAL, "bsw_run: NULL argument");
+    int rc = busy_check(ctx, "bsw_run");
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(ctx->device0()));
+    hipStream_t s = ctx->stream0();
+    hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
+    if (ctx->hist_used < 4096) {
+        if (ctx->hist_used == ctx->hist.size()) {
+            hipEvent_t a, c;
+            HIPCHK(e, hipEventCreate(&a));
+            HIPCHK(e, hipEventCreate(&c));
+            ctx->hist.emplace_back(a, c);
+        }
+        e0 = ctx->hist[ctx->hist_used].first;
+        e1 = ctx->hist[ctx->hist_used].second;
+        ++ctx->hist_used;
+    }
+    HIPCHK(e, hipEventRecord(e0, s));
+    b->launches = 0;
+    rc = enqueue_batch(e, b->P, b->variant, b->st.d_seq.p, b->st.d_tasks.p, b->st.d_order.p, b->plan, b->st.d_out.p, s, &b->launches, fork_for(ctx, s));
+    if (rc) return rc;
+    HIPCHK(e, hipEventRecord(e1, s));
+    ctx->ev_last0 = e0; ctx->ev_last1 = e1;
+    ctx->timed = true;
+    return BSW_OK;
+}
+
+extern "C" int bsw_sync(bsw_ctx *ctx)
+{
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (ctx->worker_active) return fail(e, BSW_E_BUSY, "bsw_sync: a bsw_submit is in flight (call bsw_wait)");
+    HIPCHK(e, hipSetDevice(ctx->device0()));
+    return sync_stream(ctx, e, ctx->stream0(), ctx->devs[0].events[0]);
+}
+
+extern "C" int bsw_last_run_ms(bsw_ctx *ctx, float *ms)
+{
+    if (!ctx || !ms || !ctx->timed) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    int rc = bsw_sync(ctx);
+    if (rc) return rc;
+    HIPCHK(e, hipEventElapsedTime(ms, ctx->ev_last0, ctx->ev_last1));
+    return BSW_OK;
+}
+
+extern "C" int bsw_run_history(bsw_ctx *ctx, float *ms, int cap)
+{
+    if (!ctx || (!ms && cap > 0)) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    int rc = bsw_sync(ctx);
+    if (rc) return rc;
+    int n = 0;
+    for (size_t i = 0; i < ctx->hist_used && n < cap; ++i, ++n)
+        HIPCHK(e, hipEventElapsedTime(&ms[n], ctx->hist[i].first, ctx->hist[i].second));
+    ctx->hist_used = 0;
+    return n;
+}
+
+extern "C" int bsw_download(bsw_ctx *ctx, bsw_dev_batch *b, bsw_result *out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!b || (!out && b->n)) return fail(e, BSW_E_INVAL, "bsw_download: NULL argument");
+    int rc = bsw_sync(ctx);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpy(out, b->st.d_out.p, b->n * sizeof(bsw_result), hipMemcpyDeviceToHost));
+    return BSW_OK;
+}
+
+extern "C" int bsw_batch_info(const bsw_dev_batch *b, uint64_t *n_tasks, uint64_t *in_bytes, uint64_t *out_bytes, uint64_t *n_launches)
+{
+    if (!b) return BSW_E_INVAL;
+    if (n_tasks) *n_tasks = b->n;
+    if (in_bytes) *in_bytes = b->seq_words * 8 + b->n * sizeof(bsw_dtask) + (uint64_t)b->plan.redo_off * sizeof(uint32_t);
+    if (out_bytes) *out_bytes = b->n * sizeof(bsw_result);
+    if (n_launches) *n_launches = b->launches;
+    return BSW_OK;
+}
+
+extern "C" int bsw_batch_order(bsw_ctx *ctx, const bsw_dev_batch *b, uint32_t *order, uint32_t *seg)
+{
+    if (!ctx) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    if (!b || !seg) return fail(e, BSW_E_INVAL, "bsw_batch_order: NULL argument");
+    int rc = bsw_sync(ctx);
+    if (rc) return rc;
+    plan_segments(b->plan, seg);
+    if (order && b->plan.redo_off)
+        HIPCHK(e, hipMemcpy(order, b->st.d_order.p, (size_t)b->plan.redo_off * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return BSW_OK;
+}
+
+/* ---- a HANDFUL of seeds (the scalar ksw_extend2 entry points, tiny batches): no device-side staging at all.
+ * The batch path's pack kernel, two memsets and three binning kernels are seven launches of ~6 us each in front of the DP
+ * kernel (profiles/r3/scalar_call_timeline.txt: 58 us before the extension starts).  For up to SMALL_BATCH seeds the host
+ * packs the bases (a few hundred bytes), sorts the seeds into their general-kernel classes, and ONE DMA carries
+ * sequences, task records, order lists and zeroed counters; then the DP kernel(s), then the result copy. ---- */
+#define SMALL_BATCH 256
+static int run_small(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params &p, const bsw_dparams &dp,
+                     const bsw_task *tasks, size_t n, bsw_result *out)
+{
+    std::vector<bsw_dtask> dt(n);
+    std::vector<bsw_rawoff> ro(n);
+    chunk_info ci;
+    int rc = prepare_chunk(e, &p, BSW_KERNEL_WAVE, tasks, n, false, dt.data(), ro.data(), ci);   /* validation, word offsets, class counts */
+    if (rc) return rc;
+    const batch_plan &pl = ci.plan;
+    const size_t n_ctr = 2 + BSW_MAX_WAVE_CLASSES;
+    const size_t w_seq = ci.words + 4, w_tasks = (n * sizeof(bsw_dtask) + 7) / 8, w_order = ((pl.order_len + n_ctr) * sizeof(uint32_t) + 7) / 8;
+    const size_t total = w_seq + w_tasks + w_order;
+    hipError_t he;
+    if ((he = st.h_blob.reserve(total)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    if ((he = st.d_blob.reserve(total)) != hipSuccess) return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    uint64_t *hb = st.h_blob.p;
+    memset(hb, 0, total * sizeof(uint64_t));
+    for (size_t i = 0; i < n; ++i) {                 /* the device sequence format, packed here */
+        const bsw_task &t = tasks[i];
+        const bsw_dtask &d = dt[i];
+        if (t.lqlen) { bsw_pack_bases(t.lquery, t.lqlen, hb + d.lq_off); if (t.ltlen) bsw_pack_bases(t.ltarget, t.ltlen, hb + d.lt_off); }
+        if (t.rqlen) { bsw_pack_bases(t.rquery, t.rqlen, hb + d.rq_off); if (t.rtlen) bsw_pack_bases(t.rtarget, t.rtlen, hb + d.rt_off); }
+    }
+    memcpy(hb + w_seq, dt.data(), n * sizeof(bsw_dtask));
+    uint32_t *ho = (uint32_t *)(hb + w_seq + w_tasks);
+    {
+        uint32_t cur[BSW_MAX_WAVE_CLASSES];
+        for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) cur[c] = pl.wave_start[c];
+        for (size_t i = 0; i < n; ++i) ho[cur[bsw_wave_class_of(&ci.bp, std::max(tasks[i].lqlen, tasks[i].rqlen))]++] = (uint32_t)i;
+    }
+    HIPCHK(e, hipMemcpyAsync(st.d_blob.p, hb, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    const uint64_t *d_seq = st.d_blob.p;
+    const bsw_dtask *d_tasks = (const bsw_dtask *)(st.d_blob.p + w_seq);
+    uint32_t *d_order = (uint32_t *)(st.d_blob.p + w_seq + w_tasks), *ctr = d_order + pl.order_len;   /* (zero: copied that way) */
+    /* the result records go straight to pinned (device-visible) host memory: a few 96-byte stores over the link instead of
+     * a device buffer, a copy and its launch */
+    const bool out_direct = is_registered(out, n * sizeof(bsw_result));
+    if (!out_direct && (he = st.h_out.reserve(n)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    bsw_result *res = out_direct ? out : st.h_out.p;
+    const int nc = bsw::wave_class_count();
+    for (int c = 0; c < nc; ++c) {
+        const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
+        if (cnt) HIPCHK(e, bsw::launch_wave(c, p.variant, dp, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, ctr + 1 + c, res, s));
+    }
+    rc = sync_stream(ctx, e, s, ev);
+    if (rc) return rc;
+    if (!out_direct) memcpy(out, st.h_out.p, n * sizeof(bsw_result));
+    return BSW_OK;
+}
+
+/* ---- one synchronous chunk through a staging slot (small batches; the streaming workers use the same steps) ---- */
+BSW_LOCAL int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params &p, const bsw_dparams &dp,
+                     const bsw_task *tasks, size_t n, bsw_result *out, int gather_threads, const gate_turn *turn, bool packed)
+{
+    if (n == 0) return BSW_OK;
+    {
+        static const bool nosmall = getenv("BSW_NO_SMALL") != nullptr;     /* (measurements) */
+        if (!nosmall && n <= SMALL_BATCH && !packed && !turn && ctx->cfg.kernel != BSW_KERNEL_LANE && ctx->cfg.result_format == BSW_RESULT_FULL)
+            return run_small(ctx, e, st, s, ev, p, dp, tasks, n, out);
+    }
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = dbg ? tnow() : 0;
+    hipError_t he;
+    if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess)
+        return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    chunk_info ci;
+    int rc = prepare_chunk(e, &p, ctx->cfg.kernel, tasks, n, false, st.h_tasks.p, st.h_roff.p, ci, false, packed);
+    if (rc) return rc;
+    const double t_b = dbg ? tnow() : 0;
+    if (!ci.direct) {
+        if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+        if (packed) gather_packed(tasks, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
+        else gather_raw(tasks, st.h_roff.p, n, false, st.h_raw.p, gather_threads);
+    }
+    const double t_c = dbg ? tnow() : 0;
+    rc = stage_device(e, st, s, ci, n, false, nullptr, nullptr, turn);
+    if (rc) return rc;
+    /* BSW_RESULT_PAIR: `out` addresses bsw_pair[n]; the dense 32-byte records come from their own device array */
+    const bool pairs = ctx->cfg.result_format == BSW_RESULT_PAIR;
+    const size_t rec = pairs ? sizeof(bsw_pair) : sizeof(bsw_result);
+    if (pairs && (he = st.d_pair.reserve(n + 1)) != hipSuccess) return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, s, nullptr, fork_for(ctx, s), pairs ? st.d_pair.p : nullptr);
+    if (rc) return rc;
+    const bool out_direct = is_registered(out, n * rec);
+    if (!out_direct && (he = st.h_out.reserve(n)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    HIPCHK(e, hipMemcpyAsync(out_direct ? (void *)out : (void *)st.h_out.p, pairs ? (const void *)st.d_pair.p : (const void *)st.d_out.p, n * rec, hipMemcpyDeviceToHost, s));
+    const double t_d = dbg ? tnow() : 0;
+    rc = sync_stream(ctx, e, s, ev);
+    if (rc) return rc;
+    const double t_e = dbg ? tnow() : 0;
+    if (!out_direct) memcpy((void *)out, st.h_out.p, n * rec);
+    if (dbg) fprintf(stderr, "[bsw] chunk n=%zu %s: prepare %.3f ms, gather %.3f, enqueue %.3f, gpu wait %.3f, copy-out %.3f (t0=%.3f)\n", n,
+                     ci.direct ? "direct" : "gather", t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, tnow() - t_e, t_a);
+    return BSW_OK;
+}
+
+/* ---- streaming submit: one host thread per (device, slot); chunk k -> device k mod G, slot (k / G) mod S —
+ * the round-robin of the reference's four TBB/RBB pairs over its PE arrays (batch_manager.v:343-348,418,745-773) ---- */
+struct chunk_span {
+    size_t base, cnt;
+};
+
+/* tasks[0..n) -> per-device chunk lists.  Chunks are equal-sized (a short tail chunk would fall below the lane
+ * kernel's minimum batch), chunk c of the plan belongs to device c mod G, and every device's first
+ * chunk is cut in two so that its first DMA — the only one no kernel overlaps — is short. */
+static std::vector<std::vector<chunk_span>> plan_chunks(size_t n, size_t chunk, size_t G)
+{
+    std::vector<std::vector<chunk_span>> out(G);
+    if (n == 0) return out;
+    size_t nch = (n + chunk / 2) / chunk;
+    if (nch == 0) nch = 1;
+    size_t per = ((n + nch - 1) / nch + 255) & ~(size_t)255;
+    size_t c = 0;
+    for (size_t base = 0; base < n; base += per, ++c) {
+        const size_t cnt = std::min(per, n - base);
+        std::vector<chunk_span> &v = out[c % G];
+        if (v.empty() && cnt >= 3 * (size_t)LANE_AUTO_MIN + 1024) {     /* (the smaller part still holds a lane launch's worth of one-sided seeds; two-sided ones take the general kernels there, at the same cost) */
+            const size_t h = ((cnt / 3) + 255) & ~(size_t)255;
+            v.push_back(chunk_span{base, h});
+            v.push_back(chunk_span{base + h, cnt - h});
+        } else
+            v.push_back(chunk_span{base, cnt});
+    }
+    return out;
+}
+
+/* One slot = one host thread + one stream + one set of staging buffers.  Per chunk: host pass (validate, lay out,
+ * count) -> wait for the slot's previous chunk -> input DMAs in the device's chunk order -> pack, bin, DP kernels,
+ * result DMA.  The host pass of chunk k+S runs while chunk k is still on the GPU: it only needs the pinned host
+ * staging, which is free again as soon as chunk k's input DMAs are done. */
+static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp, const bsw_task *tasks,
+                       const bsw_ref *ref, const bsw_ref_task *rtasks,   /* non-NULL: seeds against the device-resident reference */
+                       bsw_result *out, const std::vector<chunk_span> &chunks, size_t d, size_t s, int gather_threads,
+                       std::atomic<int> &abort_flag, h2d_gate &gate, errs &e, bool packed)
+{
+    std::vector<bsw_task> rt_tasks;                 /* ref mode: this chunk's seeds as tasks (left queries by reference) */
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_host = 0, t_staging = 0, t_finish = 0, t_stage = 0;
+    dev_state &dev = ctx->devs[d];
+    const size_t S = dev.slots.size();
+    stage_t &st = dev.slots[s];
+    hipStream_t stream = dev.streams[s];
+    struct { bool active = false; size_t n = 0; char *out = nullptr; bool direct = false, copied = false; } pend;
+    /* BSW_RESULT_PAIR: `out` addresses bsw_pair[n]; the dense 32-byte records come from their own device array */
+    const bool pairs = ctx->cfg.result_format == BSW_RESULT_PAIR;
+    const size_t rec = pairs ? sizeof(bsw_pair) : sizeof(bsw_result);
+    auto d_res = [&]() -> const void * { return pairs ? (const void *)st.d_pair.p : (const void *)st.d_out.p; };
+    bool queued = false;                            /* some async op of the current chunk may be on the stream (set before the first one) */
+    auto bail = [&](int rc) {                       /* wake the slots waiting for their DMA turn; leave nothing in flight */
+        abort_flag = 1;
+        { std::lock_guard<std::mutex> lk(gate.mu); }
+        gate.cv.notify_all();
+        /* a failure after stage_device queued its first copy leaves DMAs out of the caller's registered arena and kernels
+         * in flight although pend.active is still false: drain the stream (with the watchdog) before the error is reported,
+         * so the caller may free or reuse that memory as soon as bsw_wait returns */
+        if (pend.active || queued) { errs quiet; (void)sync_stream(ctx, quiet, stream, dev.events[s]); pend.active = false; queued = false; }
+        return rc;
+    };
+    hipError_t he = hipSetDevice(dev.device);
+    if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)));
+    auto finish = [&]() -> int {                    /* the slot's chunk in flight: wait (watchdog), hand the results over */
+        if (!pend.active) return BSW_OK;
+        pend.active = false;
+        int rc = BSW_OK;
+        if (!pend.copied) {                         /* kernels done -> result DMA -> done */
+            rc = wait_event(ctx, e, dev.events[s]);
+            if (rc) return rc;
+            const hipError_t ce = hipMemcpyAsync(pend.direct ? (void *)pend.out : (void *)st.h_out.p, d_res(), pend.n * rec, hipMemcpyDeviceToHost, stream);
+            if (ce != hipSuccess) return fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(ce));
+        }
+        rc = sync_stream(ctx, e, stream, dev.events[s]);
+        if (rc) return rc;
+        if (!pend.direct) memcpy(pend.out, st.h_out.p, pend.n * rec);
+        return BSW_OK;
+    };
+    for (size_t k = s; k < chunks.size() && !abort_flag; k += S) {            /* k-th chunk of this device */
+        const bsw_task *ct = tasks ? tasks + chunks[k].base : nullptr;
+        const size_t n = chunks[k].cnt;
+        int rc = BSW_OK;
+        const double t0 = dbg ? tnow() : 0;
+        if (pend.active) rc = wait_event(ctx, e, dev.h2d_done[s]);           /* pinned host staging is free again */
+        if (rc) return bail(rc);
+        const double t1 = dbg ? tnow() : 0;
+        if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess ||
+            (rtasks && (he = st.h_desc.reserve(n + 1)) != hipSuccess))
+            return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
+        chunk_info ci;
+        if (rtasks) {                               /* mem_chain2aln's task extraction fused into the pass; the targets stay on the device */
+            const bsw_ref_task *crt = rtasks + chunks[k].base;
+            const size_t base = chunks[k].base;
+            bsw_refx *rx = st.h_desc.p;
+            size_t so = 0;
+            rc = prepare_chunk_t(e, &p, ctx->cfg.kernel, [&](size_t i, bsw_task &tmp, int &erc) -> const bsw_task * {
+                erc = ref_to_task(e, &p, ref->l_pac, crt[i], base + i, true, nullptr, so, tmp);
+                rx[i] = bsw_refx{crt[i].seed.rbeg - 1, crt[i].seed.rbeg + crt[i].seed.len};
+                return erc ? nullptr : &tmp;
+            }, n, true, st.h_tasks.p, st.h_roff.p, ci, true);
+            if (rc) return bail(rc);
+            if (!ci.direct) {                       /* reads in pageable memory: materialise the tasks for the gather */
+                rt_tasks.resize(n);
+                for (size_t i = 0; i < n && !rc; ++i) rc = ref_to_task(e, &p, ref->l_pac, crt[i], base + i, true, nullptr, so, rt_tasks[i]);
+                if (rc) return bail(rc);
+                ct = rt_tasks.data();
+                gather_offsets(ct, n, true, st.h_roff.p);
+            }
+        } else {
+            rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci, false, packed);
+            if (rc) return bail(rc);
+        }
+        if (!ci.direct) {
+            if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
+            if (packed) gather_packed(ct, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
+            else gather_raw(ct, st.h_roff.p, n, rtasks != nullptr, st.h_raw.p, gather_threads, rtasks != nullptr);
+        }
+        const double t2 = dbg ? tnow() : 0;
+        rc = finish();
+        if (rc) return bail(rc);
+        const double t3 = dbg ? tnow() : 0;
+        gate_turn turn;
+        turn.gate = &gate; turn.seq = k; turn.ev = dev.h2d_done[s]; turn.abort_flag = &abort_flag;
+        queued = true;
+        rc = stage_device(e, st, stream, ci, n, rtasks != nullptr, ref, nullptr, &turn, d);
+        if (!rc && pairs && (he = st.d_pair.reserve(n + 1)) != hipSuccess) rc = fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+        if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr, fork_for(ctx, stream), pairs ? st.d_pair.p : nullptr);
+        if (rc) return bail(rc);
+        char *co = (char *)out + chunks[k].base * rec;
+        pend.direct = is_registered(co, n * rec);
+        if (!pend.direct && (he = st.h_out.reserve(n)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
+        /* A result copy queued behind its kernels sits at the head of its DMA engine's ring until they finish and holds up
+         * the copies queued to that engine after it (profiles/r2/wire_submit_timeline.txt).  With the reference on the
+         * device the input DMAs are short and that wait is what the pipeline loses (+7 % when the slot thread issues the
+         * result DMA itself once the kernels are done); with 448 B per seed of input the link is busy anyway and the
+         * extra host round trip per chunk costs more than it saves (-6 %), so there the copy is queued right away. */
+        const bool late = rtasks != nullptr;
+        if (!late) he = hipMemcpyAsync(pend.direct ? (void *)co : (void *)st.h_out.p, d_res(), n * rec, hipMemcpyDeviceToHost, stream);
+        else he = hipEventRecord(dev.events[s], stream);
+        if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(he)));
+        pend.copied = !late;
+        pend.active = true; pend.n = n; pend.out = co;
+        queued = false;                             /* from here on finish() / bail() drain through pend */
+        if (dbg) { const double t4 = tnow(); t_staging += t1 - t0; t_host += t2 - t1; t_finish += t3 - t2; t_stage += t4 - t3; }
+    }
+    const double t5 = dbg ? tnow() : 0;
+    const int rc = finish();
+    if (dbg) fprintf(stderr, "[bsw] slot %zu.%zu: wait staging %.2f ms, host pass %.2f, wait results %.2f, DMA turn + enqueue %.2f, drain %.2f\n",
+                     d, s, t_staging, t_host, t_finish, t_stage, tnow() - t5);
+    return rc ? bail(rc) : BSW_OK;
+}
+
+static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, const bsw_ref *ref, const bsw_ref_task *rtasks,
+                           size_t n, bsw_result *out, bool packed = false)
+{
+    bsw_dparams dp;
+    int rc = check_params(ctx->err, &p, &dp);
+    if (rc) return rc;
+    const size_t G = ctx->devs.size(), S = (size_t)ctx->cfg.streams;
+    const std::vector<std::vector<chunk_span>> chunks = plan_chunks(n, ctx->cfg.chunk_tasks, G);
+    struct wk { size_t d, s; int rc = 0; errs e; };
+    std::vector<wk> ws;
+    for (size_t s = 0; s < S; ++s)
+        for (size_t d = 0; d < G; ++d)
+            if (s < chunks[d].size()) { wk w; w.d = d; w.s = s; ws.push_back(w); }
+    if (ws.empty()) return BSW_OK;
+    const int gather_threads = std::max(1, ctx->cfg.pack_threads / (int)ws.size());
+    std::atomic<int> abort_flag{0};
+    std::vector<h2d_gate> gates(G);
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < ws.size(); ++k)
+        th.emplace_back([&, k]() { ws[k].rc = slot_worker(ctx, p, dp, tasks, ref, rtasks, out, chunks[ws[k].d], ws[k].d, ws[k].s, gather_threads, abort_flag, gates[ws[k].d], ws[k].e, packed); });
+    ws[0].rc = slot_worker(ctx, p, dp, tasks, ref, rtasks, out, chunks[ws[0].d], ws[0].d, ws[0].s, gather_threads, abort_flag, gates[ws[0].d], ws[0].e, packed);
+    for (auto &t : th) t.join();
+    for (int pass = 0; pass < 2; ++pass)             /* report the failure itself, not the slots it made give up */
+        for (auto &w : ws)
+            if (w.rc && (pass || w.e.msg.compare(0, 7, "aborted") != 0)) { ctx->err = w.e; return w.rc; }
+    return BSW_OK;
+}
+
+extern "C" int bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!p || (!tasks && n) || (!out && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_submit: NULL argument");
+    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "bsw_submit: context is dead (an earlier wait for the GPU timed out)");
+    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "previous bsw_submit not waited for");
+    bsw_dparams dp;
+    int rc = check_params(ctx->err, p, &dp);
+    if (rc) return rc;
+    ctx->worker_active = true;
+    ctx->worker_rc = 0;
+    bsw_params pc = *p;
+    ctx->worker = std::thread([ctx, pc, tasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, tasks, nullptr, nullptr, n, out); });
+    return BSW_OK;
+}
+
+/* bsw_submit for callers that keep their sequences 4-bit packed — 16 bases per uint64, base k in bits [4k, 4k+3], codes
+ * 0-3 = ACGT, 4-7 = N, every sequence on an 8-byte boundary, lengths still in bases: the device's own layout and the
+ * encoding the reference ships over its link (8 bases per 32-bit word, sw_pe_array_proc_element.v:1638,1677-1683).  The
+ * words of a registered arena are DMA'd straight into the sequence buffer: no pack kernel, less than half the PCIe bytes
+ * of byte-per-base input.  bsw_pack_bases() converts one sequence.  Wait with bsw_wait. */
+extern "C" int bsw_submit_packed(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!p || (!tasks && n) || (!out && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_submit_packed: NULL argument");
+    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "bsw_submit_packed: context is dead (an earlier wait for the GPU timed out)");
+    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "previous bsw_submit not waited for");
+    bsw_dparams dp;
+    int rc = check_params(ctx->err, p, &dp);
+    if (rc) return rc;
+    ctx->worker_active = true;
+    ctx->worker_rc = 0;
+    bsw_params pc = *p;
+    ctx->worker = std::thread([ctx, pc, tasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, tasks, nullptr, nullptr, n, out, true); });
+    return BSW_OK;
+}
+
+/* bsw_submit for seeds against a DEVICE-RESIDENT reference (F3): only the reads cross PCIe; the targets are fetched
+ * from the 2-bit pac on the GPU, the left flank of every read is mirrored by the pack kernel.  Wait with bsw_wait. */
+extern "C" int bsw_submit_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rtasks, size_t n, bsw_result *out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!p || !ref || (!rtasks && n) || (!out && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_submit_ref: NULL argument");
+    if (ref->d_pac.size() != ctx->devs.size()) return fail(ctx->err, BSW_E_INVAL, "bsw_submit_ref: the reference was uploaded through another context");
+    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "bsw_submit_ref: context is dead (an earlier wait for the GPU timed out)");
+    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "previous bsw_submit not waited for");
+    bsw_dparams dp;
+    int rc = check_params(ctx->err, p, &dp);
+    if (rc) return rc;
+    ctx->worker_active = true;
+    ctx->worker_rc = 0;
+    bsw_params pc = *p;
+    ctx->worker = std::thread([ctx, pc, ref, rtasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, nullptr, ref, rtasks, n, out); });
+    return BSW_OK;
+}
+
+extern "C" int bsw_wait(bsw_ctx *ctx)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!ctx->worker_active) return BSW_OK;
+    if (ctx->worker.joinable()) ctx->worker.join();
+    ctx->worker_active = false;
+    return ctx->worker_rc;
+}
+

@@ -1,0 +1,307 @@
+/*
+ * bsw_internal.h — what the host-side translation units of libbwasw_mi355.so share (internal; the public C ABI is
+ * include/bwa_sw_mi355.h): the context and staging types, the error channel, and the handful of functions that cross
+ * file boundaries.
+ *   bsw_ctx.hip     context, registered host memory, parameter validation, the device sequence format on the host
+ *   bsw_batch.hip   the batch manager: host pass, device staging, kernel launches, resident batches, streaming pipeline
+ *   bsw_scalar.hip  batched plain ksw_extend2 and the drop-in scalar entry points' shared queue
+ *   bsw_wire.hip    the reference's 256 KiB / 16 KiB wire format end to end (F1)
+ *   bsw_f4.hip      ksw_global2 / ksw_align2 hosts (F4)
+ * Everything here has hidden visibility: the shared object exports the C ABI only.
+ */
+#ifndef BSW_INTERNAL_H
+#define BSW_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bsw_device.h"
+#include "bsw_stage.h"
+
+#define BSW_LOCAL __attribute__((visibility("hidden")))
+
+struct bsw_ref {
+    std::vector<uint8_t *> d_pac;     /* one copy per device of the context that uploaded it (index = position in devs) */
+    int64_t l_pac = 0;
+};
+
+/* BSW_KERNEL_AUTO: a lane launch costs one wave's full duration (1.0 ms for a 131-column side) however few seeds it
+ * holds, and a chunk with both sides pays it twice; the general kernels scale with the seed count.  Measured crossovers,
+ * device-resident (profiles/r4/crossover_general_kernels.json): one-sided 131 x 257 seeds 27 k (17.4 k before the
+ * four-seeds-per-wavefront kernel took the long classes), PE mixed bins ~50 k (two lane launches of 1.05 ms against 36 ns
+ * per seed).  So: lane bins from LANE_AUTO_MIN eligible seeds PER LAUNCHED SIDE. */
+#define LANE_AUTO_MIN 26000
+inline bool lane_bins_pay(uint32_t n_lane, const uint32_t *cl, const uint32_t *cr)
+{
+    uint32_t l = 0, r = 0;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { l += cl[c]; r += cr[c]; }
+    const uint32_t sides = (l ? 1u : 0u) + (r ? 1u : 0u);
+    return n_lane >= (uint32_t)LANE_AUTO_MIN * (sides ? sides : 1u);
+}
+#define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
+#define RAW_FRONT 32                 /* ... and in front of the first one (reversed left queries) */
+
+/* How one batch is cut into kernel launches (all offsets index the device `order` array).
+ *   [wave classes][lane seeds, any order][lane left sides by qlen][lane right sides by qlen][redo list] + counter */
+struct batch_plan {
+    uint32_t wave_start[BSW_MAX_WAVE_CLASSES + 1] = {0};
+    uint32_t lane_all_off = 0, lane_all_cnt = 0;
+    uint32_t laneL_off[BSW_MAX_LANE_CLASSES + 1] = {0}, laneR_off[BSW_MAX_LANE_CLASSES + 1] = {0};
+    uint32_t redo_off = 0;
+    uint32_t order_len = 0;          /* entries before the redo counter */
+    int redo_cls = 0;
+    /* dep[lc] bit rc: some seed has its left side in lane class lc and its right side in lane class rc — the right-side
+     * launch of class rc then has to wait for the left-side launch of class lc (h0 of the right extension is the score
+     * after the left one, sw_pe_array_proc_element.v:1671).  All ones = not known. */
+    uint8_t dep[BSW_MAX_LANE_CLASSES] = {0xff, 0xff, 0xff, 0xff};
+};
+static_assert(BSW_MAX_LANE_CLASSES == 4, "batch_plan::dep initialiser");
+
+/* error text travels with the thread that produced it; the context keeps the last one */
+struct errs {
+    std::string msg;
+};
+
+inline int fail(errs &e, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    e.msg = buf;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                           \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e, BSW_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+/* ---- growable buffers ------------------------------------------------------- */
+template <class T>
+struct dbuf {                         /* device */
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t need)
+    {
+        if (cap >= need) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = need + need / 4 + 16;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+template <class T>
+struct hbuf {                         /* pinned host (or plain malloc for one-shot uploads) */
+    T *p = nullptr;
+    size_t cap = 0;
+    bool pinned = true;
+    hipError_t reserve(size_t need)
+    {
+        if (cap >= need) return hipSuccess;
+        release();
+        const size_t want = need + need / 4 + 16;
+        if (pinned) {
+            hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocPortable);
+            if (e != hipSuccess) { p = nullptr; return e; }
+        } else {
+            p = (T *)malloc(want * sizeof(T));
+            if (!p) return hipErrorOutOfMemory;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) { if (pinned) (void)hipHostFree(p); else free(p); }
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+/* staging of one chunk (streaming slot) or of one resident batch */
+struct stage_t {
+    hbuf<uint8_t> h_raw;              /* gather target; unused when the caller's memory is registered */
+    hbuf<bsw_dtask> h_tasks;
+    hbuf<bsw_rawoff> h_roff;
+    hbuf<bsw_result> h_out;
+    hbuf<bsw_refx> h_desc;          /* ref mode: target coordinates per seed */
+    hbuf<bsw_wireoff> h_woff;
+    dbuf<uint8_t> d_raw;
+    dbuf<uint64_t> d_seq;
+    dbuf<bsw_dtask> d_tasks;
+    dbuf<bsw_rawoff> d_roff;
+    dbuf<uint32_t> d_order, d_bins;
+    dbuf<bsw_result> d_out;
+    dbuf<bsw_pair> d_pair;            /* BSW_RESULT_PAIR: the dense 32-byte records that cross PCIe */
+    hbuf<uint64_t> h_blob;            /* small batches: packed sequences | task records | order lists + counters, one DMA */
+    dbuf<uint64_t> d_blob;
+    dbuf<bsw_refx> d_desc;
+    dbuf<bsw_wireoff> d_woff;
+    void set_pinned(bool on) { h_raw.pinned = h_tasks.pinned = h_roff.pinned = h_out.pinned = h_desc.pinned = h_woff.pinned = h_blob.pinned = on; }
+    void release_host() { h_raw.release(); h_tasks.release(); h_roff.release(); h_out.release(); h_desc.release(); h_woff.release(); h_blob.release(); }
+    void release_transient_dev() { d_raw.release(); d_roff.release(); d_bins.release(); d_desc.release(); d_woff.release(); d_blob.release(); }
+    void release()
+    {
+        release_host();
+        release_transient_dev();
+        d_seq.release(); d_tasks.release(); d_order.release(); d_out.release(); d_pair.release();
+    }
+};
+
+/* The lane classes of one side are independent launches: they run side by side on auxiliary streams so that one class's
+ * tail (its last waves running alone) fills with the other's waves — a 72-column wave (168 registers, 47 KB of LDS per
+ * four waves) and a 136-column wave (256, 70 KB) fit one SIMD / one CU together.  One set per slot stream, created right
+ * behind it (the runtime deals streams onto its hardware queues in creation order; streams that share a queue run
+ * their kernels one after the other, profiles/r3/e2e_hw_queues.txt). */
+#define BSW_FORK_AUX (BSW_MAX_LANE_CLASSES - 1)
+struct fork_t {
+    hipStream_t aux[BSW_FORK_AUX] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_left[BSW_MAX_LANE_CLASSES] = {nullptr}, ev_right[BSW_MAX_LANE_CLASSES] = {nullptr};
+    bool ok = false;
+};
+
+struct dev_state {
+    int device = 0;
+    std::vector<hipStream_t> streams;
+    std::vector<fork_t> forks;        /* one per stream */
+    std::vector<hipEvent_t> events;   /* one per stream, for the watchdog */
+    std::vector<hipEvent_t> h2d_done; /* one per stream: the chunk's input DMAs have finished */
+    std::vector<stage_t> slots;
+};
+
+/* Input DMAs of one device run in chunk order, one chunk at a time: chunk k+1's transfer then overlaps chunk k's
+ * kernels instead of every slot transferring (and then computing) at the same moment — the TBB fill order of the
+ * reference's batch manager (batch_manager.v:418,745-773). */
+struct h2d_gate {
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t next = 0;                  /* sequence number of the chunk whose turn it is */
+    hipEvent_t last = nullptr;        /* recorded after the previous chunk's input DMAs */
+};
+
+struct refbatch_req {
+    const uint32_t *in;
+    uint32_t *out;
+};
+
+struct bsw_ctx {
+    bsw_config cfg{};
+    std::vector<dev_state> devs;
+    std::atomic<bool> dead{false};    /* a wait for the GPU timed out: every later call fails fast */
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    /* per-run event pairs since the last bsw_run_history() call (kernel time of every bsw_run) */
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> hist;
+    size_t hist_used = 0;
+    hipEvent_t ev_last0 = nullptr, ev_last1 = nullptr;
+    errs err;
+    /* async submit */
+    std::thread worker;
+    bool worker_active = false;
+    int worker_rc = 0;
+    /* small synchronous batches (bsw_extend_batch, scalar ABI, wire format) */
+    stage_t small;
+    /* banded global alignment (F4) */
+    dbuf<bsw_gdtask> g_tasks;
+    dbuf<uint8_t> g_z;
+    dbuf<uint32_t> g_cig, g_order;
+    dbuf<bsw_gresult> g_res;
+    dbuf<bsw_adtask> a_tasks;         /* local alignment (bsw_align_batch) */
+    dbuf<unsigned long long> a_bl;
+    dbuf<bsw_kswr> a_res;
+    std::vector<refbatch_req> ref_queue;
+    int device0() const { return devs[0].device; }
+    hipStream_t stream0() const { return devs[0].streams[0]; }
+};
+
+struct bsw_dev_batch {
+    uint64_t n = 0;
+    bsw_dparams P{};
+    int variant = 0;
+    stage_t st;                       /* device buffers of the batch (host side released after upload) */
+    uint64_t seq_words = 0;
+    batch_plan plan;
+    uint64_t launches = 0;
+    uint64_t h2d_bytes = 0;           /* bytes the upload moved over PCIe */
+};
+
+/* ---- bsw_ctx.hip ---- */
+BSW_LOCAL int wait_event(bsw_ctx *ctx, errs &e, hipEvent_t ev);
+BSW_LOCAL int sync_stream(bsw_ctx *ctx, errs &e, hipStream_t st, hipEvent_t ev);
+BSW_LOCAL bool is_registered(const void *p, size_t len);
+BSW_LOCAL int check_params(errs &e, const bsw_params *p, bsw_dparams *dp);
+BSW_LOCAL int mat_max(const int8_t *mat);
+BSW_LOCAL int gap_limit(const bsw_params *p, int mx, int qlen, int end_bonus);
+BSW_LOCAL size_t nwords(int len);
+BSW_LOCAL int busy_check(bsw_ctx *ctx, const char *what);
+
+/* ---- bsw_batch.hip ---- */
+/* How one batch is cut into kernel launches lives in batch_plan (above); a chunk's host pass leaves this: */
+struct chunk_info {
+    size_t words = 0;                 /* seq words the chunk needs */
+    const uint8_t *lo = nullptr, *hi = nullptr;   /* span of every sequence the chunk references */
+    size_t sum_len = 0;               /* bytes referenced (= gather size) */
+    bool direct = false;              /* raw bytes are DMA'd straight out of registered memory */
+    bool rev_left = false;            /* left queries sit forwards in raw, their offsets point at the last base (bsw_submit_ref) */
+    uint32_t raw_bias = 0;            /* direct: rawoff holds the low 32 bits of the host pointers, raw byte = off - bias */
+    bool packed = false;              /* the caller's sequences are 4-bit packed words already (bsw_submit_packed): they are
+                                         DMA'd straight into `seq`, no pack kernel */
+    batch_plan plan;
+    bsw_binparams bp;
+};
+
+struct gate_turn {                    /* this chunk's place in its device's input-DMA order */
+    h2d_gate *gate = nullptr;
+    size_t seq = 0;
+    hipEvent_t ev = nullptr;
+    std::atomic<int> *abort_flag = nullptr;
+};
+BSW_LOCAL size_t order_capacity(size_t n);
+BSW_LOCAL int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams &bp);
+BSW_LOCAL bool narrow_foldable(const bsw_binparams &bp);
+BSW_LOCAL void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_t *dep);
+BSW_LOCAL const fork_t *fork_for(const bsw_ctx *ctx, hipStream_t s);
+BSW_LOCAL int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
+                            uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches,
+                            const fork_t *fk = nullptr, bsw_pair *d_pair = nullptr);
+BSW_LOCAL int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params &p, const bsw_dparams &dp,
+                        const bsw_task *tasks, size_t n, bsw_result *out, int gather_threads, const gate_turn *turn = nullptr, bool packed = false);
+
+/* ---- bsw_scalar.hip: the queue the drop-in scalar entry points share ---- */
+struct scalar_req {
+    int kind = 0;                     /* 0 ksw_extend2, 1 ksw_align2, 2 ksw_global2: all three share the queue and the trip */
+    bsw_params p;
+    bsw_ext_task t;                   /* extend */
+    bsw_ext x;
+    bsw_atask at;                     /* align */
+    bsw_kswr ar;
+    bsw_gtask gt;                     /* global */
+    bsw_gresult gr;
+    int cap = 0;                      /* CIGAR words this call can take (0: score only) */
+    std::vector<uint32_t> cg;
+    int rc = 0;
+    bool done = false;
+};
+BSW_LOCAL void scalar_call(scalar_req &req);
+
+#endif

@@ -1,0 +1,287 @@
+/*
+ * bsw_wire.hip — the reference's wire format end to end: bsw_refbatch_submit / _wait / _run over 256 KiB task batches and 16 KiB result batches (bwa_mem_sw.v:163-170, task_parse.v:1931-1940)
+ * (part of the host side of libbwasw_mi355.so; shared types and the functions that cross files: bsw_internal.h)
+ */
+#include "bsw_internal.h"
+
+/* ---- reference wire format end to end (F1) -----------------------------------------
+ * bsw_refbatch_submit queues 256 KiB task batches; bsw_refbatch_wait parses the 8-word headers on the host
+ * (task_parse.v:1931-1940), DMAs the batches as they are, unpacks the nibble streams on the GPU
+ * (bsw_wire_pack_kernel) and runs everything queued as one device batch. */
+extern "C" int bsw_refbatch_submit(bsw_ctx *ctx, const uint32_t *in_words, uint32_t *out_words)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!in_words || !out_words) return fail(ctx->err, BSW_E_INVAL, "bsw_refbatch_submit: NULL argument");
+    int rc = busy_check(ctx, "bsw_refbatch_submit");
+    if (rc) return rc;
+    if (ctx->ref_queue.size() >= BSW_REFBATCH_MAX_INFLIGHT) return fail(ctx->err, BSW_E_BUSY, "%d task batches already in flight", BSW_REFBATCH_MAX_INFLIGHT);
+    if (in_words[2] > BSW_REFBATCH_MAX_TASKS) return fail(ctx->err, BSW_E_LIMIT, "task batch announces %u tasks (> %d)", in_words[2], BSW_REFBATCH_MAX_TASKS);
+    ctx->ref_queue.push_back(refbatch_req{in_words, out_words});
+    return BSW_OK;
+}
+
+/* one run of queued batches [q0, q1) that share G0/G1 */
+/* queued batches [q0, q1) (same scoring header) -> one device batch on stream s, nothing waited for: headers parsed on
+ * host threads, batches DMA'd as they are, nibble streams unpacked on the GPU.  *n_out = tasks enqueued (0: nothing
+ * in flight, the result batches are already written). */
+/* wire batches per device batch and device batches in flight: measured best at 16 x 4 (profiles/r2/wire_format_rate.jsonl).
+ * 16 batches = ~13 k seeds stay below the lane kernels' minimum batch on purpose: a lane launch costs one wave's full
+ * duration (1.6 ms per side) however few seeds it holds, the wave-per-seed kernel finishes such a group sooner. */
+#define REFBATCH_GROUP 16
+#define REFBATCH_SLOTS 4
+static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int zdrop, stage_t &st, hipStream_t s, size_t *n_out)
+{
+    errs &e = ctx->err;
+    *n_out = 0;
+    const uint32_t *W0 = ctx->ref_queue[q0].in;
+    bsw_params p;
+    bsw_default_params(&p);                       /* matrix a=1,b=4,N=-1 is hard-wired (sw_extend.v:1915-1940) */
+    p.o_del = (int)(W0[0] & 0xff); p.e_del = (int)((W0[0] >> 8) & 0xff);
+    p.o_ins = (int)((W0[0] >> 16) & 0xff); p.e_ins = (int)((W0[0] >> 24) & 0xff);
+    p.pen_clip5 = (int)(W0[1] & 0xff); p.pen_clip3 = (int)((W0[1] >> 8) & 0xff);
+    p.w = (int)((W0[1] >> 16) & 0xff);
+    p.zdrop = zdrop; p.variant = variant; p.max_band_try = 2;
+    bsw_dparams dp;
+    int rc = check_params(e, &p, &dp);
+    if (rc) return rc;
+    size_t n = 0;
+    for (size_t q = q0; q < q1; ++q) n += ctx->ref_queue[q].in[2];
+    if (n == 0) {
+        for (size_t q = q0; q < q1; ++q) memset(ctx->ref_queue[q].out, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
+        return BSW_OK;
+    }
+    const size_t nb = q1 - q0, wire_words = nb * (size_t)BSW_REFBATCH_IN_WORDS;
+    hipError_t he;
+    if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_woff.reserve(n + 1)) != hipSuccess ||
+        (he = st.h_out.reserve(n + 1)) != hipSuccess || (he = st.h_raw.reserve(wire_words * 4 + RAW_SLACK)) != hipSuccess)
+        return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    /* headers -> task records (host: 8 words per task) */
+    chunk_info ci;
+    rc = fill_binparams(e, &p, ctx->cfg.kernel, ci.bp);
+    if (rc) return rc;
+    bsw_binparams &bp = ci.bp;
+    uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0};
+    uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0;
+    uint64_t acc = 0;
+    /* pass 1 (cheap): where every batch's tasks and sequence words start */
+    std::vector<uint64_t> wbase(nb + 1, 0), tbase(nb + 1, 0);
+    for (size_t q = q0; q < q1; ++q) {
+        const uint32_t *W = ctx->ref_queue[q].in;
+        const uint32_t nt = W[2];
+        uint64_t words = 0;
+        for (uint32_t i = 0; i < nt; ++i) {
+            const uint32_t *H = &W[8 + 8 * i];
+            const int lq = (int)(H[0] & 0xff), lt = (int)((H[0] >> 16) & 0x7ff), rq = (int)(H[1] & 0xff), rt = (int)((H[1] >> 16) & 0x7ff);
+            words += (lq ? nwords(lq) + nwords(lt) : 0) + (rq ? nwords(rq) + nwords(rt) : 0);
+        }
+        wbase[q - q0 + 1] = wbase[q - q0] + words;
+        tbase[q - q0 + 1] = tbase[q - q0] + nt;
+    }
+    acc = wbase[nb];
+    /* pass 2 (parallel over batches): records, class counts, and the batch itself into pinned staging */
+    struct part { uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0; int rc = 0; errs e; };
+    const size_t nth = std::max<size_t>(1, std::min<size_t>((size_t)ctx->cfg.pack_threads, nb / 4));
+    std::vector<part> parts(nth);
+    auto parse = [&](size_t t) {
+        part &pt = parts[t];
+        for (size_t q = q0 + t; q < q1; q += nth) {
+            const uint32_t *W = ctx->ref_queue[q].in;
+            const uint32_t nt = W[2];
+            uint64_t a2 = wbase[q - q0];
+            size_t ti = (size_t)tbase[q - q0];
+            const int64_t base = nt ? (int64_t)(8 + 8 * nt) - (int64_t)W[8 + 2] : 0;
+            for (uint32_t i = 0; i < nt; ++i, ++ti) {
+                const uint32_t *H = &W[8 + 8 * i];
+                bsw_dtask &d = st.h_tasks.p[ti];
+                bsw_wireoff &wo = st.h_woff.p[ti];
+                memset(&d, 0, sizeof(d));
+                const int lq = (int)(H[0] & 0xff), lt = (int)((H[0] >> 16) & 0x7ff), rq = (int)(H[1] & 0xff), rt = (int)((H[1] >> 16) & 0x7ff);
+                const int64_t pos = base + (int64_t)H[2];
+                if (pos < 8 + 8 * (int64_t)nt || pos + (lq + rq + lt + rt + 7) / 8 > BSW_REFBATCH_IN_WORDS) {
+                    pt.rc = fail(pt.e, BSW_E_INVAL, "malformed task batch (task %u: data position)", i);
+                    return;
+                }
+                const int h0 = (int)(H[4] & 0xff);
+                if (h0 <= 0) { pt.rc = fail(pt.e, BSW_E_INVAL, "task batch: task %u has h0 <= 0", i); return; }
+                wo.nib = ((uint64_t)(q - q0) * BSW_REFBATCH_IN_WORDS + (uint64_t)pos) * 8u;
+                wo.lqlen = (uint16_t)lq; wo.rqlen = (uint16_t)rq; wo.ltlen = (uint16_t)lt; wo.rtlen = (uint16_t)rt;
+                if (lq) { d.lq_off = (uint32_t)a2; a2 += nwords(lq); d.lt_off = (uint32_t)a2; a2 += nwords(lt); }
+                if (rq) { d.rq_off = (uint32_t)a2; a2 += nwords(rq); d.rt_off = (uint32_t)a2; a2 += nwords(rt); }
+                d.lqlen = (uint16_t)lq; d.rqlen = (uint16_t)rq; d.ltlen = (uint16_t)lt; d.rtlen = (uint16_t)rt;
+                /* H5/H6 = {max_del[31:16], max_ins[15:0]}: the band limit the RTL applies (proc_element.v:925,933).  A
+                 * non-positive limit (never written by bwa: both are >= 1) reads as 1, exactly as bsw_refbatch_decode maps it,
+                 * so a malformed header gives the same band through either entry point */
+                auto lim = [](uint32_t h) {
+                    const int mi = (int)(int16_t)(h & 0xffff), md = (int)(int16_t)(h >> 16);
+                    const int l = mi < md ? mi : md;
+                    return (uint16_t)(l < 1 ? 1 : l);
+                };
+                d.wlim_l = lim(H[5]); d.wlim_r = lim(H[6]);
+                d.h0 = h0; d.init_score = (int)(int16_t)(H[3] & 0xffff); d.qbeg = (int)(H[3] >> 16); d.tag = H[7];
+                const int wc = bsw_wave_class_of(&bp, std::max(lq, rq));
+                ++pt.cw_all[wc];
+                const int bits = bsw_seed_lane_bits(&bp, lq, rq, h0);
+                if (!bits) ++pt.cw[wc];
+                else { ++pt.n_lane; if (lq) ++pt.cl[bsw_side_lane_class(&bp, bits, lq)]; if (rq) ++pt.cr[bsw_side_lane_class(&bp, bits, rq)]; }
+            }
+            memcpy((uint32_t *)st.h_raw.p + (q - q0) * (size_t)BSW_REFBATCH_IN_WORDS, W, BSW_REFBATCH_IN_WORDS * sizeof(uint32_t));
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nth; ++t) th.emplace_back(parse, t);
+        parse(0);
+        for (auto &x : th) x.join();
+    }
+    for (const part &pt : parts) {
+        if (pt.rc) { e = pt.e; return pt.rc; }
+        for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) { cw_all[c] += pt.cw_all[c]; cw[c] += pt.cw[c]; }
+        for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { cl[c] += pt.cl[c]; cr[c] += pt.cr[c]; }
+        n_lane += pt.n_lane;
+    }
+    if (ctx->cfg.kernel == BSW_KERNEL_AUTO && !lane_bins_pay(n_lane, cl, cr)) bp.lane_on = 0;
+    if (bp.lane_on && narrow_foldable(bp)) narrow_fold(bp, cl, cr, nullptr);     /* (wire-format groups: one launch per side) */
+    if (!bp.lane_on) { memcpy(cw, cw_all, sizeof(cw)); memset(cl, 0, sizeof(cl)); memset(cr, 0, sizeof(cr)); n_lane = 0; }
+    batch_plan &pl = ci.plan;
+    pl = batch_plan();
+    for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) pl.wave_start[c + 1] = pl.wave_start[c] + cw[c];
+    uint32_t cur = pl.wave_start[BSW_MAX_WAVE_CLASSES];
+    pl.lane_all_off = cur; pl.lane_all_cnt = n_lane; cur += n_lane;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { pl.laneL_off[c] = cur; cur += cl[c]; }
+    pl.laneL_off[BSW_MAX_LANE_CLASSES] = cur;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { pl.laneR_off[c] = cur; cur += cr[c]; }
+    pl.laneR_off[BSW_MAX_LANE_CLASSES] = cur;
+    pl.redo_off = cur; pl.order_len = cur + n_lane;
+    pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
+    /* (pl.dep stays all ones: the wire-format groups run their classes on one stream) */
+    memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
+    bp.lane_all_off = pl.lane_all_off;
+    memcpy(bp.laneL_off, pl.laneL_off, sizeof(bp.laneL_off));
+    memcpy(bp.laneR_off, pl.laneR_off, sizeof(bp.laneR_off));
+    /* device: wire batches -> seq, bins, DP kernels, results */
+    if ((he = st.d_raw.reserve(wire_words * 4 + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve((size_t)acc + 4)) != hipSuccess ||
+        (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_woff.reserve(n + 1)) != hipSuccess ||
+        (he = st.d_order.reserve(order_capacity(n))) != hipSuccess || (he = st.d_bins.reserve(BSW_BIN_WORDS)) != hipSuccess ||
+        (he = st.d_out.reserve(n + 1)) != hipSuccess)
+        return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    HIPCHK(e, hipMemcpyAsync(st.d_raw.p, st.h_raw.p, wire_words * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_woff.p, st.h_woff.p, n * sizeof(bsw_wireoff), hipMemcpyHostToDevice, s));
+    HIPCHK(e, bsw::launch_wire_pack((const uint32_t *)st.d_raw.p, st.d_tasks.p, st.d_woff.p, (uint32_t)n, st.d_seq.p, s));
+    HIPCHK(e, bsw::launch_bin(bp, st.d_seq.p, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
+    rc = enqueue_batch(e, dp, variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, pl, st.d_out.p, s, nullptr);
+    if (rc) return rc;
+    /* the result DMA is issued by refbatch_collect once the kernels are done: a copy queued now would sit in its DMA
+     * engine's ring until then and hold up the next group's input copies queued behind it */
+    *n_out = n;
+    return BSW_OK;
+}
+
+/* wait for an enqueued group and write its 16 KiB result batches (host threads, one batch at a time each) */
+static int refbatch_collect(bsw_ctx *ctx, size_t q0, size_t q1, size_t n, stage_t &st, hipStream_t s, hipEvent_t ev)
+{
+    errs &e = ctx->err;
+    {
+        const int rc0 = sync_stream(ctx, e, s, ev);
+        if (rc0) return rc0;
+        HIPCHK(e, hipMemcpyAsync(st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
+    }
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
+    int rc = sync_stream(ctx, e, s, ev);
+    if (rc) return rc;
+    if (dbg) fprintf(stderr, "[bsw] wire:   waited %.3f ms for the GPU\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+    const size_t nb = q1 - q0;
+    std::vector<size_t> tbase(nb + 1, 0);
+    for (size_t q = q0; q < q1; ++q) tbase[q - q0 + 1] = tbase[q - q0] + ctx->ref_queue[q].in[2];
+    const size_t nth = std::max<size_t>(1, std::min<size_t>((size_t)ctx->cfg.pack_threads, nb / 4));
+    std::vector<int> trc(nth, 0);
+    auto enc = [&](size_t t) {
+        for (size_t q = q0 + t; q < q1; q += nth) {
+            const uint32_t nt = ctx->ref_queue[q].in[2];
+            memset(ctx->ref_queue[q].out, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
+            const int r = bsw_refbatch_encode_results(st.h_out.p + tbase[q - q0], nt, ctx->ref_queue[q].out);
+            if (r < 0) trc[t] = r;
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nth; ++t) th.emplace_back(enc, t);
+    enc(0);
+    for (auto &x : th) x.join();
+    for (int r : trc)
+        if (r < 0) return fail(e, r, "result batch encode");
+    return BSW_OK;
+}
+
+extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
+{
+    if (!ctx) return BSW_E_INVAL;
+    int rc = busy_check(ctx, "bsw_refbatch_wait");
+    if (rc) { ctx->ref_queue.clear(); return rc; }
+    errs &e = ctx->err;
+    if (variant != BSW_VARIANT_H && variant != BSW_VARIANT_M) { ctx->ref_queue.clear(); return fail(e, BSW_E_INVAL, "bad variant"); }
+    if (hipSetDevice(ctx->device0()) != hipSuccess) { ctx->ref_queue.clear(); return fail(e, BSW_E_HIP, "hipSetDevice"); }
+    const size_t nq = ctx->ref_queue.size();
+    /* Runs of batches with the same scoring header become device batches of at most REFBATCH_GROUP wire batches, up to
+     * REFBATCH_SLOTS of them in flight: the host parses the next group and writes an earlier group's result batches
+     * while the others are on the GPU (the reference's manager keeps its four TBB/RBB pairs busy the same way,
+     * batch_manager.v:418,745-773). */
+    dev_state &dev = ctx->devs[0];
+    static const size_t grp_tune = getenv("BSW_REFBATCH_GROUP") ? (size_t)std::max(1, atoi(getenv("BSW_REFBATCH_GROUP"))) : (size_t)REFBATCH_GROUP;   /* (measurements) */
+    const size_t grp_env = grp_tune;
+    const size_t NS = std::max<size_t>(1, std::min<size_t>(REFBATCH_SLOTS, dev.slots.size()));
+    const size_t slot_of[REFBATCH_SLOTS] = {0, 1, 2, 3};
+    struct flight { bool active = false; size_t q0 = 0, q1 = 0, n = 0; } fl[REFBATCH_SLOTS];
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = tnow();
+    auto collect = [&](size_t sl) -> int {
+        if (!fl[sl].active) return BSW_OK;
+        fl[sl].active = false;
+        const double t0 = tnow();
+        const int r = refbatch_collect(ctx, fl[sl].q0, fl[sl].q1, fl[sl].n, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], dev.events[slot_of[sl]]);
+        if (dbg) fprintf(stderr, "[bsw] wire: collect slot %zu batches [%zu,%zu): +%.3f .. +%.3f ms\n", sl, fl[sl].q0, fl[sl].q1, t0 - t_start, tnow() - t_start);
+        return r;
+    };
+    auto drain = [&]() { for (size_t sl = 0; sl < NS; ++sl) if (fl[sl].active) { errs quiet; (void)sync_stream(ctx, quiet, dev.streams[slot_of[sl]], dev.events[slot_of[sl]]); fl[sl].active = false; } };
+    size_t k = 0;
+    for (size_t q0 = 0; q0 < nq;) {
+        size_t q1 = q0 + 1;
+        while (q1 < nq && q1 - q0 < grp_env && ctx->ref_queue[q1].in[0] == ctx->ref_queue[q0].in[0] && ctx->ref_queue[q1].in[1] == ctx->ref_queue[q0].in[1]) ++q1;
+        if (nq - q1 < grp_env / 2)                                 /* no runt group at the end of a run */
+            while (q1 < nq && ctx->ref_queue[q1].in[0] == ctx->ref_queue[q0].in[0] && ctx->ref_queue[q1].in[1] == ctx->ref_queue[q0].in[1]) ++q1;
+        const size_t sl = k++ % NS;
+        rc = collect(sl);
+        size_t n_enq = 0;
+        const double te = tnow();
+        if (!rc) rc = refbatch_enqueue(ctx, q0, q1, variant, zdrop, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], &n_enq);
+        if (dbg) fprintf(stderr, "[bsw] wire: enqueue slot %zu batches [%zu,%zu) %zu tasks: +%.3f .. +%.3f ms\n", sl, q0, q1, n_enq, te - t_start, tnow() - t_start);
+        if (rc) {
+            /* a failure half-way through refbatch_enqueue leaves copies out of the queued batches / kernels on this slot's
+             * stream with fl[sl].active still false: drain that stream too before the caller gets its buffers back */
+            { errs quiet; (void)sync_stream(ctx, quiet, dev.streams[slot_of[sl]], dev.events[slot_of[sl]]); }
+            drain(); ctx->ref_queue.clear(); return rc;
+        }
+        if (n_enq) { fl[sl].active = true; fl[sl].q0 = q0; fl[sl].q1 = q1; fl[sl].n = n_enq; }
+        q0 = q1;
+    }
+    for (size_t sl = 0; sl < NS; ++sl) {
+        const size_t s2 = (k + sl) % NS;                                  /* oldest first */
+        rc = collect(s2);
+        if (rc) { drain(); ctx->ref_queue.clear(); return rc; }
+    }
+    ctx->ref_queue.clear();
+    return (int)nq;
+}
+
+extern "C" int bsw_refbatch_run(bsw_ctx *ctx, const uint32_t *in_words, uint32_t *out_words, int variant, int zdrop)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!ctx->ref_queue.empty()) return fail(ctx->err, BSW_E_BUSY, "bsw_refbatch_run: task batches are queued (call bsw_refbatch_wait)");
+    int rc = bsw_refbatch_submit(ctx, in_words, out_words);
+    if (rc) return rc;
+    const uint32_t n = in_words[2];
+    rc = bsw_refbatch_wait(ctx, variant, zdrop);
+    return rc < 0 ? rc : (int)n;
+}
+

@@ -53,7 +53,7 @@ assert EXT_TASK.itemsize == 40 and SYNTH.itemsize == 72 and CONFIG.itemsize == 1
 
 REFBATCH_IN_WORDS, REFBATCH_OUT_WORDS, REFBATCH_MAX_TASKS = 65536, 4096, 819
 KERNEL_AUTO, KERNEL_WAVE, KERNEL_LANE = 0, 1, 2
-LANE_AUTO_MIN = 26000          # BSW_KERNEL_AUTO uses lane bins only from this many eligible seeds PER LAUNCHED SIDE (bsw_api.hip)
+LANE_AUTO_MIN = 26000          # BSW_KERNEL_AUTO uses lane bins only from this many eligible seeds PER LAUNCHED SIDE (bsw_internal.h)
 VARIANT_H, VARIANT_M = 0, 1
 
 ERRORS = {0: "BSW_OK", -1: "BSW_E_NODEVICE", -2: "BSW_E_INVAL", -3: "BSW_E_LIMIT", -4: "BSW_E_HIP",

@@ -1,5 +1,5 @@
-// Sanitizer run of the C++ batch manager's host logic (validation, chunk layout, class counts, plan replay): bsw_api.hip is compiled
-// host-only with -fsanitize=address,undefined and linked against stubs for the kernel launchers.
+// Sanitizer run of the C++ batch manager's host logic (validation, chunk layout, class counts, plan replay): the host-side .hip files
+// (bsw_ctx / bsw_batch / bsw_scalar / bsw_wire / bsw_f4) are compiled host-only with -fsanitize=address,undefined and linked against stubs for the kernel launchers.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -13,13 +13,14 @@ namespace bsw {
 static const int kW[] = {1, 2, 3, 4, 8, 16};
 int wave_class_count() { return 6; }
 int wave_class_cols(int c) { return kW[c] * 64; }
-static const int kLb[] = {8, 8, 16}, kLc[] = {136, 232, 136};
-int lane_class_count() { return 3; }
+static const int kLb[] = {8, 8, 8, 16}, kLc[] = {72, 136, 232, 136};
+int lane_class_count() { return 4; }
 int lane_class_cols(int c) { return kLc[c]; }
 int lane_class_bits(int c) { return kLb[c]; }
-hipError_t launch_wave(int, int, const bsw_dparams &, const uint64_t *, const bsw_dtask *, const uint32_t *, uint32_t, const uint32_t *, bsw_result *, hipStream_t) { return hipSuccess; }
+hipError_t launch_wave(int, int, const bsw_dparams &, const uint64_t *, const bsw_dtask *, const uint32_t *, uint32_t, const uint32_t *, uint32_t *, bsw_result *, hipStream_t) { return hipSuccess; }
 hipError_t launch_lane(int, int, const bsw_dparams &, int, const uint64_t *, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, hipStream_t) { return hipSuccess; }
-hipError_t launch_finalize(const bsw_dparams &, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, uint32_t *, uint32_t *, hipStream_t) { return hipSuccess; }
+hipError_t launch_finalize(const bsw_dparams &, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, uint32_t *, uint32_t *, bsw_pair *, hipStream_t) { return hipSuccess; }
+hipError_t launch_pairs_from_results(const uint32_t *, uint32_t, const uint32_t *, const bsw_result *, bsw_pair *, hipStream_t) { return hipSuccess; }
 hipError_t launch_pack(const uint8_t *, const bsw_dtask *, const bsw_rawoff *, uint32_t, uint32_t, int, const uint8_t *, int64_t, const bsw_refx *, uint64_t *, hipStream_t) { return hipSuccess; }
 hipError_t launch_wire_pack(const uint32_t *, const bsw_dtask *, const bsw_wireoff *, uint32_t, uint64_t *, hipStream_t) { return hipSuccess; }
 hipError_t launch_bin(const bsw_binparams &, const uint64_t *, const bsw_dtask *, uint32_t, uint32_t *, uint32_t *, hipStream_t) { return hipSuccess; }

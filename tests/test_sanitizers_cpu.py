@@ -21,12 +21,16 @@ def test_host_c_code_under_asan_ubsan(tmp_path):
 
 
 def test_batch_manager_host_logic_under_asan_ubsan(tmp_path):
-    """bsw_api.hip compiled host-only with sanitizers, kernel launchers stubbed: validation, SWAR packing, binning."""
+    """The host-side translation units compiled host-only with sanitizers, kernel launchers stubbed: validation, SWAR packing,
+    binning, the narrow-class decision."""
     hipcc = "/opt/rocm/bin/hipcc"
     inc = ["-I", os.path.join(ROOT, "include")]
     san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
     objs = []
-    for name, src, cc in (("api", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_api.hip"), "hip"),
+    csrc = os.path.join(ROOT, "bwa-mem-sw_amd", "csrc")
+    for name, src, cc in (("ctx", os.path.join(csrc, "bsw_ctx.hip"), "hip"), ("batch", os.path.join(csrc, "bsw_batch.hip"), "hip"),
+                          ("scalar", os.path.join(csrc, "bsw_scalar.hip"), "hip"), ("wire", os.path.join(csrc, "bsw_wire.hip"), "hip"),
+                          ("f4", os.path.join(csrc, "bsw_f4.hip"), "hip"),
                           ("plan", os.path.join(ROOT, "tests", "asan_plan.cpp"), "hip"),
                           ("synth", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_synth.c"), "c"),
                           ("glue", os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_glue.c"), "c"),
