@@ -95,6 +95,14 @@ with host.BswContext(device=0, kernel=host.KERNEL_WAVE) as c:
         tasks, arena = host.make_tasks(seeds)
         p = host.default_params(w=300, zdrop=0)
         assert_same(c.extend_pairs(p, tasks), orc.pair_batch(p, tasks, nthreads=8), tasks)
+# the redo list of the lane kernels (its length is counted on the device) through the same kernel
+with host.BswContext(device=0, kernel=host.KERNEL_LANE) as c:
+    for over in (dict(w=8, zdrop=0), dict(w=3), dict(variant=1, w=12, max_band_try=3)):
+        p = host.default_params(**over)
+        tasks, arena = host.synth_tasks(20000, seed=81, seed_len_min=19, seed_len_max=60, seed_at_start=0, indel_rate=0.02, junk_frac=0.1, n_rate=0.001)
+        want = orc.pair_batch(p, tasks, nthreads=8)
+        assert int((want["left"]["aw"] > p["w"][0]).sum() + (want["right"]["aw"] > p["w"][0]).sum()) > 20       # band retries happen
+        assert_same(c.extend_pairs(p, tasks), want, tasks)
 print("ok")
 """
 
