@@ -60,3 +60,31 @@ def test_compiler_leaves_the_accumulator_registers_alone():
              and int(re.search(r"\ba\[?(\d+)", l).group(1)) not in allowed]
     assert not stray, stray[:5]
     assert out.count("v_accvgpr_read_b32") > 100 and out.count("v_accvgpr_write_b32") > 100
+
+
+def test_three_wave_kernel_spills_only_outside_its_row_loop():
+    """bsw_lane2_kernel<9, 3, ...> (the 72-column class) is held to 168 VGPRs so that three waves share a SIMD; the compiler
+    pays for that with a dozen spills.  They must sit in the prologue and in the cold code behind the row loop (target
+    staging one row in 64, query-N bodies) — a scratch access inside the row loop would cost every row a memory round trip."""
+    src = os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_lane2_kernel.hip")
+    out = subprocess.check_output(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DBSW_L2_ASM_BODY=1", "-Wno-unused-function",
+                                   "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", src, "-o", "-"], stderr=subprocess.DEVNULL, text=True)
+    seen = 0
+    for m in re.finditer(r"^(_ZN3bsw16bsw_lane2_kernelILi9ELi3E\w+):.*?s_endpgm", out, re.S | re.M):
+        body = m.group(0).split("\n")
+        labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+        loops = []
+        for i, l in enumerate(body):
+            b = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+            if b and labels.get(b.group(1), 1 << 30) < i:
+                lo = labels[b.group(1)]
+                loops.append((sum(1 for x in body[lo:i] if "v_pk_" in x), lo, i))
+        # the row loop: the first back edge that closes around the hot block bodies (the cold code — target staging, query-N
+        # bodies — is laid out BEHIND it and jumps back into it: those later back edges span it too)
+        npk, lo, hi = min((x for x in loops if x[0] > 1000 and x[2] - x[1] > 3000), key=lambda x: x[2])
+        inside = [x.strip() for x in body[lo:hi] if "scratch_" in x]
+        assert not inside, (m.group(1), inside[:4])
+        vg = re.search(r"\.vgpr_count:\s+(\d+)", out[out.index(".name:           " + m.group(1)):])
+        assert vg and int(vg.group(1)) <= 168, vg and vg.group(1)
+        seen += 1
+    assert seen == 4                                           # variant H / M x shared / separate gap penalties
