@@ -20,7 +20,8 @@ def main():
                                os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_lane2_kernel.hip")], stderr=subprocess.DEVNULL)
         text = open(out).read()
     lines = text.split("\n")
-    hdr = [i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l][0]
+    k0 = [i for i, l in enumerate(lines) if l.startswith("_ZN3bsw16bsw_lane2_kernelILi17ELi2ELb0ELb1E")][0]   # the headline instantiation
+    hdr = [i for i, l in enumerate(lines) if i > k0 and "Loop Header: Depth=1" in l][0]
     blocks, cur = [], None
     for i in range(hdr, len(lines)):
         l = lines[i]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/pmc_latest.json: the counters bench.py quotes in its `roofline` object, from a tools/profile.sh output
-directory (separate rocprofv3 --pmc passes) + tools/isa_histogram.py.  HBM bytes per MI355X_MICROARCH.md's gfx950
+directory (separate rocprofv3 --pmc passes).  HBM bytes per MI355X_MICROARCH.md's gfx950
 correction: FETCH_SIZE (KiB) x 2 + WRITE_SIZE (KiB), summed over the DP kernels of one bsw_run step."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,6 @@ step = {k: v for k, v in allk.items() if any(x in k for x in ("lane2_kernel", "l
 fetch = sum(v.get("FETCH_SIZE", 0) for v in step.values())
 write = sum(v.get("WRITE_SIZE", 0) for v in step.values())
 main = max(step.items(), key=lambda kv: kv[1].get("avg_ns", 0))
-isa = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_histogram.py")]))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_hash: the code these counters belong to)
 out = {"workload": workload, "seeds_per_gpu": seeds, "source_hash": bench.kernel_source_hash(), "source": os.path.basename(os.path.dirname(d) if d.endswith(".json") else d.rstrip("/")),
@@ -24,7 +23,6 @@ out = {"workload": workload, "seeds_per_gpu": seeds, "source_hash": bench.kernel
        "valu_lane_insts_per_cell": round(main[1]["SQ_INSTS_VALU"] * 64 / cells, 2),
        "valu_issue_busy": round(main[1]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (main[1]["GRBM_GUI_ACTIVE"] / 8), 3),
        "waves_per_simd_avg": round(main[1]["SQ_WAVE_CYCLES"] * 4 / 1024 / (main[1]["GRBM_GUI_ACTIVE"] / 8), 2),
-       "peak_opcode_weighted_tops": isa["peak_opcode_weighted_tops"], "dense_path_valu_insts_per_pair_cell": isa["valu_insts_per_pair_cell"],
        "clock_ghz": round(main[1]["GRBM_GUI_ACTIVE"] / 8 / main[1]["avg_ns"], 3)}
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(out))
