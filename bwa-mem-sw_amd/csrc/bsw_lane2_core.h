@@ -677,12 +677,17 @@ struct lane2l {
         uint32_t mk2 = 0;                                   /* running row max: (m << 8) | absolute column, per half */
         uint32_t Fnz = 0xffffffffu, Lnz = 0;                /* K8: packed first / last non-zero column trackers */
         const int blo = u.jlo >> 3, bhi = imin(u.jhi >> 3, QB - 1), bem = u.jem >> 3;
+#ifdef BSW_L2L_ALLNQ
+        const uint32_t nblk = opaque_s(0xffffffffu);        /* (experiment: the query-N body in every block) */
+#else
         const uint32_t nblk = opaque_s(u.nblk);
+#endif
         uint32_t T[8], Wcur;
+        uint32_t WNcur = nblk != 0 ? wn(blo >> 1) : 0u;     /* (waves with query Ns) the N planes of the chunk that holds the first block */
         row.load8w(blo, T, Wcur);
         /* one block: `edge` is a compile-time property of the loop it runs in (below), only the N test is per block */
         /* one block.  KIND 0: the plain body; 1: the ragged body (the row's first / last block, columns in order behind
-         * scalar guards); 2: plain or query-N body by the wave's N mask — the only kind with a test per block */
+         * scalar guards); 2: the query-N body (a wave that holds an N somewhere runs it in every block) */
         const auto step = [&](const int b, auto edge_c, auto kind_c) {
             constexpr bool EDGE = decltype(edge_c)::value;
             constexpr int KIND = decltype(kind_c)::value;
@@ -698,15 +703,15 @@ struct lane2l {
             if constexpr (KIND == 0) B::template block8<EDGE, false>(T, Wc, 0u, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
             if constexpr (KIND == 1) B::template block8_seq<EDGE>(T, Wc, Bv2, k, ENDx, mi_in, EDGE ? (u.jhi & 7) : (u.jlo & 7), h1, f, mkb, nz8);
             if constexpr (KIND == 2) {
-                /* two mutually exclusive bodies as two consecutive `if`s, not an if/else: a body that is simply run or
-                 * skipped updates T[] in place, an if/else joins differently allocated versions with a v_mov per column */
-                const bool nq = ((nblk >> b) & 1u) != 0;
-                if (!nq) B::template block8<EDGE, false>(T, Wc, 0u, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
-                if (nq) {
-                    const uint32_t WNr = wn(b >> 1);
-                    const uint32_t WNc = (b & 1) ? (WNr >> 8) : WNr;        /* the block's N bits in bits 0..7 of each half */
-                    B::template block8<EDGE, true>(T, Wc, WNc, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
-                }
+                /* the query-N body in EVERY block of a wave that holds an N anywhere, no test per block: with zero N bits it
+                 * computes what the plain body does.  (Round 3 tested per block and ran the plain body where it could: a wave
+                 * of 128 N-holding queries has an N in 23 of its 29 blocks, and the tested loops cost every block 16 % —
+                 * such waves ran 1.31x as long as plain ones; they start first, and at one wave per SIMD and three rounds per
+                 * launch the longest waves set the launch's length: 250 bp lost 8.6 % to 8.6 % of its waves,
+                 * profiles/r4/lane2l_n_waves.json.)  The N bits of the NEXT block are fetched before this block's body. */
+                const uint32_t WNc = (b & 1) ? (WNcur >> 8) : WNcur;        /* the block's N bits in bits 0..7 of each half */
+                WNcur = wn(imin(b + 1, QB - 1) >> 1);
+                B::template block8<EDGE, true>(T, Wc, WNc, Bv2, D2, k, ENDx, mi_in, h1, f, mkb, nz8);
             }
             /* row max: the block's key carries the column inside the block; + j0 makes it absolute (< 256: low byte).
              * K8: nz8 = non-zero bits of the block's stored eh entries, seed A in [7:0], seed B in [23:16].
@@ -722,7 +727,7 @@ struct lane2l {
         using edge_t = std::integral_constant<bool, true>;
         using plain_t = std::integral_constant<int, 0>;
         using ragged_t = std::integral_constant<int, 1>;
-        using ntest_t = std::integral_constant<int, 2>;
+        using allnq_t = std::integral_constant<int, 2>;
         /* the blocks below every active seed's `end` first (mask-free bodies), then the ones that hold some seed's `end`:
          * two loops, so that the dense / edge decision costs no scalar instructions per block (at one wave per SIMD the
          * scalar instructions of the block loop take issue slots like everything else).  A wave whose queries hold no N
@@ -741,8 +746,8 @@ struct lane2l {
             for (; b <= be; ++b) step(b, edge_t{}, plain_t{});
             if (rl && b <= bhi) step(b, edge_t{}, ragged_t{});
         } else {
-            for (; b <= bd; ++b) step(b, dense_t{}, ntest_t{});
-            for (; b <= bhi; ++b) step(b, edge_t{}, ntest_t{});
+            for (; b <= bd; ++b) step(b, dense_t{}, allnq_t{});
+            for (; b <= bhi; ++b) step(b, edge_t{}, allnq_t{});
         }
         L2_STAMP(3);
         sfor<2>([&](auto xi) {

@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
     __shared__ uint4 lds_k4[NQ4][L::KEEP_NONE + 1];                 /* keep-mask table (match_words) */
     __shared__ uint32_t lds_k1[NR ? NR : 1][L::KEEP_NONE + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#ifdef BSW_L2L_WAVELOG
+    const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();      /* (profiling build: tools/wave_timeline.py) */
+#endif
     const uint32_t w0 = (blockIdx.x * 4u + (uint32_t)wv) * 128u + (uint32_t)lane;
     for (int b = (int)threadIdx.x; b <= L::KEEP_NONE; b += 256) {
 #pragma unroll
@@ -361,6 +364,11 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
         bsw_ext e;
         e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
         e.gscore = s.gscore; e.max_off = s.max_off; e.aw = P.w; e.cells = s.cells;
+#ifdef BSW_L2L_WAVELOG
+        e.max_off = (int)(wl_t0 & 0x7fffffffu); e.aw = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffffu);
+        e.cells = ((unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) | ((unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);
+        e.gscore = (int)__builtin_popcount(nblk);                           /* blocks with a query N in this wave */
+#endif
         if (side == 0) out[ti[x]].left = e; else out[ti[x]].right = e;
     });
 }

@@ -37,7 +37,8 @@ def test_block_loops_sit_on_the_instruction_grid(listing):
     for kern in ("Li29ELi1ELb0ELb1", "Li29ELi1ELb0ELb0", "Li29ELi1ELb1ELb1", "Li29ELi1ELb1ELb0"):
         ls = isa_align.loops(text, kern)
         # the block loops: one or two block bodies (>= 100 64-bit instructions) and little else
-        block = [l for l in ls if 100 <= l["wide"] and l["instructions"] <= 640]
+        # (a back edge that also spans a row's wave reductions is a short path of the ROW loop — a row of one block — not a block loop)
+        block = [l for l in ls if 100 <= l["wide"] and l["instructions"] <= 640 and not l["row_head"]]
         assert len(block) >= 4, (kern, ls)          # N-free dense / edge, general dense / edge (the latter with two back edges)
         for l in block:
             assert l["wide_off_grid"] <= 4, (kern, l)

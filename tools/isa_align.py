@@ -87,7 +87,8 @@ def loops(text, want):
                 if tgt < a and a - tgt > 600:
                     seg = [r for r in lst if tgt <= r[0] <= a]
                     out.append(dict(kernel=k, start=tgt, end=a, instructions=len(seg), scalar=sum(1 for x in seg if x[2].startswith("s_")),
-                                    wide=sum(1 for x in seg if x[1] >= 2), wide_off_grid=sum(1 for x in seg if x[1] >= 2 and x[0] % 8)))
+                                    wide=sum(1 for x in seg if x[1] >= 2), wide_off_grid=sum(1 for x in seg if x[1] >= 2 and x[0] % 8),
+                                    row_head=sum(1 for x in seg if "row_bcast:31" in x[3])))     # > 0: the span holds a row's wave reductions — a path of the ROW loop, not a block loop
     return out
 
 
