@@ -4,6 +4,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
+rm -rf gpurun_out/r4prof
 tools/profile.sh r4prof/head > /dev/null
 tools/profile_quick.sh r4prof/mixed --workload 150bp_w100_mixed_bins > /dev/null
 tools/profile_quick.sh r4prof/w250 --workload 250bp_w500 > /dev/null
