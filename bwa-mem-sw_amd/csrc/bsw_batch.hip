@@ -346,11 +346,13 @@ static void gather_raw(const bsw_task *tasks, const bsw_rawoff *ro, size_t n, bo
 }
 
 /* ---- device side of a chunk: DMA, pack, (fetch), bin, and optionally the DP kernels ---------- */
-BSW_LOCAL const fork_t *fork_for(const bsw_ctx *ctx, hipStream_t s)
+/* pipeline: the caller is a slot of the streaming pipeline — its chunks' tails are filled by the other slots' chunks, and a
+ * stream that waits for a flag holds up whatever shares its hardware queue, so the tail-fill mode stays out of it */
+BSW_LOCAL const fork_t *fork_for(const bsw_ctx *ctx, hipStream_t s, bool pipeline)
 {
     for (const dev_state &d : ctx->devs)
         for (size_t k = 0; k < d.streams.size(); ++k)
-            if (d.streams[k] == s) return k < d.forks.size() && d.forks[k].ok ? &d.forks[k] : nullptr;
+            if (d.streams[k] == s) return k < d.forks.size() && d.forks[k].ok && !(pipeline && d.forks[k].mode == 2) ? &d.forks[k] : nullptr;
     return nullptr;
 }
 
@@ -372,6 +374,48 @@ BSW_LOCAL int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const ui
     }
     if (pl.lane_all_cnt) {
         const int nlc = bsw::lane_class_count();
+        /* TAIL FILL (fork mode 2, §4.1b): the lane launches of the chunk as ONE chain — left sides narrowest class first, then
+         * right sides widest first: a long right side belongs to a short left side and the other way round, so every launch's
+         * seeds are ready as early as they can be — on up to three streams in rotation.  A launch waits for the events of the
+         * left-side launches that hold its seeds (plan.dep) and for the FLAG of the launch before it in the chain, which that
+         * kernel raises when its last workgroup has started (the looped 232-column kernel; another kernel's flag is raised behind
+         * it): from then on every slot that frees up stays free, so the next launch takes the ragged end and never a slot a
+         * wave of the wider kernel could have had.  250 bp / w = 500: the 232-column launches of both sides run back to back and
+         * the 136-column right sides fill the end, 16.6 - 17.1 ms per 1 M seeds -> 16.2 with two flags, (gpurun_out/r6p). */
+        struct link { int side, cls; uint32_t off, cnt; };
+        link chain[2 * BSW_MAX_LANE_CLASSES];
+        int nchain = 0;
+        bool chain_pays = false;
+        if (fk && fk->mode == 2) {
+            for (int c = 0; c < nlc; ++c)
+                if (pl.laneL_off[c + 1] - pl.laneL_off[c]) chain[nchain++] = link{0, c, pl.laneL_off[c], pl.laneL_off[c + 1] - pl.laneL_off[c]};
+            for (int c = nlc - 1; c >= 0; --c)
+                if (pl.laneR_off[c + 1] - pl.laneR_off[c]) chain[nchain++] = link{1, c, pl.laneR_off[c], pl.laneR_off[c + 1] - pl.laneR_off[c]};
+            for (int i = 0; i + 1 < nchain; ++i) chain_pays = chain_pays || bsw::lane_class_signals_tail(chain[i].cls);
+        }
+        if (chain_pays) {
+            const hipStream_t rot[3] = {s, fk->aux[0], fk->aux[1]};
+            hipStream_t lst[BSW_MAX_LANE_CLASSES] = {nullptr};
+            uint32_t target = 1u;                                       /* what the previous launch's flag reaches */
+            for (int i = 0; i + 1 < nchain; ++i) HIPCHK(e, hipStreamWriteValue32(s, fk->flags[i], 0u, 0));
+            HIPCHK(e, hipEventRecord(fk->ev_fork, s));                 /* everything queued on s so far (input DMAs, pack, bins), and the flags are down */
+            for (int a = 0; a < 2; ++a) HIPCHK(e, hipStreamWaitEvent(fk->aux[a], fk->ev_fork, 0));
+            for (int i = 0; i < nchain; ++i) {
+                const link &k = chain[i];
+                const hipStream_t ks = rot[i % 3];
+                if (k.side == 1)
+                    for (int lc = 0; lc < nlc; ++lc)
+                        if (lst[lc] && lst[lc] != ks && ((pl.dep[lc] >> k.cls) & 1)) HIPCHK(e, hipStreamWaitEvent(ks, fk->ev_left[lc], 0));
+                if (i > 0) HIPCHK(e, hipStreamWaitValue32(ks, fk->flags[i - 1], target, hipStreamWaitValueGte, 0xffffffffu));
+                HIPCHK(e, bsw::launch_lane(k.cls, variant, P, k.side, d_seq, d_tasks, d_order + k.off, k.cnt, d_out, ks, i + 1 < nchain ? fk->flags[i] : nullptr, &target));
+                HIPCHK(e, hipEventRecord(k.side ? fk->ev_right[k.cls] : fk->ev_left[k.cls], ks));
+                if (k.side == 0) lst[k.cls] = ks;
+                if (launches) ++*launches;
+            }
+            for (int i = 0; i < nchain; ++i)                             /* join: the slot stream waits for whatever ran elsewhere */
+                if (rot[i % 3] != s) HIPCHK(e, hipStreamWaitEvent(s, chain[i].side ? fk->ev_right[chain[i].cls] : fk->ev_left[chain[i].cls], 0));
+        } else {
+        if (fk && fk->mode != 1) fk = nullptr;                           /* (a chain that would gain nothing: plain launches on s) */
         /* The classes of a side side by side: the k-th non-empty class of a side (widest first: its waves run longest) goes
          * to stream k — the slot stream, then the auxiliary ones.  A right-side launch waits for exactly the left-side
          * launches that hold one of its seeds (plan.dep); streams are in-order, so only other streams' launches need an event. */
@@ -408,6 +452,7 @@ BSW_LOCAL int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const ui
                 if (lstream[c] && lstream[c] != s) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_left[c], 0));
                 if (rstream[c] && rstream[c] != s) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_right[c], 0));
             }
+        }
         }
         HIPCHK(e, bsw::launch_finalize(P, d_tasks, d_order + pl.lane_all_off, pl.lane_all_cnt, d_out,
                                        d_order + pl.redo_off, redo_cnt, d_pair, s));
@@ -1048,7 +1093,7 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         queued = true;
         rc = stage_device(e, st, stream, ci, n, rtasks != nullptr, ref, nullptr, &turn, d);
         if (!rc && pairs && (he = st.d_pair.reserve(n + 1)) != hipSuccess) rc = fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
-        if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr, fork_for(ctx, stream), pairs ? st.d_pair.p : nullptr);
+        if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr, fork_for(ctx, stream, true), pairs ? st.d_pair.p : nullptr);
         if (rc) return bail(rc);
         char *co = (char *)out + chunks[k].base * rec;
         pend.direct = is_registered(co, n * rec);

@@ -158,6 +158,8 @@ static void ctx_release(bsw_ctx *ctx)
             for (auto &f : d.forks) {
                 for (auto a : f.aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
                 if (f.ev_fork) (void)hipEventDestroy(f.ev_fork);
+                if (f.ev_fork_r) (void)hipEventDestroy(f.ev_fork_r);
+                for (uint32_t *fl : f.flags) if (fl) (void)hipFree(fl);
                 for (auto ev : f.ev_left) if (ev) (void)hipEventDestroy(ev);
                 for (auto ev : f.ev_right) if (ev) (void)hipEventDestroy(ev);
             }
@@ -224,11 +226,19 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
             d.streams.push_back(st);
             {
-                /* off unless BSW_FORK=1: with the narrow class folded wherever wider sides exist, the only workload with two
-                 * classes per side is 250 bp (136 + 232 columns) — 1 971 GCUPS forked, 1 974 not (gpurun_out/r4h, r4b) */
-                static const bool nofork = getenv("BSW_FORK") == nullptr;
+                /* The lane classes of one side on several streams.  Default (mode 2, stream 0 of a device only — the stream
+                 * resident batches and synchronous chunks run on): TAIL FILL, the narrower classes of a side are released
+                 * when the last workgroup of the widest class's launch has started (§4.1b: 250 bp, the 232-column launch's
+                 * ragged end).  BSW_FORK=1: every stream, all classes of a side released at once (round 4's first version:
+                 * 1 971 GCUPS on 250 bp against 1 974 unforked, gpurun_out/r4h).  BSW_FORK=0: none. */
+                static const int fork_env = getenv("BSW_FORK") ? atoi(getenv("BSW_FORK")) : -1;
                 fork_t f;
-                bool good = !nofork;
+                f.mode = fork_env == 1 ? 1 : (fork_env < 0 && s == 0 ? 2 : 0);
+                bool good = f.mode != 0;
+                if (f.mode == 2) {                  /* needs stream memory operations */
+                    int can = 0;
+                    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, d.device) != hipSuccess || !can) good = false;
+                }
                 /* the auxiliary streams run at the LOWEST priority: the widest class of a side (the slot stream's) has the
                  * longest waves and must get its slots first — released at the same instant, the narrow class's many short
                  * workgroups took half the slots and the long waves started late (right side 2.8 ms instead of 2.0,
@@ -237,10 +247,14 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
                 static const bool noprio = getenv("BSW_FORK_NOPRIO") != nullptr;
                 if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || noprio) least = 0;
                 for (int a = 0; a < BSW_FORK_AUX && good; ++a) good = hipStreamCreateWithPriority(&f.aux[a], hipStreamNonBlocking, least) == hipSuccess;
-                good = good && hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming) == hipSuccess;
+                good = good && hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming) == hipSuccess &&
+                       hipEventCreateWithFlags(&f.ev_fork_r, hipEventDisableTiming) == hipSuccess;
                 for (int c = 0; c < BSW_MAX_LANE_CLASSES && good; ++c)
                     good = hipEventCreateWithFlags(&f.ev_left[c], hipEventDisableTiming) == hipSuccess &&
                            hipEventCreateWithFlags(&f.ev_right[c], hipEventDisableTiming) == hipSuccess;
+                for (int k = 0; k < 2 * BSW_MAX_LANE_CLASSES && good && f.mode == 2; ++k)
+                    good = hipExtMallocWithFlags((void **)&f.flags[k], sizeof(uint64_t), hipMallocSignalMemory) == hipSuccess;
+                if (!good) (void)hipGetLastError();     /* (optional machinery: its failure is not the next launch's error) */
                 f.ok = good;
                 d.forks.push_back(f);              /* (not ok: the classes of a side run one after the other on the slot stream) */
             }

@@ -176,7 +176,11 @@ struct stage_t {
 #define BSW_FORK_AUX (BSW_MAX_LANE_CLASSES - 1)
 struct fork_t {
     hipStream_t aux[BSW_FORK_AUX] = {nullptr};
-    hipEvent_t ev_fork = nullptr, ev_left[BSW_MAX_LANE_CLASSES] = {nullptr}, ev_right[BSW_MAX_LANE_CLASSES] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_fork_r = nullptr, ev_left[BSW_MAX_LANE_CLASSES] = {nullptr}, ev_right[BSW_MAX_LANE_CLASSES] = {nullptr};
+    /* mode 2 (tail fill): a chunk's lane launches form a chain, each released when the LAST workgroup of the one before it
+     * has started — flags[i], signal memory written by launch i's kernel, waited for by launch i+1's stream */
+    uint32_t *flags[2 * BSW_MAX_LANE_CLASSES] = {nullptr};   /* (signal memory comes in 8-byte allocations) */
+    int mode = 0;                     /* 0 none, 1 all classes of a side at once (BSW_FORK=1), 2 tail fill */
     bool ok = false;
 };
 
@@ -280,7 +284,7 @@ BSW_LOCAL size_t order_capacity(size_t n);
 BSW_LOCAL int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams &bp);
 BSW_LOCAL bool narrow_foldable(const bsw_binparams &bp);
 BSW_LOCAL void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_t *dep);
-BSW_LOCAL const fork_t *fork_for(const bsw_ctx *ctx, hipStream_t s);
+BSW_LOCAL const fork_t *fork_for(const bsw_ctx *ctx, hipStream_t s, bool pipeline = false);
 BSW_LOCAL int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
                             uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches,
                             const fork_t *fk = nullptr, bsw_pair *d_pair = nullptr);

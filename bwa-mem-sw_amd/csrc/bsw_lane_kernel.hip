@@ -456,6 +456,7 @@ static const lane_class_t *lane_classes(int *n)
 int lane_class_count() { int n; lane_classes(&n); return n; }
 int lane_class_cols(int cls) { int n; return lane_classes(&n)[cls].qb * 8; }
 int lane_class_bits(int cls) { int n; return lane_classes(&n)[cls].bits; }
+bool lane_class_signals_tail(int cls) { int n; return cls >= 0 && lane_classes(&n)[cls].kind == K_LANE2L_29; }
 
 /* bsw_lane2_kernel.hip: two seeds per lane, packed 16-bit math, unrolled blocks — the 72-column class at three waves per
  * SIMD, the 136-column class at two; bsw_lane2l_kernel.hip: the same arithmetic with the blocks walked by a loop and the
@@ -464,10 +465,24 @@ bool lane2_params_ok(const bsw_dparams &P, int variant);
 hipError_t launch_lane2(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
                         uint32_t n, bsw_result *out, hipStream_t s);
 hipError_t launch_lane2l(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
-                         const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s);
+                         const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target);
+
+static hipError_t launch_lane_k(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
+                                const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *&tail_flag, uint32_t *tail_target);
 
 hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
-                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s)
+                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target)
+{
+    if (tail_target) *tail_target = 1u;
+    hipError_t e = launch_lane_k(cls, variant, P, side, seq, tasks, order, n, out, s, tail_flag, tail_target);
+    /* nobody took the flag (an empty launch, a kernel that does not signal): it is raised behind the launch instead, so
+     * that whoever waits for it never waits forever */
+    if (e == hipSuccess && tail_flag) e = hipStreamWriteValue32(s, tail_flag, 1u, 0);
+    return e;
+}
+
+static hipError_t launch_lane_k(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
+                                const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *&tail_flag, uint32_t *tail_target)
 {
     if (n == 0) return hipSuccess;
     int ncls;
@@ -478,8 +493,8 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
          * instruction-cache bound at one wave per SIMD: profiles/r3/lane2_wide_*) */
         static const bool nol = getenv("BSW_NO_LANE2L") != nullptr, narrow = getenv("BSW_LANE2L_NARROW") != nullptr;
         if (C.kind == K_LANE2L_29) {
-            if (!nol) return launch_lane2l(29, P, variant, side, seq, tasks, order, n, out, s);
-        } else if (C.kind == K_LANE2_17 && narrow) return launch_lane2l(17, P, variant, side, seq, tasks, order, n, out, s);
+            if (!nol) { uint32_t *tf = tail_flag; tail_flag = nullptr; return launch_lane2l(29, P, variant, side, seq, tasks, order, n, out, s, tf, tail_target); }
+        } else if (C.kind == K_LANE2_17 && narrow) return launch_lane2l(17, P, variant, side, seq, tasks, order, n, out, s, nullptr, nullptr);
         else return launch_lane2(C.qb, P, variant, side, seq, tasks, order, n, out, s);
     }
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins;

@@ -238,8 +238,50 @@ def test_narrow_class_beside_the_wide_one(fork):
     side waits for exactly the left launches that hold its seeds.  The switches are read once per process: own process."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BSW_NARROW_SHARE="0")
-    if fork == "1":
-        env["BSW_FORK"] = "1"
+    env = dict(os.environ, BSW_NARROW_SHARE="0", BSW_FORK=fork)
     out = subprocess.run([sys.executable, "-c", NARROW_SNIPPET % dict(root=root)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
+
+
+CHAIN_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import __graft_entry__ as g
+host, orc = g.load_package().host, g.load_oracle()
+from test_gpu_parity import assert_same
+for variant, gaps in ((0, {}), (1, dict(o_del=5, e_del=2, o_ins=7, e_ins=1))):
+    p = host.default_params(variant=variant, w=500, **gaps)
+    tasks, arena = host.synth_tasks(60000, seed=91 + variant, read_len=250, seed_len_min=19, seed_len_max=40, seed_at_start=0, sub_rate=0.04,
+                                    indel_rate=0.01, junk_frac=0.05, n_rate=0.0005, w=500)
+    want = orc.pair_batch(p, tasks, nthreads=8)
+    with host.BswContext(device=0, kernel=host.KERNEL_LANE) as c:
+        for rep in range(3):                        # the flags are reset and raised again by every run
+            b = c.upload(p, tasks); c.run(b); c.run(b); c.sync()
+            got, launches = c.download(b), b.info()["launches"]
+            b.free()
+            assert launches == %(launches)d, launches           # left + right x the lane classes in use + finalize + redo list
+            assert_same(got, want, tasks)
+        got = c.extend_pairs(p, tasks)              # the synchronous chunk path shares stream 0 and its chain
+        assert_same(got, want, tasks)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("mode", ["chain", "chain3", "0", "1"])
+def test_lane_launches_as_a_chain_on_250_bp_reads(mode):
+    """250 bp reads have sides in the 136- and the 232-column class.  By default the chunk's lane launches form a chain on
+    three streams — left narrow, left wide, right wide, right narrow — each released by the launch before it: the looped
+    kernel counts its started workgroups in a word of signal memory, the next launch's stream waits until it reads the
+    grid size, so the follower takes the ragged end of the wide launch and never a slot it could still use (chain3: with the
+    72-column class forced on, six launches); BSW_FORK=0: one stream; BSW_FORK=1: the classes of a side released together."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("BSW_FORK", None)
+    if mode in ("0", "1"):
+        env["BSW_FORK"] = mode
+    if mode == "chain3":
+        env["BSW_NARROW_SHARE"] = "0"
+    out = subprocess.run([sys.executable, "-c", CHAIN_SNIPPET % dict(root=root, launches=8 if mode == "chain3" else 6)], env=env,
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
