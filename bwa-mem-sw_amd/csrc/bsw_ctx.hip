@@ -10,6 +10,7 @@
  * There is no CPU compute path here: every DP cell is evaluated by the HIP kernels.
  * This file: bsw_create / bsw_destroy, bsw_host_*, defaults and validation, bsw_pack_bases / bsw_pack_tasks.
  */
+#include <strings.h>
 #include "bsw_internal.h"
 
 /* ---- watchdog: never block in the runtime without a deadline (the RTL documents an
@@ -232,8 +233,18 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
                  * ragged end).  BSW_FORK=1: every stream, all classes of a side released at once (round 4's first version:
                  * 1 971 GCUPS on 250 bp against 1 974 unforked, gpurun_out/r4h).  BSW_FORK=0: none. */
                 static const int fork_env = getenv("BSW_FORK") ? atoi(getenv("BSW_FORK")) : -1;
+                /* a launch that waits for a word another launch raises needs the two to RUN side by side: whatever makes the
+                 * runtime or a tool run one kernel at a time (rocprofv3 --pmc / thread trace, blocking launches) would leave
+                 * the waiting one spinning for ever, so the chain is off there */
+                static const bool serialized = []() {
+                    for (const char *v : {"ROCPROF_COUNTER_COLLECTION", "ROCPROF_ADVANCED_THREAD_TRACE", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING", "AMD_SERIALIZE_KERNEL"}) {
+                        const char *x = getenv(v);
+                        if (x && *x && strcmp(x, "0") != 0 && strcasecmp(x, "false") != 0 && strcasecmp(x, "off") != 0) return true;
+                    }
+                    return false;
+                }();
                 fork_t f;
-                f.mode = fork_env == 1 ? 1 : (fork_env < 0 && s == 0 ? 2 : 0);
+                f.mode = fork_env == 1 ? 1 : (fork_env < 0 && s == 0 && !serialized ? 2 : 0);
                 bool good = f.mode != 0;
                 if (f.mode == 2) {                  /* needs stream memory operations */
                     int can = 0;
