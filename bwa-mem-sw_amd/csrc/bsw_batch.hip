@@ -356,85 +356,133 @@ BSW_LOCAL const fork_t *fork_for(const bsw_ctx *ctx, hipStream_t s, bool pipelin
     return nullptr;
 }
 
-BSW_LOCAL int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
-                         uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches,
-                         const fork_t *fk, bsw_pair *d_pair)
+/* one batch (or one part of a split resident batch) as enqueue_parts() sees it */
+struct lane_job {
+    const bsw_dparams *P;
+    int variant;
+    const uint64_t *d_seq;
+    const bsw_dtask *d_tasks;
+    uint32_t *d_order;
+    const batch_plan *pl;
+    bsw_result *d_out;
+    bsw_pair *d_pair;
+    uint64_t *launches;
+};
+
+/* The general-kernel launches, the lane launches and the pair decision of `nj` independent parts on stream s.
+ *
+ * THE LANE LAUNCHES AS A CHAIN (fork mode 2).  Per part: left sides narrowest class first, then right sides
+ * widest first — a long right side belongs to a short left side and the other way round, so every launch's seeds are ready
+ * as early as they can be; the left launches of all parts before the right ones.  The links go round four streams.  A link
+ * waits for the events of the left-side launches of its part that hold its seeds (plan.dep) and for the FLAG of the link
+ * before it: the two-seeds-per-lane kernels count their started workgroups in a device word, a sleeping wave in front of the follower polls it, and once the count
+ * reaches the grid size every slot that frees up stays free (another kernel's flag is raised behind it) — the follower takes
+ * the ragged end of its predecessor and never a slot one of the predecessor's waves could have had.  Worth its stream
+ * operations only where some link does NOT depend on the link before it (otherwise it would have to wait for the end anyway):
+ * 250 bp reads (136- and 232-column classes: 16.6 - 17.1 ms per 1 M seeds -> 16.0, gpurun_out/r7c).  Several parts: a resident
+ * batch uploaded as two halves so that the right sides of one run in the end of the other's left sides was measured and
+ * LOSES (mixed PE bins 4.42 -> 4.91 ms: every launch has the floor of its longest waves, 1.39 ms, and a half-batch launch is
+ * little more than that floor; longest-first over the whole batch packs better than any chain of parts) — the interface
+ * stays general, one part is what runs. */
+static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, const fork_t *fk)
 {
-    const int nc = bsw::wave_class_count();
-    /* device words behind the order lists: [0] the redo list's length, [1 + c] the work counter of wave class c's launch,
-     * [1 + BSW_MAX_WAVE_CLASSES] the redo launch's — zeroed here, on the stream, before anything counts in them */
-    uint32_t *redo_cnt = d_order + pl.order_len;
-    HIPCHK(e, hipMemsetAsync(redo_cnt, 0, (2 + BSW_MAX_WAVE_CLASSES) * sizeof(uint32_t), s));
-    for (int c = 0; c < nc; ++c) {
-        const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
-        if (!cnt) continue;
-        HIPCHK(e, bsw::launch_wave(c, variant, P, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, redo_cnt + 1 + c, d_out, s));
-        if (d_pair) HIPCHK(e, bsw::launch_pairs_from_results(d_order + pl.wave_start[c], cnt, nullptr, d_out, d_pair, s));
-        if (launches) ++*launches;
-    }
-    if (pl.lane_all_cnt) {
-        const int nlc = bsw::lane_class_count();
-        /* TAIL FILL (fork mode 2, §4.1b): the lane launches of the chunk as ONE chain — left sides narrowest class first, then
-         * right sides widest first: a long right side belongs to a short left side and the other way round, so every launch's
-         * seeds are ready as early as they can be — on up to three streams in rotation.  A launch waits for the events of the
-         * left-side launches that hold its seeds (plan.dep) and for the FLAG of the launch before it in the chain, which that
-         * kernel raises when its last workgroup has started (the looped 232-column kernel; another kernel's flag is raised behind
-         * it): from then on every slot that frees up stays free, so the next launch takes the ragged end and never a slot a
-         * wave of the wider kernel could have had.  250 bp / w = 500: the 232-column launches of both sides run back to back and
-         * the 136-column right sides fill the end, 16.6 - 17.1 ms per 1 M seeds -> 16.2 with two flags, (gpurun_out/r6p). */
-        struct link { int side, cls; uint32_t off, cnt; };
-        link chain[2 * BSW_MAX_LANE_CLASSES];
-        int nchain = 0;
-        bool chain_pays = false;
-        if (fk && fk->mode == 2) {
-            for (int c = 0; c < nlc; ++c)
-                if (pl.laneL_off[c + 1] - pl.laneL_off[c]) chain[nchain++] = link{0, c, pl.laneL_off[c], pl.laneL_off[c + 1] - pl.laneL_off[c]};
-            for (int c = nlc - 1; c >= 0; --c)
-                if (pl.laneR_off[c + 1] - pl.laneR_off[c]) chain[nchain++] = link{1, c, pl.laneR_off[c], pl.laneR_off[c + 1] - pl.laneR_off[c]};
-            for (int i = 0; i + 1 < nchain; ++i) chain_pays = chain_pays || bsw::lane_class_signals_tail(chain[i].cls);
+    const int nc = bsw::wave_class_count(), nlc = bsw::lane_class_count();
+    for (int j = 0; j < nj; ++j) {
+        const lane_job &J = jobs[j];
+        const batch_plan &pl = *J.pl;
+        /* device words behind the order lists: [0] the redo list's length, [1 + c] the work counter of wave class c's launch,
+         * [1 + BSW_MAX_WAVE_CLASSES] the redo launch's — zeroed here, on the stream, before anything counts in them */
+        uint32_t *redo_cnt = J.d_order + pl.order_len;
+        HIPCHK(e, hipMemsetAsync(redo_cnt, 0, (2 + BSW_MAX_WAVE_CLASSES) * sizeof(uint32_t), s));
+        for (int c = 0; c < nc; ++c) {
+            const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
+            if (!cnt) continue;
+            HIPCHK(e, bsw::launch_wave(c, J.variant, *J.P, J.d_seq, J.d_tasks, J.d_order + pl.wave_start[c], cnt, nullptr, redo_cnt + 1 + c, J.d_out, s));
+            if (J.d_pair) HIPCHK(e, bsw::launch_pairs_from_results(J.d_order + pl.wave_start[c], cnt, nullptr, J.d_out, J.d_pair, s));
+            if (J.launches) ++*J.launches;
         }
-        if (chain_pays) {
-            const hipStream_t rot[3] = {s, fk->aux[0], fk->aux[1]};
-            hipStream_t lst[BSW_MAX_LANE_CLASSES] = {nullptr};
-            uint32_t target = 1u;                                       /* what the previous launch's flag reaches */
-            for (int i = 0; i + 1 < nchain; ++i) HIPCHK(e, hipStreamWriteValue32(s, fk->flags[i], 0u, 0));
-            HIPCHK(e, hipEventRecord(fk->ev_fork, s));                 /* everything queued on s so far (input DMAs, pack, bins), and the flags are down */
-            for (int a = 0; a < 2; ++a) HIPCHK(e, hipStreamWaitEvent(fk->aux[a], fk->ev_fork, 0));
-            for (int i = 0; i < nchain; ++i) {
-                const link &k = chain[i];
-                const hipStream_t ks = rot[i % 3];
-                if (k.side == 1)
-                    for (int lc = 0; lc < nlc; ++lc)
-                        if (lst[lc] && lst[lc] != ks && ((pl.dep[lc] >> k.cls) & 1)) HIPCHK(e, hipStreamWaitEvent(ks, fk->ev_left[lc], 0));
-                if (i > 0) HIPCHK(e, hipStreamWaitValue32(ks, fk->flags[i - 1], target, hipStreamWaitValueGte, 0xffffffffu));
-                HIPCHK(e, bsw::launch_lane(k.cls, variant, P, k.side, d_seq, d_tasks, d_order + k.off, k.cnt, d_out, ks, i + 1 < nchain ? fk->flags[i] : nullptr, &target));
-                HIPCHK(e, hipEventRecord(k.side ? fk->ev_right[k.cls] : fk->ev_left[k.cls], ks));
-                if (k.side == 0) lst[k.cls] = ks;
-                if (launches) ++*launches;
+    }
+    struct link { int job, side, cls; uint32_t off, cnt; };
+    constexpr int MAXL = 2 * BSW_MAX_LANE_CLASSES;
+    link chain[MAXL];
+    int nchain = 0;
+    bool chain_pays = false;
+    if (fk && fk->mode == 2) {
+        bool fits = true;
+        for (int side = 0; side < 2; ++side)
+            for (int j = 0; j < nj; ++j) {
+                const batch_plan &pl = *jobs[j].pl;
+                if (!pl.lane_all_cnt) continue;
+                for (int k = 0; k < nlc; ++k) {
+                    const int c = side ? nlc - 1 - k : k;
+                    const uint32_t *off = side ? pl.laneR_off : pl.laneL_off;
+                    if (off[c + 1] - off[c] == 0) continue;
+                    if (nchain == MAXL) { fits = false; break; }
+                    chain[nchain++] = link{j, side, c, off[c], off[c + 1] - off[c]};
+                }
             }
-            for (int i = 0; i < nchain; ++i)                             /* join: the slot stream waits for whatever ran elsewhere */
-                if (rot[i % 3] != s) HIPCHK(e, hipStreamWaitEvent(s, chain[i].side ? fk->ev_right[chain[i].cls] : fk->ev_left[chain[i].cls], 0));
-        } else {
-        if (fk && fk->mode != 1) fk = nullptr;                           /* (a chain that would gain nothing: plain launches on s) */
+        auto depends = [&](const link &x, const link &on) {     /* x cannot start before `on` is done */
+            return x.job == on.job && x.side == 1 && on.side == 0 && ((jobs[x.job].pl->dep[on.cls] >> x.cls) & 1);
+        };
+        for (int i = 0; fits && i + 1 < nchain; ++i)
+            chain_pays = chain_pays || (bsw::lane_class_signals_tail(chain[i].cls) && !depends(chain[i + 1], chain[i]));
+    }
+    if (chain_pays) {
+        const hipStream_t rot[4] = {s, fk->aux[0], fk->aux[1], fk->aux[2]};
+        hipStream_t on[MAXL];                                        /* the stream of link i */
+        uint32_t target = 1u;                                        /* what the previous link's flag reaches */
+        HIPCHK(e, hipMemsetAsync(fk->flag_mem, 0, (size_t)MAXL * 64 * sizeof(uint32_t), s));
+        HIPCHK(e, hipEventRecord(fk->ev_fork, s));                  /* everything queued on s so far (input DMAs, pack, bins, general kernels), and the flags are down */
+        for (int a = 0; a < BSW_FORK_AUX; ++a) HIPCHK(e, hipStreamWaitEvent(fk->aux[a], fk->ev_fork, 0));
+        for (int i = 0; i < nchain; ++i) {
+            const link &k = chain[i];
+            const lane_job &J = jobs[k.job];
+            const hipStream_t ks = on[i] = rot[i % 4];
+            for (int h = 0; h < i; ++h) {
+                const link &l = chain[h];
+                if (on[h] != ks && l.job == k.job && l.side == 0 && k.side == 1 && ((J.pl->dep[l.cls] >> k.cls) & 1)) HIPCHK(e, hipStreamWaitEvent(ks, fk->ev_link[h], 0));
+            }
+            if (i > 0) HIPCHK(e, bsw::launch_wait_count(fk->flag(i - 1), target, ks));
+            HIPCHK(e, bsw::launch_lane(k.cls, J.variant, *J.P, k.side, J.d_seq, J.d_tasks, J.d_order + k.off, k.cnt, J.d_out, ks, i + 1 < nchain ? fk->flag(i) : nullptr, &target));
+            HIPCHK(e, hipEventRecord(fk->ev_link[i], ks));
+            if (J.launches) ++*J.launches;
+        }
+        for (int i = 0; i < nchain; ++i)                              /* join: the slot stream waits for whatever ran elsewhere */
+            if (on[i] != s) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_link[i], 0));
+    }
+    for (int j = 0; j < nj; ++j) {
+        const lane_job &J = jobs[j];
+        const batch_plan &pl = *J.pl;
+        if (!pl.lane_all_cnt) continue;
+        const bsw_dparams &P = *J.P;
+        const int variant = J.variant;
+        const uint64_t *d_seq = J.d_seq;
+        const bsw_dtask *d_tasks = J.d_tasks;
+        uint32_t *d_order = J.d_order, *redo_cnt = J.d_order + pl.order_len;
+        bsw_result *d_out = J.d_out;
+        bsw_pair *d_pair = J.d_pair;
+        uint64_t *launches = J.launches;
+        if (!chain_pays) {
+        const fork_t *fk1 = fk && fk->mode == 1 ? fk : nullptr;       /* (mode 2 without a chain that pays: plain launches on s) */
         /* The classes of a side side by side: the k-th non-empty class of a side (widest first: its waves run longest) goes
          * to stream k — the slot stream, then the auxiliary ones.  A right-side launch waits for exactly the left-side
          * launches that hold one of its seeds (plan.dep); streams are in-order, so only other streams' launches need an event. */
         hipStream_t lstream[BSW_MAX_LANE_CLASSES] = {nullptr}, rstream[BSW_MAX_LANE_CLASSES] = {nullptr};
         int nl = 0, nr = 0;
         for (int c = nlc - 1; c >= 0; --c) {
-            if (pl.laneL_off[c + 1] - pl.laneL_off[c]) { lstream[c] = (fk && nl > 0 && nl <= BSW_FORK_AUX) ? fk->aux[nl - 1] : s; ++nl; }
-            if (pl.laneR_off[c + 1] - pl.laneR_off[c]) { rstream[c] = (fk && nr > 0 && nr <= BSW_FORK_AUX) ? fk->aux[nr - 1] : s; ++nr; }
+            if (pl.laneL_off[c + 1] - pl.laneL_off[c]) { lstream[c] = (fk1 && nl > 0 && nl <= BSW_FORK_AUX) ? fk1->aux[nl - 1] : s; ++nl; }
+            if (pl.laneR_off[c + 1] - pl.laneR_off[c]) { rstream[c] = (fk1 && nr > 0 && nr <= BSW_FORK_AUX) ? fk1->aux[nr - 1] : s; ++nr; }
         }
-        const bool forked = fk && (nl > 1 || nr > 1);
+        const bool forked = fk1 && (nl > 1 || nr > 1);
         if (forked) {
-            HIPCHK(e, hipEventRecord(fk->ev_fork, s));                 /* everything queued on s so far (input DMAs, pack, bins) */
-            for (int a = 0; a < BSW_FORK_AUX; ++a) HIPCHK(e, hipStreamWaitEvent(fk->aux[a], fk->ev_fork, 0));
+            HIPCHK(e, hipEventRecord(fk1->ev_fork, s));                 /* everything queued on s so far (input DMAs, pack, bins) */
+            for (int a = 0; a < BSW_FORK_AUX; ++a) HIPCHK(e, hipStreamWaitEvent(fk1->aux[a], fk1->ev_fork, 0));
         }
         for (int c = nlc - 1; c >= 0; --c) {
             const uint32_t cnt = pl.laneL_off[c + 1] - pl.laneL_off[c];
             if (!cnt) continue;
             HIPCHK(e, bsw::launch_lane(c, variant, P, 0, d_seq, d_tasks, d_order + pl.laneL_off[c], cnt, d_out, lstream[c]));
-            if (forked) HIPCHK(e, hipEventRecord(fk->ev_left[c], lstream[c]));
+            if (forked) HIPCHK(e, hipEventRecord(fk1->ev_left[c], lstream[c]));
             if (launches) ++*launches;
         }
         for (int c = nlc - 1; c >= 0; --c) {
@@ -442,15 +490,15 @@ BSW_LOCAL int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const ui
             if (!cnt) continue;
             if (forked)
                 for (int lc = 0; lc < nlc; ++lc)
-                    if (lstream[lc] && lstream[lc] != rstream[c] && ((pl.dep[lc] >> c) & 1)) HIPCHK(e, hipStreamWaitEvent(rstream[c], fk->ev_left[lc], 0));
+                    if (lstream[lc] && lstream[lc] != rstream[c] && ((pl.dep[lc] >> c) & 1)) HIPCHK(e, hipStreamWaitEvent(rstream[c], fk1->ev_left[lc], 0));
             HIPCHK(e, bsw::launch_lane(c, variant, P, 1, d_seq, d_tasks, d_order + pl.laneR_off[c], cnt, d_out, rstream[c]));
-            if (forked && rstream[c] != s) HIPCHK(e, hipEventRecord(fk->ev_right[c], rstream[c]));
+            if (forked && rstream[c] != s) HIPCHK(e, hipEventRecord(fk1->ev_right[c], rstream[c]));
             if (launches) ++*launches;
         }
         if (forked) {                                                   /* join: the slot stream waits for whatever ran elsewhere */
             for (int c = 0; c < nlc; ++c) {
-                if (lstream[c] && lstream[c] != s) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_left[c], 0));
-                if (rstream[c] && rstream[c] != s) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_right[c], 0));
+                if (lstream[c] && lstream[c] != s) HIPCHK(e, hipStreamWaitEvent(s, fk1->ev_left[c], 0));
+                if (rstream[c] && rstream[c] != s) HIPCHK(e, hipStreamWaitEvent(s, fk1->ev_right[c], 0));
             }
         }
         }
@@ -463,6 +511,14 @@ BSW_LOCAL int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const ui
         if (launches) *launches += 2;
     }
     return BSW_OK;
+}
+
+BSW_LOCAL int enqueue_batch(errs &e, const bsw_dparams &P, int variant, const uint64_t *d_seq, const bsw_dtask *d_tasks,
+                         uint32_t *d_order, const batch_plan &pl, bsw_result *d_out, hipStream_t s, uint64_t *launches,
+                         const fork_t *fk, bsw_pair *d_pair)
+{
+    const lane_job j = {&P, variant, d_seq, d_tasks, d_order, &pl, d_out, d_pair, launches};
+    return enqueue_parts(e, &j, 1, s, fk);
 }
 
 /* the raw bytes and the task records are in st.h_* (or the caller's registered arena): move them, pack, bin */

@@ -160,9 +160,10 @@ static void ctx_release(bsw_ctx *ctx)
                 for (auto a : f.aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
                 if (f.ev_fork) (void)hipEventDestroy(f.ev_fork);
                 if (f.ev_fork_r) (void)hipEventDestroy(f.ev_fork_r);
-                for (uint32_t *fl : f.flags) if (fl) (void)hipFree(fl);
+                if (f.flag_mem) (void)hipFree(f.flag_mem);
                 for (auto ev : f.ev_left) if (ev) (void)hipEventDestroy(ev);
                 for (auto ev : f.ev_right) if (ev) (void)hipEventDestroy(ev);
+                for (auto ev : f.ev_link) if (ev) (void)hipEventDestroy(ev);
             }
             for (auto s : d.streams) (void)hipStreamDestroy(s);
             for (auto ev : d.events) (void)hipEventDestroy(ev);
@@ -227,15 +228,15 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
             d.streams.push_back(st);
             {
-                /* The lane classes of one side on several streams.  Default (mode 2, stream 0 of a device only — the stream
-                 * resident batches and synchronous chunks run on): TAIL FILL, the narrower classes of a side are released
-                 * when the last workgroup of the widest class's launch has started (§4.1b: 250 bp, the 232-column launch's
-                 * ragged end).  BSW_FORK=1: every stream, all classes of a side released at once (round 4's first version:
+                /* The lane launches of a chunk on several streams.  Default (mode 2, stream 0 of a device only — the stream
+                 * resident batches and synchronous chunks run on): a CHAIN, each launch released when every workgroup of the
+                 * one before it has started (enqueue_parts; DESIGN.md §4.1b: 250 bp, the 232-column launches' ragged ends).
+                 * BSW_FORK=1: every stream, all classes of a side released at once (round 4's first version:
                  * 1 971 GCUPS on 250 bp against 1 974 unforked, gpurun_out/r4h).  BSW_FORK=0: none. */
                 static const int fork_env = getenv("BSW_FORK") ? atoi(getenv("BSW_FORK")) : -1;
                 /* a launch that waits for a word another launch raises needs the two to RUN side by side: whatever makes the
                  * runtime or a tool run one kernel at a time (rocprofv3 --pmc / thread trace, blocking launches) would leave
-                 * the waiting one spinning for ever, so the chain is off there */
+                 * the waiting one asleep for ever, so the chain is off there */
                 static const bool serialized = []() {
                     for (const char *v : {"ROCPROF_COUNTER_COLLECTION", "ROCPROF_ADVANCED_THREAD_TRACE", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING", "AMD_SERIALIZE_KERNEL"}) {
                         const char *x = getenv(v);
@@ -246,10 +247,6 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
                 fork_t f;
                 f.mode = fork_env == 1 ? 1 : (fork_env < 0 && s == 0 && !serialized ? 2 : 0);
                 bool good = f.mode != 0;
-                if (f.mode == 2) {                  /* needs stream memory operations */
-                    int can = 0;
-                    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, d.device) != hipSuccess || !can) good = false;
-                }
                 /* the auxiliary streams run at the LOWEST priority: the widest class of a side (the slot stream's) has the
                  * longest waves and must get its slots first — released at the same instant, the narrow class's many short
                  * workgroups took half the slots and the long waves started late (right side 2.8 ms instead of 2.0,
@@ -264,7 +261,8 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
                     good = hipEventCreateWithFlags(&f.ev_left[c], hipEventDisableTiming) == hipSuccess &&
                            hipEventCreateWithFlags(&f.ev_right[c], hipEventDisableTiming) == hipSuccess;
                 for (int k = 0; k < 2 * BSW_MAX_LANE_CLASSES && good && f.mode == 2; ++k)
-                    good = hipExtMallocWithFlags((void **)&f.flags[k], sizeof(uint64_t), hipMallocSignalMemory) == hipSuccess;
+                    good = hipEventCreateWithFlags(&f.ev_link[k], hipEventDisableTiming) == hipSuccess;
+                if (good && f.mode == 2) good = hipMalloc((void **)&f.flag_mem, 2 * BSW_MAX_LANE_CLASSES * 64 * sizeof(uint32_t)) == hipSuccess;
                 if (!good) (void)hipGetLastError();     /* (optional machinery: its failure is not the next launch's error) */
                 f.ok = good;
                 d.forks.push_back(f);              /* (not ok: the classes of a side run one after the other on the slot stream) */

@@ -177,9 +177,11 @@ struct stage_t {
 struct fork_t {
     hipStream_t aux[BSW_FORK_AUX] = {nullptr};
     hipEvent_t ev_fork = nullptr, ev_fork_r = nullptr, ev_left[BSW_MAX_LANE_CLASSES] = {nullptr}, ev_right[BSW_MAX_LANE_CLASSES] = {nullptr};
-    /* mode 2 (tail fill): a chunk's lane launches form a chain, each released when the LAST workgroup of the one before it
-     * has started — flags[i], signal memory written by launch i's kernel, waited for by launch i+1's stream */
-    uint32_t *flags[2 * BSW_MAX_LANE_CLASSES] = {nullptr};   /* (signal memory comes in 8-byte allocations) */
+    hipEvent_t ev_link[2 * BSW_MAX_LANE_CLASSES] = {nullptr};    /* mode 2: one per link of the chain */
+    /* mode 2 (tail fill): a chunk's lane launches form a chain, each released when EVERY workgroup of the one before it
+     * has started — flag(i), a device word counted up by launch i's kernel, polled by a sleeping wave in front of launch i+1 */
+    uint32_t *flag_mem = nullptr;     /* 2 * BSW_MAX_LANE_CLASSES words, one per 256-byte line */
+    uint32_t *flag(int i) const { return flag_mem + 64 * i; }
     int mode = 0;                     /* 0 none, 1 all classes of a side at once (BSW_FORK=1), 2 tail fill */
     bool ok = false;
 };

@@ -85,8 +85,11 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
                                                              const uint64_t *__restrict__ seq,
                                                              const bsw_dtask *__restrict__ tasks,
                                                              const uint32_t *__restrict__ order, const uint32_t n,
-                                                             bsw_result *__restrict__ out)
+                                                             bsw_result *__restrict__ out, uint32_t *tail_flag)
 {
+    /* *tail_flag counts the workgroups that have a slot (bsw_lane2l_kernel.hip): the next launch of the
+     * chunk's chain is released when the count reaches the grid size */
+    if (tail_flag && threadIdx.x == 0) __hip_atomic_fetch_add(tail_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     using L = l2::lane2<QB, VM, SYM>;
     constexpr int QMAX = L::QMAX, NW = L::NW, NC = L::NC;
     static_assert(QMAX <= BSW_LANE_QBINS && QMAX <= 256, "row-max key and binning assume at most 256 eh[] columns");
@@ -286,17 +289,18 @@ bool lane2_params_ok(const bsw_dparams &P, int variant)
 }
 
 hipError_t launch_lane2(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
-                        uint32_t n, bsw_result *out, hipStream_t s)
+                        uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target)
 {
-    if (n == 0) return hipSuccess;
+    if (n == 0) return tail_flag ? hipMemsetD32Async((hipDeviceptr_t)tail_flag, 1, 1, s) : hipSuccess;
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins, vm = variant == BSW_VARIANT_M;
     const dim3 grid((n + 511u) / 512u), block(256);
+    if (tail_flag && tail_target) *tail_target = grid.x;              /* the flag's value once every workgroup has started */
 #define BSW_L2_GO(QB, WPS)                                                                                                    \
     do {                                                                                                                      \
-        if (!vm && sym) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);   \
-        else if (!vm) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, false, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);    \
-        else if (sym) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out);      \
-        else hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out);              \
+        if (!vm && sym) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag);   \
+        else if (!vm) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, false, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag);    \
+        else if (sym) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag);      \
+        else hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag);              \
     } while (0)
     /* 72 columns: 72 row registers + the working set = 168 VGPRs, three waves per SIMD (the spills the compiler takes at
      * that bound sit in the prologue and in the cold target-staging / query-N code, none in the row loop: tests/test_isa_audit.py) */

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
     /* *tail_flag counts the workgroups that have a slot.  When it reaches gridDim.x every slot that frees up stays free, and
      * whoever waits for that (the next launch of the chunk's chain) may have them.  A count, not "the last
      * block has started": the eight XCDs take their blocks round-robin and run ahead of each other by whole workgroups */
-    if (tail_flag && threadIdx.x == 0) __hip_atomic_fetch_add(tail_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tail_flag && threadIdx.x == 0) __hip_atomic_fetch_add(tail_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     using L = l2::lane2l<QB, VM, SYM>;
     using LB = typename L::B;
     constexpr int QMAX = L::QMAX, NW = L::NW, NC = L::NC;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
 hipError_t launch_lane2l(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
                          const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target)
 {
-    if (n == 0) return tail_flag ? hipStreamWriteValue32(s, tail_flag, 1u, 0) : hipSuccess;
+    if (n == 0) return tail_flag ? hipMemsetD32Async((hipDeviceptr_t)tail_flag, 1, 1, s) : hipSuccess;
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins, vm = variant == BSW_VARIANT_M;
     const dim3 grid((n + 511u) / 512u), block(256);
     if (tail_flag && tail_target) *tail_target = grid.x;              /* the flag's value once every workgroup has started */

@@ -456,14 +456,14 @@ static const lane_class_t *lane_classes(int *n)
 int lane_class_count() { int n; lane_classes(&n); return n; }
 int lane_class_cols(int cls) { int n; return lane_classes(&n)[cls].qb * 8; }
 int lane_class_bits(int cls) { int n; return lane_classes(&n)[cls].bits; }
-bool lane_class_signals_tail(int cls) { int n; return cls >= 0 && lane_classes(&n)[cls].kind == K_LANE2L_29; }
+bool lane_class_signals_tail(int cls) { int n; return cls >= 0 && lane_classes(&n)[cls].kind != K_LANE16; }
 
 /* bsw_lane2_kernel.hip: two seeds per lane, packed 16-bit math, unrolled blocks — the 72-column class at three waves per
  * SIMD, the 136-column class at two; bsw_lane2l_kernel.hip: the same arithmetic with the blocks walked by a loop and the
  * row in AccVGPRs (232 columns, one wave per SIMD) */
 bool lane2_params_ok(const bsw_dparams &P, int variant);
 hipError_t launch_lane2(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
-                        uint32_t n, bsw_result *out, hipStream_t s);
+                        uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target);
 hipError_t launch_lane2l(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
                          const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target);
 
@@ -477,7 +477,7 @@ hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, con
     hipError_t e = launch_lane_k(cls, variant, P, side, seq, tasks, order, n, out, s, tail_flag, tail_target);
     /* nobody took the flag (an empty launch, a kernel that does not signal): it is raised behind the launch instead, so
      * that whoever waits for it never waits forever */
-    if (e == hipSuccess && tail_flag) e = hipStreamWriteValue32(s, tail_flag, 1u, 0);
+    if (e == hipSuccess && tail_flag) e = hipMemsetD32Async((hipDeviceptr_t)tail_flag, 1, 1, s);
     return e;
 }
 
@@ -495,7 +495,7 @@ static hipError_t launch_lane_k(int cls, int variant, const bsw_dparams &P, int 
         if (C.kind == K_LANE2L_29) {
             if (!nol) { uint32_t *tf = tail_flag; tail_flag = nullptr; return launch_lane2l(29, P, variant, side, seq, tasks, order, n, out, s, tf, tail_target); }
         } else if (C.kind == K_LANE2_17 && narrow) return launch_lane2l(17, P, variant, side, seq, tasks, order, n, out, s, nullptr, nullptr);
-        else return launch_lane2(C.qb, P, variant, side, seq, tasks, order, n, out, s);
+        else { uint32_t *tf = tail_flag; tail_flag = nullptr; return launch_lane2(C.qb, P, variant, side, seq, tasks, order, n, out, s, tf, tail_target); }
     }
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins;
     switch (C.fb) {
@@ -510,6 +510,23 @@ hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const u
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(bsw_pair_finalize, dim3((n + 255u) / 256u), dim3(256), 0, s, P, tasks, order, n, out, redo, redo_cnt, pairs);
+    return hipGetLastError();
+}
+
+/* One wave that sleeps until *flag >= target: what a stream runs in front of a launch that must not start before the
+ * launch ahead of it in the chunk's chain has placed its last workgroup (enqueue_parts).  It polls every
+ * ~3 us and sleeps in between — the runtime's own stream wait (hipStreamWaitValue32 -> __amd_rocclr_streamOpsWait) spins
+ * without a pause and takes the issue slots of the waves that share its SIMD: every launch beside it got a straggler
+ * (a 1.5 ms half-batch launch took 2.4, gpurun_out/r7b). */
+__global__ __launch_bounds__(64) void bsw_wait_count(const uint32_t *flag, const uint32_t target)
+{
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(127);
+}
+
+hipError_t launch_wait_count(const uint32_t *flag, uint32_t target, hipStream_t s)
+{
+    hipLaunchKernelGGL(bsw_wait_count, dim3(1), dim3(64), 0, s, flag, target);
     return hipGetLastError();
 }
 

@@ -270,9 +270,9 @@ print("ok")
 @pytest.mark.parametrize("mode", ["chain", "chain3", "0", "1"])
 def test_lane_launches_as_a_chain_on_250_bp_reads(mode):
     """250 bp reads have sides in the 136- and the 232-column class.  By default the chunk's lane launches form a chain on
-    three streams — left narrow, left wide, right wide, right narrow — each released by the launch before it: the looped
-    kernel counts its started workgroups in a word of signal memory, the next launch's stream waits until it reads the
-    grid size, so the follower takes the ragged end of the wide launch and never a slot it could still use (chain3: with the
+    four streams — left narrow, left wide, right wide, right narrow — each released by the launch before it: the kernels
+    count their started workgroups in a device word, one sleeping wave in front of the next launch polls it until it reads
+    the grid size, so the follower takes the ragged end of the wide launch and never a slot it could still use (chain3: with the
     72-column class forced on, six launches); BSW_FORK=0: one stream; BSW_FORK=1: the classes of a side released together."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
