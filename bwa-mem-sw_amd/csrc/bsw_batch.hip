@@ -373,7 +373,7 @@ struct lane_job {
  *
  * THE LANE LAUNCHES AS A CHAIN (fork mode 2).  Per part: left sides narrowest class first, then right sides
  * widest first — a long right side belongs to a short left side and the other way round, so every launch's seeds are ready
- * as early as they can be; the left launches of all parts before the right ones.  The links go round four streams.  A link
+ * as early as they can be; the left launches of all parts before the right ones.  The links go round the device's slot streams (up to four; the others are idle while stream 0 runs a resident batch or a synchronous chunk).  A link
  * waits for the events of the left-side launches of its part that hold its seeds (plan.dep) and for the FLAG of the link
  * before it: the two-seeds-per-lane kernels count their started workgroups in a device word, a sleeping wave in front of the follower polls it, and once the count
  * reaches the grid size every slot that frees up stays free (another kernel's flag is raised behind it) — the follower takes
@@ -429,15 +429,16 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
     }
     if (chain_pays) {
         const hipStream_t rot[4] = {s, fk->aux[0], fk->aux[1], fk->aux[2]};
+        const int nrot = 1 + fk->naux;                               /* 2 .. 4 */
         hipStream_t on[MAXL];                                        /* the stream of link i */
         uint32_t target = 1u;                                        /* what the previous link's flag reaches */
         HIPCHK(e, hipMemsetAsync(fk->flag_mem, 0, (size_t)MAXL * 64 * sizeof(uint32_t), s));
         HIPCHK(e, hipEventRecord(fk->ev_fork, s));                  /* everything queued on s so far (input DMAs, pack, bins, general kernels), and the flags are down */
-        for (int a = 0; a < BSW_FORK_AUX; ++a) HIPCHK(e, hipStreamWaitEvent(fk->aux[a], fk->ev_fork, 0));
+        for (int a = 0; a < fk->naux; ++a) HIPCHK(e, hipStreamWaitEvent(fk->aux[a], fk->ev_fork, 0));
         for (int i = 0; i < nchain; ++i) {
             const link &k = chain[i];
             const lane_job &J = jobs[k.job];
-            const hipStream_t ks = on[i] = rot[i % 4];
+            const hipStream_t ks = on[i] = rot[i % nrot];
             for (int h = 0; h < i; ++h) {
                 const link &l = chain[h];
                 if (on[h] != ks && l.job == k.job && l.side == 0 && k.side == 1 && ((J.pl->dep[l.cls] >> k.cls) & 1)) HIPCHK(e, hipStreamWaitEvent(ks, fk->ev_link[h], 0));

@@ -157,7 +157,7 @@ static void ctx_release(bsw_ctx *ctx)
         if (!dead) {
             for (auto s : d.streams) (void)hipStreamSynchronize(s);
             for (auto &f : d.forks) {
-                for (auto a : f.aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
+                if (f.mode == 1) for (auto a : f.aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }      /* (mode 2 borrows the slot streams) */
                 if (f.ev_fork) (void)hipEventDestroy(f.ev_fork);
                 if (f.ev_fork_r) (void)hipEventDestroy(f.ev_fork_r);
                 if (f.flag_mem) (void)hipFree(f.flag_mem);
@@ -254,7 +254,11 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
                 int least = 0, greatest = 0;
                 static const bool noprio = getenv("BSW_FORK_NOPRIO") != nullptr;
                 if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || noprio) least = 0;
-                for (int a = 0; a < BSW_FORK_AUX && good; ++a) good = hipStreamCreateWithPriority(&f.aux[a], hipStreamNonBlocking, least) == hipSuccess;
+                /* (mode 2 BORROWS the device's other slot streams further down: they are idle whenever stream 0 runs a resident
+                 * batch or a synchronous chunk, they sit on hardware queues of their own, and three more streams created
+                 * here would push the slot streams onto shared queues — the runtime deals streams onto its four queues in
+                 * creation order, and every pipeline leg of bench.py lost 5 - 20 % when that happened, gpurun_out/r7g) */
+                for (int a = 0; a < BSW_FORK_AUX && good && f.mode == 1; ++a) good = hipStreamCreateWithPriority(&f.aux[a], hipStreamNonBlocking, least) == hipSuccess;
                 good = good && hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming) == hipSuccess &&
                        hipEventCreateWithFlags(&f.ev_fork_r, hipEventDisableTiming) == hipSuccess;
                 for (int c = 0; c < BSW_MAX_LANE_CLASSES && good; ++c)
@@ -271,6 +275,12 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
             d.events.push_back(ev);
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
             d.h2d_done.push_back(ev);
+        }
+        if (!d.forks.empty() && d.forks[0].ok && d.forks[0].mode == 2) {
+            fork_t &f = d.forks[0];
+            f.naux = 0;
+            for (size_t k = 1; k < d.streams.size() && f.naux < BSW_FORK_AUX; ++k) f.aux[f.naux++] = d.streams[k];
+            if (f.naux == 0) f.ok = false;          /* (a context of one stream: nothing to chain on) */
         }
     }
     if (hipSetDevice(ctx->device0()) != hipSuccess ||
