@@ -443,7 +443,10 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
                 const link &l = chain[h];
                 if (on[h] != ks && l.job == k.job && l.side == 0 && k.side == 1 && ((J.pl->dep[l.cls] >> k.cls) & 1)) HIPCHK(e, hipStreamWaitEvent(ks, fk->ev_link[h], 0));
             }
-            if (i > 0) HIPCHK(e, bsw::launch_wait_count(fk->flag(i - 1), target, ks));
+            /* BSW_CHAIN_SELFTEST (tests only): a target no count reaches, so that EVERY wait runs into its deadline — what a tool
+             * that runs the waiter before the launch raising its word does; results must not change, bsw_chain_timeouts counts */
+            static const bool selftest = getenv("BSW_CHAIN_SELFTEST") != nullptr;
+            if (i > 0) HIPCHK(e, bsw::launch_wait_count(fk->flag(i - 1), selftest ? 0xffffffffu : target, fk->expired(), ks));
             HIPCHK(e, bsw::launch_lane(k.cls, J.variant, *J.P, k.side, J.d_seq, J.d_tasks, J.d_order + k.off, k.cnt, J.d_out, ks, i + 1 < nchain ? fk->flag(i) : nullptr, &target));
             HIPCHK(e, hipEventRecord(fk->ev_link[i], ks));
             if (J.launches) ++*J.launches;
@@ -896,6 +899,26 @@ extern "C" int bsw_download(bsw_ctx *ctx, bsw_dev_batch *b, bsw_result *out)
     return BSW_OK;
 }
 
+extern "C" int bsw_chain_timeouts(bsw_ctx *ctx, uint64_t *n)
+{
+    if (!ctx || !n) return BSW_E_INVAL;
+    errs &e = ctx->err;
+    int rc = bsw_sync(ctx);
+    if (rc) return rc;
+    uint64_t total = 0;
+    for (dev_state &d : ctx->devs)
+        for (fork_t &f : d.forks)
+            if (f.ok && f.mode == 2 && f.flag_mem) {
+                uint32_t v = 0;
+                HIPCHK(e, hipSetDevice(d.device));
+                HIPCHK(e, hipMemcpy(&v, f.expired(), sizeof(v), hipMemcpyDeviceToHost));
+                total += v;
+            }
+    HIPCHK(e, hipSetDevice(ctx->device0()));
+    *n = total;
+    return BSW_OK;
+}
+
 extern "C" int bsw_batch_info(const bsw_dev_batch *b, uint64_t *n_tasks, uint64_t *in_bytes, uint64_t *out_bytes, uint64_t *n_launches)
 {
     if (!b) return BSW_E_INVAL;
@@ -925,6 +948,14 @@ extern "C" int bsw_batch_order(bsw_ctx *ctx, const bsw_dev_batch *b, uint32_t *o
  * packs the bases (a few hundred bytes), sorts the seeds into their general-kernel classes, and ONE DMA carries
  * sequences, task records, order lists and zeroed counters; then the DP kernel(s), then the result copy. ---- */
 #define SMALL_BATCH 256
+/* an enqueue failed half-way: wait for what IS in flight (DMAs out of the pinned staging, kernels storing into the caller's
+ * buffers) before the caller may reuse or free anything; a wait that fails too marks the context dead (sync_stream does) */
+static void drain_after_error(bsw_ctx *ctx, errs &e, hipStream_t s, hipEvent_t ev)
+{
+    errs keep = e;
+    if (sync_stream(ctx, e, s, ev) != BSW_OK) ctx->dead = true;      /* nothing can be promised about the buffers any more */
+    else e = keep;                                                   /* report the launch failure, not the drain */
+}
 static int run_small(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent_t ev, const bsw_params &p, const bsw_dparams &dp,
                      const bsw_task *tasks, size_t n, bsw_result *out)
 {
@@ -955,7 +986,7 @@ static int run_small(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent
         for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) cur[c] = pl.wave_start[c];
         for (size_t i = 0; i < n; ++i) ho[cur[bsw_wave_class_of(&ci.bp, std::max(tasks[i].lqlen, tasks[i].rqlen))]++] = (uint32_t)i;
     }
-    HIPCHK(e, hipMemcpyAsync(st.d_blob.p, hb, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(st.d_blob.p, hb, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));      /* (the first thing on the stream: nothing to drain if it fails) */
     const uint64_t *d_seq = st.d_blob.p;
     const bsw_dtask *d_tasks = (const bsw_dtask *)(st.d_blob.p + w_seq);
     uint32_t *d_order = (uint32_t *)(st.d_blob.p + w_seq + w_tasks), *ctr = d_order + pl.order_len;   /* (zero: copied that way) */
@@ -967,7 +998,13 @@ static int run_small(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEvent
     const int nc = bsw::wave_class_count();
     for (int c = 0; c < nc; ++c) {
         const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
-        if (cnt) HIPCHK(e, bsw::launch_wave(c, p.variant, dp, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, ctr + 1 + c, res, s));
+        if (!cnt) continue;
+        if (hipError_t le = bsw::launch_wave(c, p.variant, dp, d_seq, d_tasks, d_order + pl.wave_start[c], cnt, nullptr, ctr + 1 + c, res, s)) {
+            /* kernels already launched store into pinned h_out / the caller's registered `out`, and the H2D copy of h_blob may
+             * still be reading it: nothing of this call may be in flight when the caller gets its buffers back */
+            drain_after_error(ctx, e, s, ev);
+            return fail(e, BSW_E_HIP, "launch: %s", hipGetErrorString(le));
+        }
     }
     rc = sync_stream(ctx, e, s, ev);
     if (rc) return rc;
@@ -982,7 +1019,7 @@ BSW_LOCAL int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEv
     if (n == 0) return BSW_OK;
     {
         static const bool nosmall = getenv("BSW_NO_SMALL") != nullptr;     /* (measurements) */
-        if (!nosmall && n <= SMALL_BATCH && !packed && !turn && ctx->cfg.kernel != BSW_KERNEL_LANE && ctx->cfg.result_format == BSW_RESULT_FULL)
+        if (!nosmall && n <= SMALL_BATCH && !packed && !turn && ctx->cfg.kernel != BSW_KERNEL_LANE)
             return run_small(ctx, e, st, s, ev, p, dp, tasks, n, out);
     }
     static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
@@ -1003,15 +1040,17 @@ BSW_LOCAL int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEv
     const double t_c = dbg ? tnow() : 0;
     rc = stage_device(e, st, s, ci, n, false, nullptr, nullptr, turn);
     if (rc) return rc;
-    /* BSW_RESULT_PAIR: `out` addresses bsw_pair[n]; the dense 32-byte records come from their own device array */
-    const bool pairs = ctx->cfg.result_format == BSW_RESULT_PAIR;
-    const size_t rec = pairs ? sizeof(bsw_pair) : sizeof(bsw_result);
-    if (pairs && (he = st.d_pair.reserve(n + 1)) != hipSuccess) return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
-    rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, s, nullptr, fork_for(ctx, s), pairs ? st.d_pair.p : nullptr);
-    if (rc) return rc;
+    /* `out` is ALWAYS bsw_result[n] here, whatever the context's result_format: the only caller is bsw_extend_batch
+     * (ext_group reads res[k].right); BSW_RESULT_PAIR applies to the bsw_submit* calls, whose slot workers have their own path */
+    const size_t rec = sizeof(bsw_result);
+    rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, s, nullptr, fork_for(ctx, s), nullptr);
+    if (rc) { drain_after_error(ctx, e, s, ev); return rc; }
     const bool out_direct = is_registered(out, n * rec);
     if (!out_direct && (he = st.h_out.reserve(n)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
-    HIPCHK(e, hipMemcpyAsync(out_direct ? (void *)out : (void *)st.h_out.p, pairs ? (const void *)st.d_pair.p : (const void *)st.d_out.p, n * rec, hipMemcpyDeviceToHost, s));
+    if (hipError_t ce = hipMemcpyAsync(out_direct ? (void *)out : (void *)st.h_out.p, (const void *)st.d_out.p, n * rec, hipMemcpyDeviceToHost, s)) {
+        drain_after_error(ctx, e, s, ev);
+        return fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(ce));
+    }
     const double t_d = dbg ? tnow() : 0;
     rc = sync_stream(ctx, e, s, ev);
     if (rc) return rc;

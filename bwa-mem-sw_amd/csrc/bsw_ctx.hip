@@ -133,7 +133,10 @@ extern "C" void bsw_default_config(bsw_config *c)
     c->n_devices = 0;
     c->timeout_ms = 120000;
     c->result_format = BSW_RESULT_FULL;
+    c->pin_threads = 1;
 }
+
+extern "C" int bsw_abi_version(void) { return BSW_ABI_VERSION; }
 
 extern "C" int bsw_device_count(void)
 {
@@ -183,18 +186,25 @@ static void ctx_release(bsw_ctx *ctx)
     delete ctx;
 }
 
-extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
+extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out) { return bsw_create_sized(cfg, sizeof(bsw_config), out); }
+
+extern "C" int bsw_create_sized(const bsw_config *cfg, size_t cfg_size, bsw_ctx **out)
 {
     if (!out) return BSW_E_INVAL;
     *out = nullptr;
     bsw_config c;
-    if (cfg) c = *cfg; else bsw_default_config(&c);
+    bsw_default_config(&c);
+    /* a caller built against an older header passes its own sizeof: the fields it does not know keep their defaults */
+    if (cfg) {
+        if (cfg_size < offsetof(bsw_config, timeout_ms) || cfg_size > sizeof(bsw_config)) return BSW_E_INVAL;
+        memcpy(&c, cfg, cfg_size);
+    }
     if (c.streams < 1) c.streams = 2;
     if (c.streams > 8) c.streams = 8;
     if (c.pack_threads < 1) c.pack_threads = 1;
     if (c.chunk_tasks == 0) c.chunk_tasks = 131072;
-    if (c.timeout_ms <= 0) c.timeout_ms = 120000;
-    if (const char *t = getenv("BSW_TIMEOUT_MS")) { if (atoi(t) > 0) c.timeout_ms = atoi(t); }
+    /* BSW_TIMEOUT_MS is the DEFAULT for hosts that pass no timeout of their own; an explicit bsw_config.timeout_ms wins */
+    if (c.timeout_ms <= 0) { const char *t = getenv("BSW_TIMEOUT_MS"); c.timeout_ms = t && atoi(t) > 0 ? atoi(t) : 120000; }
     if (c.n_devices < 0 || c.n_devices > BSW_MAX_DEVICES) return BSW_E_INVAL;
     if (c.result_format != BSW_RESULT_FULL && c.result_format != BSW_RESULT_PAIR) return BSW_E_INVAL;
     if (c.n_devices == 0) { c.n_devices = 1; c.devices[0] = c.device; }
@@ -234,18 +244,11 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
                  * BSW_FORK=1: every stream, all classes of a side released at once (round 4's first version:
                  * 1 971 GCUPS on 250 bp against 1 974 unforked, gpurun_out/r4h).  BSW_FORK=0: none. */
                 static const int fork_env = getenv("BSW_FORK") ? atoi(getenv("BSW_FORK")) : -1;
-                /* a launch that waits for a word another launch raises needs the two to RUN side by side: whatever makes the
-                 * runtime or a tool run one kernel at a time (rocprofv3 --pmc / thread trace, blocking launches) would leave
-                 * the waiting one asleep for ever, so the chain is off there */
-                static const bool serialized = []() {
-                    for (const char *v : {"ROCPROF_COUNTER_COLLECTION", "ROCPROF_ADVANCED_THREAD_TRACE", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING", "AMD_SERIALIZE_KERNEL"}) {
-                        const char *x = getenv(v);
-                        if (x && *x && strcmp(x, "0") != 0 && strcasecmp(x, "false") != 0 && strcasecmp(x, "off") != 0) return true;
-                    }
-                    return false;
-                }();
+                /* (the chain's waiting wave is bounded — bsw_wait_count gives up after 20 ms and the follower starts early, which
+                 * is correct: the flag is a scheduling hint, data dependencies are events — so nothing here looks at profiler or
+                 * launch-serialising environment variables any more; BSW_FORK=0 is the manual switch) */
                 fork_t f;
-                f.mode = fork_env == 1 ? 1 : (fork_env < 0 && s == 0 && !serialized ? 2 : 0);
+                f.mode = fork_env == 1 ? 1 : (fork_env < 0 && s == 0 ? 2 : 0);
                 bool good = f.mode != 0;
                 /* the auxiliary streams run at the LOWEST priority: the widest class of a side (the slot stream's) has the
                  * longest waves and must get its slots first — released at the same instant, the narrow class's many short
@@ -266,7 +269,9 @@ extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out)
                            hipEventCreateWithFlags(&f.ev_right[c], hipEventDisableTiming) == hipSuccess;
                 for (int k = 0; k < 2 * BSW_MAX_LANE_CLASSES && good && f.mode == 2; ++k)
                     good = hipEventCreateWithFlags(&f.ev_link[k], hipEventDisableTiming) == hipSuccess;
-                if (good && f.mode == 2) good = hipMalloc((void **)&f.flag_mem, 2 * BSW_MAX_LANE_CLASSES * 64 * sizeof(uint32_t)) == hipSuccess;
+                /* (one more line behind the flags: how many waiting waves gave up at their deadline, bsw_chain_timeouts) */
+                if (good && f.mode == 2) good = hipMalloc((void **)&f.flag_mem, (2 * BSW_MAX_LANE_CLASSES + 1) * 64 * sizeof(uint32_t)) == hipSuccess &&
+                                                hipMemset(f.flag_mem, 0, (2 * BSW_MAX_LANE_CLASSES + 1) * 64 * sizeof(uint32_t)) == hipSuccess;
                 if (!good) (void)hipGetLastError();     /* (optional machinery: its failure is not the next launch's error) */
                 f.ok = good;
                 d.forks.push_back(f);              /* (not ok: the classes of a side run one after the other on the slot stream) */

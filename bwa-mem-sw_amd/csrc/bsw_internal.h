@@ -182,6 +182,7 @@ struct fork_t {
      * has started — flag(i), a device word counted up by launch i's kernel, polled by a sleeping wave in front of launch i+1 */
     uint32_t *flag_mem = nullptr;     /* 2 * BSW_MAX_LANE_CLASSES words, one per 256-byte line */
     uint32_t *flag(int i) const { return flag_mem + 64 * i; }
+    uint32_t *expired() const { return flag_mem + 64 * 2 * BSW_MAX_LANE_CLASSES; }   /* waits that ended at their deadline */
     int mode = 0;                     /* 0 none, 1 all classes of a side at once (BSW_FORK=1), 2 tail fill */
     int naux = BSW_FORK_AUX;          /* streams in aux[] (mode 2: the device's other slot streams, borrowed) */
     bool ok = false;

@@ -513,20 +513,40 @@ hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const u
     return hipGetLastError();
 }
 
-/* One wave that sleeps until *flag >= target: what a stream runs in front of a launch that must not start before the
- * launch ahead of it in the chunk's chain has placed its last workgroup (enqueue_parts).  It polls every
- * ~3 us and sleeps in between — the runtime's own stream wait (hipStreamWaitValue32 -> __amd_rocclr_streamOpsWait) spins
- * without a pause and takes the issue slots of the waves that share its SIMD: every launch beside it got a straggler
- * (a 1.5 ms half-batch launch took 2.4, gpurun_out/r7b). */
-__global__ __launch_bounds__(64) void bsw_wait_count(const uint32_t *flag, const uint32_t target)
+/* One wave that sleeps until *flag >= target OR A DEADLINE PASSES: what a stream runs in front of a launch that should not
+ * start before the launch ahead of it in the chunk's chain has placed its last workgroup (enqueue_parts).
+ * It polls every ~3 us and sleeps in between — the runtime's own stream wait (hipStreamWaitValue32 ->
+ * __amd_rocclr_streamOpsWait) spins without a pause and takes the issue slots of the waves that share its SIMD: every
+ * launch beside it got a straggler (a 1.5 ms half-batch launch took 2.4, gpurun_out/r7b).
+ *
+ * THE FLAG IS A SCHEDULING HINT, NOT A DEPENDENCY: every data dependency between the links of a chain is a stream event
+ * (plan.dep -> ev_link in enqueue_parts).  A follower released early is still correct, it merely competes for wave slots
+ * with its predecessor.  So the wait is BOUNDED: after BSW_WAIT_TICKS of the constant 100 MHz s_memrealtime counter
+ * (20 ms; the longest launch a chain holds, a 232-column side of 1 M seeds, runs 7 ms) the wave gives up and the follower
+ * starts.  That is what makes the chain safe wherever kernels are run one at a time (rocprofv3 --pmc, HIP_LAUNCH_BLOCKING,
+ * AMD_SERIALIZE_KERNEL, a debugger): there the waiter is scheduled BEFORE the launch that would raise its word, finds the
+ * word down, and returns after the deadline instead of sleeping for ever (the reference's TBB -> PE array -> RBB hand-off is
+ * a hardware FSM that cannot wedge, tbb.v:110-123, rbb.v:219-224).  tests/test_gpu_lane.py runs the chain under both settings. */
+#ifndef BSW_WAIT_TICKS
+#define BSW_WAIT_TICKS 2000000ull
+#endif
+__global__ __launch_bounds__(64) void bsw_wait_count(const uint32_t *flag, const uint32_t target, uint32_t *expired)
 {
-    if (threadIdx.x == 0)
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(127);
+    if (threadIdx.x == 0) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > BSW_WAIT_TICKS) {
+                if (expired) __hip_atomic_fetch_add(expired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(127);
+        }
+    }
 }
 
-hipError_t launch_wait_count(const uint32_t *flag, uint32_t target, hipStream_t s)
+hipError_t launch_wait_count(const uint32_t *flag, uint32_t target, uint32_t *expired, hipStream_t s)
 {
-    hipLaunchKernelGGL(bsw_wait_count, dim3(1), dim3(64), 0, s, flag, target);
+    hipLaunchKernelGGL(bsw_wait_count, dim3(1), dim3(64), 0, s, flag, target, expired);
     return hipGetLastError();
 }
 

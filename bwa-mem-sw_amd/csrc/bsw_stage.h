@@ -32,7 +32,7 @@ bool lane_class_signals_tail(int cls);    /* its launch raises launch_lane's tai
 hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
                        const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag = nullptr, uint32_t *tail_target = nullptr);
 /* pairs != NULL (BSW_RESULT_PAIR): the pair-level record goes to pairs[task], 32 bytes, instead of back into out[task] */
-hipError_t launch_wait_count(const uint32_t *flag, uint32_t target, hipStream_t s);    /* one sleeping wave until *flag >= target */
+hipError_t launch_wait_count(const uint32_t *flag, uint32_t target, uint32_t *expired, hipStream_t s);    /* one sleeping wave until *flag >= target or 20 ms */
 hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,
                            bsw_result *out, uint32_t *redo, uint32_t *redo_cnt, bsw_pair *pairs, hipStream_t s);
 hipError_t launch_pairs_from_results(const uint32_t *order, uint32_t n, const uint32_t *n_dev, const bsw_result *out, bsw_pair *pairs, hipStream_t s);

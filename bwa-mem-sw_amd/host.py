@@ -43,7 +43,7 @@ REF_TASK = np.dtype([("query", "<u8"), ("l_query", "<i4"), ("init_score", "<i4")
 MAX_DEVICES = 16
 CONFIG = np.dtype([("device", "<i4"), ("kernel", "<i4"), ("streams", "<i4"), ("pack_threads", "<i4"),
                    ("chunk_tasks", "<u8"), ("n_devices", "<i4"), ("devices", "<i4", (MAX_DEVICES,)),
-                   ("timeout_ms", "<i4"), ("result_format", "<i4"), ("_pad", "<i4")])
+                   ("timeout_ms", "<i4"), ("result_format", "<i4"), ("pin_threads", "<i4")])
 PAIR = np.dtype([("tag", "<u4"), ("qb", "<i4"), ("qe", "<i4"), ("rb", "<i4"), ("re", "<i4"),
                  ("score", "<i4"), ("truesc", "<i4"), ("w", "<i4")])       # the RTL's 5-word record: the first 32 bytes of RESULT
 RESULT_FULL, RESULT_PAIR = 0, 1
@@ -93,6 +93,8 @@ def lib():
             "bsw_default_params": (None, [vp]), "bsw_default_config": (None, [vp]),
             "bsw_device_count": (C.c_int, []),
             "bsw_create": (C.c_int, [vp, C.POINTER(vp)]), "bsw_destroy": (None, [vp]),
+            "bsw_create_sized": (C.c_int, [vp, sz, C.POINTER(vp)]), "bsw_abi_version": (C.c_int, []),
+            "bsw_chain_timeouts": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
             "bsw_last_error": (C.c_char_p, [vp]),
             "bsw_submit": (C.c_int, [vp, vp, vp, sz, vp]), "bsw_wait": (C.c_int, [vp]),
             "bsw_submit_packed": (C.c_int, [vp, vp, vp, sz, vp]),
@@ -150,7 +152,7 @@ def lib():
 
 EXPORTS = ["ksw_global2", "ksw_global", "bsw_global_batch", "bsw_align_batch", "ksw_align2", "ksw_align", "ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_scalar_stats", "bsw_host_alloc", "bsw_host_free",
            "bsw_host_register", "bsw_host_unregister", "bsw_batch_order", "bsw_refbatch_submit", "bsw_refbatch_wait", "bsw_default_params", "bsw_default_config",
-           "bsw_device_count", "bsw_create", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
+           "bsw_device_count", "bsw_create", "bsw_create_sized", "bsw_abi_version", "bsw_chain_timeouts", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
            "bsw_submit_packed", "bsw_upload_packed", "bsw_pack_tasks", "bsw_pack_tasks_bound",
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
@@ -286,7 +288,7 @@ class BswContext:
     """One GPU context = one of the reference's PE arrays behind its batch manager."""
 
     def __init__(self, device=0, kernel=KERNEL_AUTO, streams=4, pack_threads=4, chunk_tasks=131072, devices=None,
-                 timeout_ms=0, result_format=RESULT_FULL):
+                 timeout_ms=0, result_format=RESULT_FULL, pin_threads=None):
         cfg = np.zeros(1, dtype=CONFIG)
         lib().bsw_default_config(cfg.ctypes.data)
         cfg["device"], cfg["kernel"], cfg["streams"] = device, kernel, streams
@@ -297,6 +299,8 @@ class BswContext:
         if timeout_ms:
             cfg["timeout_ms"] = timeout_ms
         cfg["result_format"] = result_format
+        if pin_threads is not None:
+            cfg["pin_threads"] = 1 if pin_threads else -1
         self.out_dtype = PAIR if result_format == RESULT_PAIR else RESULT      # what the submit calls hand back
         h = C.c_void_p()
         rc = lib().bsw_create(cfg.ctypes.data, C.byref(h))
@@ -308,6 +312,12 @@ class BswContext:
     def _chk(self, rc, what):
         if rc:
             raise BswError(rc, "%s: %s" % (what, lib().bsw_last_error(self.handle).decode()))
+
+    def chain_timeouts(self):
+        """Waits of the launch chain that ended at their deadline (0 unless kernels are being run one at a time)."""
+        v = C.c_uint64(0)
+        self._chk(lib().bsw_chain_timeouts(self.handle, C.byref(v)), "bsw_chain_timeouts")
+        return v.value
 
     def close(self):
         if self.handle:

@@ -142,7 +142,17 @@ typedef struct bsw_config {
     int32_t timeout_ms;     /* watchdog on every wait for the GPU (def 120000); on expiry the call fails
                                with BSW_E_HIP and the context is dead (every later call fails fast)  */
     int32_t result_format;  /* BSW_RESULT_FULL (def): bsw_result[n]; BSW_RESULT_PAIR: bsw_pair[n] from the bsw_submit* calls */
-} bsw_config;
+    int32_t pin_threads;    /* 0 / 1 (def): the slot and gather threads of a device run on the CPUs of that GPU's NUMA node
+                               (/sys/bus/pci/devices/<bdf>/local_cpulist, intersected with the process affinity) and their
+                               pinned staging is allocated and first touched from there — one manager next to its arrays
+                               (batch_manager.v:745-773); -1: threads and staging are left where the OS puts them */
+} bsw_config;               /* 104 bytes in ABI 5 (pin_threads took the tail padding of ABI 4) */
+
+/* ABI of this header.  bsw_config has no size field of its own: bsw_create() reads sizeof(bsw_config) of THIS header, so a
+ * caller built against an older, shorter struct must use bsw_create_sized() with ITS sizeof (fields beyond it take their
+ * defaults) — or check bsw_abi_version() == BSW_ABI_VERSION at start-up.  History: 3 = 96-byte config; 4 = result_format
+ * (104 bytes); 5 = pin_threads in the former padding, bsw_create_sized, bsw_chain_timeouts. */
+#define BSW_ABI_VERSION 5
 
 #define BSW_RESULT_FULL  0
 #define BSW_RESULT_PAIR  1
@@ -177,6 +187,12 @@ void     bsw_default_params(bsw_params *p);          /* bwa defaults a=1,b=4,o=6
 void     bsw_default_config(bsw_config *c);
 int      bsw_device_count(void);                     /* gfx950 devices visible; <=0 if none */
 int      bsw_create(const bsw_config *cfg, bsw_ctx **out);
+int      bsw_create_sized(const bsw_config *cfg, size_t cfg_size, bsw_ctx **out);   /* cfg_size = the CALLER's sizeof(bsw_config) */
+int      bsw_abi_version(void);                      /* BSW_ABI_VERSION the library was built with */
+/* How many of the launch chain's waiting waves gave up at their 20 ms deadline so far (the chain's flag is a
+ * scheduling hint, a follower released early is still correct).  Non-zero where kernels are run one at a time
+ * (rocprofv3 --pmc, HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL); 0 in normal operation.  Synchronises the context. */
+int      bsw_chain_timeouts(bsw_ctx *ctx, uint64_t *n);
 void     bsw_destroy(bsw_ctx *ctx);
 const char *bsw_last_error(const bsw_ctx *ctx);      /* text of the last failure  */
 

@@ -285,3 +285,57 @@ def test_lane_launches_as_a_chain_on_250_bp_reads(mode):
     out = subprocess.run([sys.executable, "-c", CHAIN_SNIPPET % dict(root=root, launches=8 if mode == "chain3" else 6)], env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
+
+
+WEDGE_SNIPPET = r"""
+import sys, time, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import __graft_entry__ as g
+host, orc = g.load_package().host, g.load_oracle()
+from test_gpu_parity import assert_same
+p = host.default_params(w=500)
+tasks, arena = host.synth_tasks(40000, seed=93, read_len=250, seed_len_min=19, seed_len_max=40, seed_at_start=0, sub_rate=0.04,
+                                indel_rate=0.01, junk_frac=0.05, n_rate=0.0005, w=500)
+want = orc.pair_batch(p, tasks, nthreads=8)
+with host.BswContext(device=0, kernel=host.KERNEL_LANE, timeout_ms=60000) as c:
+    t0 = time.time()
+    for rep in range(2):
+        b = c.upload(p, tasks); c.run(b); c.sync()
+        got, launches = c.download(b), b.info()["launches"]
+        b.free()
+        assert launches == 6, launches               # the chain is ON: four lane launches + finalize + redo list
+        assert_same(got, want, tasks)
+    got = c.extend_pairs(p, tasks)
+    assert_same(got, want, tasks)
+    print("timeouts", c.chain_timeouts(), "seconds", round(time.time() - t0, 2))
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("setting", ["serialize", "blocking", "deadline"])
+def test_launch_chain_cannot_wedge(setting):
+    """The chain's waiting wave (bsw_wait_count) is BOUNDED: the word it polls is a scheduling hint, the data dependencies are
+    stream events, so where something runs kernels one at a time — and may pick the waiter before the launch that raises its
+    word — the wave gives up after 20 ms and the follower starts.  Round 4 sniffed five environment names and switched the
+    chain off; now the chain stays ON (six launches) under AMD_SERIALIZE_KERNEL=3 and HIP_LAUNCH_BLOCKING=1, and with
+    BSW_CHAIN_SELFTEST every wait is made to run into its deadline: results bit-exact, the process finishes, the expired
+    waits are counted (reference: the TBB -> PE array -> RBB hand-off is an FSM that cannot wedge, tbb.v:110-123, rbb.v:219-224)."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("BSW_FORK", "BSW_CHAIN_SELFTEST", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"):
+        env.pop(k, None)
+    if setting == "serialize":
+        env["AMD_SERIALIZE_KERNEL"] = "3"
+    elif setting == "blocking":
+        env["HIP_LAUNCH_BLOCKING"] = "1"
+    else:
+        env["BSW_CHAIN_SELFTEST"] = "1"
+    out = subprocess.run([sys.executable, "-c", WEDGE_SNIPPET % dict(root=root)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
+    m = re.search(r"timeouts (\d+) seconds ([0-9.]+)", out.stdout)
+    assert m, out.stdout
+    if setting == "deadline":
+        assert int(m.group(1)) == 6, out.stdout          # two resident runs of a four-link chain: three waits each, all expired
+                                                         # (extend_pairs streams through the slot pipeline, which does not chain)
+    assert float(m.group(2)) < 30.0, out.stdout          # and a wait that expires costs 20 ms, not a watchdog

@@ -133,3 +133,27 @@ def test_pair_record_format(host, oracle, kernel):
             for f in PAIR_FIELDS:
                 assert (gl[f] == wl[f]).all(), f
         hout.free()
+
+
+@pytest.mark.parametrize("n", [200, 3000])
+def test_extend_batch_on_a_pair_record_context(host, oracle, n):
+    """bsw_extend_batch hands back bsw_ext records whatever the context's result_format is: BSW_RESULT_PAIR applies to the
+    bsw_submit* calls only (round 4's advisor: on a PAIR context the synchronous chunk copied 32-byte pair records into the
+    96-byte array bsw_extend_batch reads its sides from).  200 tasks: the single-DMA small-batch path; 3 000: a staged chunk."""
+    rng = np.random.default_rng(11)
+    et = np.zeros(n, dtype=host.EXT_TASK)
+    keep = []
+    for i in range(n):
+        ql, tl = int(rng.integers(1, 180)), int(rng.integers(0, 260))
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = _gen.mutate(rng, t, ql, 0.04, 0.02)
+        keep.append((q, t))
+        et[i]["query"], et[i]["target"] = q.ctypes.data, t.ctypes.data if tl else 0
+        et[i]["qlen"], et[i]["tlen"] = ql, tl
+        et[i]["w"], et[i]["end_bonus"], et[i]["h0"] = int(rng.choice([3, 20, 100])), int(rng.choice([0, 5])), int(rng.integers(1, 70))
+    p = host.default_params()
+    want = oracle.ext_batch(p, et, nthreads=4)
+    with host.BswContext(device=0, result_format=host.RESULT_PAIR) as c:
+        got = c.extend_batch(p, et)
+    for f in ("score", "qle", "tle", "gtle", "gscore", "max_off", "cells"):
+        assert (got[f] == want[f]).all(), f
