@@ -106,20 +106,23 @@ PRESETS = {
 }
 
 
-def rank_cpu_sets(n):
+def rank_cpu_sets(n, avail=None, sys_root="/sys"):
     """One CPU set per rank: the CPUs this process may use, split among the ranks along NUMA nodes where the machine has
     several (>= 6x at 8 GPUs needs NUMA-local host threads; the reference's single manager sits next to its
     4 PE arrays, batch_manager.v:343-348).  With a PCI bus id per GPU (amdgpu sysfs, no GPU call) rank r gets the CPUs of
-    ITS card's node; without, the nodes are dealt round-robin.  Returns a list of sorted CPU lists (None = leave alone)."""
-    try:
-        avail = sorted(os.sched_getaffinity(0))
-    except AttributeError:
-        return [None] * n
+    ITS card's node; without, the nodes are dealt round-robin.  Returns a list of sorted CPU lists (None = leave alone).
+    `avail` / `sys_root`: the CPUs to deal out and the sysfs tree to read (tests hand in a fake tree)."""
+    if avail is None:
+        try:
+            avail = sorted(os.sched_getaffinity(0))
+        except AttributeError:
+            return [None] * n
+    avail = sorted(avail)
     nodes = []
     try:
-        for d in sorted(os.listdir("/sys/devices/system/node")):
+        for d in sorted(os.listdir(sys_root + "/devices/system/node")):
             if d.startswith("node") and d[4:].isdigit():
-                cpus = parse_cpulist(open("/sys/devices/system/node/%s/cpulist" % d).read())
+                cpus = parse_cpulist(open(sys_root + "/devices/system/node/%s/cpulist" % d).read())
                 cpus = [c for c in cpus if c in set(avail)]
                 if cpus:
                     nodes.append((int(d[4:]), cpus))
@@ -127,7 +130,7 @@ def rank_cpu_sets(n):
         pass
     if not nodes:
         nodes = [(0, avail)]
-    gpu_node = gpu_numa_nodes()
+    gpu_node = gpu_numa_nodes(sys_root)
     by_node = {}
     for r in range(n):
         node = gpu_node[r] if r < len(gpu_node) and gpu_node[r] in dict(nodes) else nodes[r % len(nodes)][0]
@@ -152,14 +155,16 @@ def parse_cpulist(text):
     return out
 
 
-def gpu_numa_nodes():
+def gpu_numa_nodes(sys_root="/sys"):
     """NUMA node of every amdgpu render node in enumeration order, from sysfs (no HIP call: the launcher must not touch the
-    GPU).  [] when the kernel does not say (-1) or the layout is unknown."""
+    GPU).  [] when the layout is unknown; a node of -1 (the kernel does not say) is kept and dealt round-robin by the caller.
+    This ORDER is an assumption — HIP may enumerate the cards differently — which every rank checks against its own device's
+    PCI address once it may touch the GPU (verify_rank_placement)."""
     out = []
     try:
-        cards = sorted((d for d in os.listdir("/sys/class/drm") if d.startswith("renderD")), key=lambda d: int(d[7:]))
+        cards = sorted((d for d in os.listdir(sys_root + "/class/drm") if d.startswith("renderD")), key=lambda d: int(d[7:]))
         for c in cards:
-            dev = os.path.realpath("/sys/class/drm/%s/device" % c)
+            dev = os.path.realpath(sys_root + "/class/drm/%s/device" % c)
             drv = os.path.basename(os.path.realpath(dev + "/driver")) if os.path.exists(dev + "/driver") else ""
             if drv != "amdgpu":
                 continue
@@ -224,11 +229,52 @@ def apply_rank_affinity():
     the library start their threads.  Returns the CPU list in effect."""
     spec = os.environ.get("BSW_RANK_CPUS")
     try:
+        global ORIG_AFFINITY
+        ORIG_AFFINITY = sorted(os.sched_getaffinity(0))
         if spec:
             os.sched_setaffinity(0, set(parse_cpulist(spec)))
         return sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError, ValueError):
         return None
+
+
+ORIG_AFFINITY = None
+
+
+def device_bdf(props):
+    """torch's device properties -> the PCI address sysfs uses ("0000:c1:00.0")"""
+    return "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+
+
+def verify_rank_placement(bdf, orig_affinity, node_peers, sys_root="/sys"):
+    """The launcher pinned this rank by the ORDER of the render nodes in sysfs, before anything could ask HIP which card
+    `local_rank` is.  Now the rank knows its card's PCI address: read that card's NUMA node and CPUs, and if the CPUs the
+    rank runs on are not the card's, re-pin onto the card's share of what the process was allowed before the launcher
+    narrowed it.  node_peers = (my index, how many) among the ranks whose cards sit on the same node.
+    Returns (numa_node, repinned, cpus in effect)."""
+    node, local = -1, []
+    try:
+        node = int(open("%s/bus/pci/devices/%s/numa_node" % (sys_root, bdf)).read().strip())
+        local = parse_cpulist(open("%s/bus/pci/devices/%s/local_cpulist" % (sys_root, bdf)).read())
+    except (OSError, ValueError):
+        pass
+    try:
+        now = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return node, False, None
+    if not local or all(c in set(local) for c in now):
+        return node, False, now                       # already next to the card (or nothing known about it)
+    cand = [c for c in (orig_affinity or now) if c in set(local)]
+    if not cand:
+        return node, False, now                       # the process may not run there at all
+    k, m = node_peers
+    per = max(1, len(cand) // max(m, 1))
+    mine = cand[k * per:(k + 1) * per] or cand
+    try:
+        os.sched_setaffinity(0, set(mine))
+    except OSError:
+        return node, False, now
+    return node, True, mine
 
 
 def kernel_source_hash():
@@ -281,15 +327,23 @@ def pmc_summary(workload, tasks):
     src = {"file": "profiles/pmc_latest.json", "collected": "earlier rocprofv3 --pmc passes of this command (tools/profile.sh), not this run"}
     try:
         j = json.load(open(PMC_FILE))
+        j = j if "workload" in j else j.get(workload, {})        # one entry per workload (round 4: a single entry)
     except Exception:
         return {}, dict(src, status="absent")
     src["source_hash"] = j.get("source_hash")
     src["tree_hash"] = kernel_source_hash()
-    if j.get("workload") != workload or j.get("seeds_per_gpu") != tasks:
+    if j.get("workload") != workload or (tasks is not None and j.get("seeds_per_gpu") != tasks):
         return {}, dict(src, status="other workload: counters omitted")
     if j.get("source_hash") != src["tree_hash"]:
         return {}, dict(src, status="stale (kernel sources changed since the counters were collected): counters omitted")
     return j, dict(src, status="matches this tree")
+
+
+def spread(runs, n):
+    """min / median / max of the timed repetitions of a PCIe-inclusive leg, as seeds per second (best first)"""
+    r = sorted(runs)
+    return {"seeds_per_s_max_median_min": [round(n / r[0], 1), round(n / float(np.median(r)), 1), round(n / r[-1], 1)],
+            "max_over_min": round(r[-1] / r[0], 3), "reps": len(r)}
 
 
 def cells_of(res):
@@ -305,6 +359,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--pool", type=int, default=8_000_000, help="--scaling strong: seeds in the one pool all ranks share (BASELINE configs[3]: 100000000)")
     ap.add_argument("--gen-threads", type=int, default=0, help="--scaling strong: threads that generate this rank's chunks (0 = the rank's CPU set, at most 32)")
+    ap.add_argument("--sample-stride", type=int, default=97, help="--scaling strong: the line carries the exact cell count of every k-th chunk of rank 0")
     ap.add_argument("--resident-chunks", type=int, default=32, help="--scaling strong: 128Ki-seed chunks per resident batch")
     ap.add_argument("--workload", default="150bp_w100_single_bin", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0)
@@ -314,6 +369,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(affinity, 16): the 1-GPU box's CPU share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 250 bp and mixed-bin side measurements (N=1 only, outside the timed region)")
+    ap.add_argument("--pe-seeds", type=int, default=10_000_000, help="seeds of the 150 bp PE mixed-bin measurement beside the headline (BASELINE configs[2]: 10 M; 0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bsw_submit (PCIe-inclusive) measurement")
     ap.add_argument("--e2e-reps", type=int, default=5, help="bsw_submit passes timed (median reported)")
     ap.add_argument("--ref-mbp", type=int, default=64, help="synthetic genome size (Mbp) of the device-resident-reference e2e leg; 0 = skip")
@@ -371,6 +427,25 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU path)"
     torch.cuda.set_device(local_rank)
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
+
+    # ---- is this rank next to ITS card?  (the launcher assumed render-node order = HIP order; bwa_mem_sw.v:162 /
+    # batch_manager.v:343-348: one manager next to its arrays) ----
+    props = torch.cuda.get_device_properties(local_rank)
+    my_bdf = device_bdf(props)
+    try:
+        my_node = int(open("/sys/bus/pci/devices/%s/numa_node" % my_bdf).read().strip())
+    except (OSError, ValueError):
+        my_node = -1
+    peers = (0, 1)
+    if dist is not None:
+        nt = torch.tensor([float(my_node)], dtype=torch.float64, device=red_dev)
+        alln = [torch.zeros_like(nt) for _ in range(world)]
+        dist.all_gather(alln, nt)
+        same = [r for r in range(world) if int(alln[r].item()) == my_node]
+        peers = (same.index(rank), len(same))
+    _node, repinned, cpus_now = verify_rank_placement(my_bdf, ORIG_AFFINITY, peers)
+    if repinned:
+        cpu_affinity = cpus_now
 
     pkg = graft.load_package()
     host = pkg.host
@@ -471,6 +546,7 @@ def main():
     kern_ms = ctx.run_history()                  # HIP events on the library's own stream, one pair per bsw_run
 
     info = {"in_bytes": 0, "out_bytes": 0, "launches": 0}
+    sample_cells = {}
     cells = ext_calls = nominal = 0
     res = None
     for gi, b in enumerate(batches):
@@ -480,6 +556,13 @@ def main():
             info[key] += bi[key]
         b.free()
         cells += cells_of(r)
+        if args.scaling == "strong":                    # exact cells of a strided sample of this rank's chunks (tests re-derive them with the oracle)
+            lo = 0
+            for c in groups[gi]:
+                sz = min(chunk, args.pool - c * chunk)
+                if c % args.sample_stride == 0:
+                    sample_cells[str(c)] = cells_of(r[lo:lo + sz])
+                lo += sz
         retry = int((r["left"]["aw"] > spec["w"]).sum() + (r["right"]["aw"] > spec["w"]).sum())
         if tasks is not None:
             res = r
@@ -576,7 +659,7 @@ def main():
         qsame = all(bool((gotq[f] == res[f]).all()) for f in host.PAIR.names)
         qctx.close()
         pout.free()
-        packed_leg = (float(np.median(runs)), psame, need, pstream, float(np.median(qruns)), qsame)
+        packed_leg = (float(np.median(runs)), psame, need, pstream, float(np.median(qruns)), qsame, list(runs), list(qruns))
         parena.free()
 
     # ---- same shape of work, seeds against a DEVICE-RESIDENT reference: only the reads cross PCIe ----
@@ -599,7 +682,7 @@ def main():
         nchk = min(50_000, n_local)
         same = bool(rctx.extend_ref(params, gref, rtasks[:nchk]).tobytes() == out_buf[:nchk].tobytes())
         ref_first = out_buf.copy() if world == 1 else None
-        ref_leg = (float(np.median(runs)), rcells, same, int(rtasks["l_query"].astype(np.int64).sum()), lp)
+        ref_leg = (float(np.median(runs)), rcells, same, int(rtasks["l_query"].astype(np.int64).sum()), lp, list(runs))
         rctx.ref_free(gref)
         rctx.close()
         ref_stream = None
@@ -615,6 +698,14 @@ def main():
                 c.ref_free(refs[id(c)]); c.close()
         hreads.free()
 
+    place = ctx.placement()
+    rank_rows = [[float(rank), float(props.pci_domain_id), float(props.pci_bus_id), float(props.pci_device_id), float(my_node),
+                  float(repinned), float(place["pinned_cpus"]), dt / args.steps * 1e3, float(len(cpu_affinity or []))]]
+    if dist is not None:
+        mine_t = torch.tensor(rank_rows[0], dtype=torch.float64, device=red_dev)
+        allr = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(allr, mine_t)
+        rank_rows = [t.tolist() for t in allr]
     if dist is not None:
         v = torch.tensor([dt, float(cells), float(ext_calls), float(n_tasks_local), float(nominal), e2e_dt or 0.0],
                          dtype=torch.float64, device=red_dev)
@@ -649,8 +740,14 @@ def main():
                        "band_w": spec["w"], "zdrop": args.zdrop, "variant": "H" if args.variant == 0 else "M", "gaps": args.gaps or "6,1,6,1",
                        "sharding": "per-read task shard (chunk c -> rank c mod N), no collective" if world > 1 else "single GPU",
                        "kernel_launches_per_step": info["launches"], "resident_batches_per_rank": len(batches), "preset": args.preset,
-                       "cpu_affinity": cpu_list_str(cpu_affinity), "rank_cpus_pinned": bool(os.environ.get("BSW_RANK_CPUS")),
-                       "setup_s": round(setup_s, 1) if args.scaling == "strong" else None},
+                       "cpu_affinity": cpu_list_str(cpu_affinity), "rank_cpus_pinned": bool(os.environ.get("BSW_RANK_CPUS")) or repinned,
+                       "ranks": [{"rank": int(r[0]), "gpu_bdf": "%04x:%02x:%02x.0" % (int(r[1]), int(r[2]), int(r[3])), "numa_node": int(r[4]),
+                                  "repinned_after_hip_check": bool(r[5]), "library_slot_threads_pinned_cpus": int(r[6]),
+                                  "ms_per_step": round(r[7], 4), "rank_cpus": int(r[8])} for r in rank_rows],
+                       "ms_per_step_min_max_over_ranks": [round(min(r[7] for r in rank_rows), 4), round(max(r[7] for r in rank_rows), 4)],
+                       "setup_s": round(setup_s, 1) if args.scaling == "strong" else None,
+                       "rank0_chunk_cells_sample": ({"every": args.sample_stride, "chunk_seeds": chunk, "generator_seed": "5000 + chunk index", "cells": sample_cells}
+                                                    if args.scaling == "strong" else None)},
             "extensions_per_s": round(ext_all * args.steps / dt_all, 1),
             "seeds_per_s": round(tasks_all * args.steps / dt_all, 1),
             "cells_per_step": cells_all,
@@ -681,6 +778,7 @@ def main():
                 "path": "bsw_submit: registered host arena DMA'd as is, pack + bin on the GPU, results DMA'd into registered host memory",
                 "bytes_per_seed_h2d": round((harena_used(tasks) + len(tasks) * 60) / max(len(tasks), 1), 1),
                 "bit_exact_vs_resident_run": e2e_same,
+                "spread": spread(e2e_runs, len(tasks)),
             }
             if e2e_stream is not None:
                 out["e2e"]["stream_two_in_flight"] = {
@@ -688,14 +786,14 @@ def main():
                     "ratio_to_hbm_resident": round((cells / e2e_stream[0] / 1e9) / gcups, 3), "host_threads": stream_threads("bytes"),
                     "batches_timed": 16, "bit_exact_vs_resident_run": e2e_stream[1]}
         if packed_leg is not None:
-            pdt, psame, pbytes, pstream, qdt, qsame = packed_leg
+            pdt, psame, pbytes, pstream, qdt, qsame, pruns, qruns_ = packed_leg
             out["e2e_packed_input"] = {
                 "seeds_per_s": round(len(tasks) / pdt, 1), "gcups": round(cells / pdt / 1e9, 1),
                 "ratio_to_hbm_resident": round((cells / pdt / 1e9) / gcups, 3), "host_threads": "4 slot threads", "reps_median_of": args.e2e_reps,
                 "path": "bsw_submit_packed: sequences 4-bit packed by the caller (16 bases per uint64, the device layout) in a registered arena, "
                         "DMA'd straight into the sequence buffer, no pack kernel; packing itself is not timed (the caller keeps its reads packed)",
                 "bytes_per_seed_h2d": round((pbytes + len(tasks) * 44) / max(len(tasks), 1), 1),
-                "bit_exact_vs_resident_run": psame,
+                "bit_exact_vs_resident_run": psame, "spread": spread(pruns, len(tasks)),
                 "stream_two_in_flight": {"seeds_per_s": round(len(tasks) / pstream[0], 1), "gcups": round(cells / pstream[0] / 1e9, 1),
                                          "ratio_to_hbm_resident": round((cells / pstream[0] / 1e9) / gcups, 3),
                                          "host_threads": stream_threads("packed"), "batches_timed": 16,
@@ -703,9 +801,9 @@ def main():
                 "pair_records": {"seeds_per_s": round(len(tasks) / qdt, 1), "gcups": round(cells / qdt / 1e9, 1),
                                  "ratio_to_hbm_resident": round((cells / qdt / 1e9) / gcups, 3), "bytes_per_seed_d2h": 32,
                                  "path": "bsw_config.result_format = BSW_RESULT_PAIR: the RTL's 5-word record alone comes back (32 of 96 bytes per seed)",
-                                 "eight_fields_equal_full_records": qsame}}
+                                 "eight_fields_equal_full_records": qsame, "spread": spread(qruns_, len(tasks))}}
         if ref_leg is not None and world == 1:
-            rdt, rcells, rsame, rbytes, rlp = ref_leg
+            rdt, rcells, rsame, rbytes, rlp, rruns = ref_leg
             out["e2e_device_reference"] = {
                 "seeds_per_s": round(n_local / rdt, 1), "gcups": round(rcells / rdt / 1e9, 1),
                 "ratio_to_hbm_resident": round((n_local / rdt) / (tasks_all * args.steps / dt_all), 3),
@@ -713,7 +811,7 @@ def main():
                 "path": "bsw_submit_ref: %d Mbp synthetic genome resident in HBM (2 bits/base), reads DMA'd from registered host memory, "
                         "targets fetched and left flanks mirrored on the GPU" % (rlp // 1_000_000),
                 "bytes_per_seed_h2d": round((rbytes + n_local * (44 + 16 + 16)) / max(n_local, 1), 1),
-                "bit_exact_vs_resident_fetch_path": rsame,
+                "bit_exact_vs_resident_fetch_path": rsame, "spread": spread(rruns, n_local),
             }
             if ref_stream is not None:
                 out["e2e_device_reference"]["stream_two_in_flight"] = {
@@ -780,6 +878,8 @@ def main():
                          "roofline_frac": round(g2 * 1e9 * VALU_OPS_PER_CELL / 1e12 / PEAK_VALU_TOPS, 4), "kernel_launches_per_step": b2.info()["launches"]}
             b2.free()
         out["other_workloads"] = extra
+        if args.pe_seeds > 0 and args.workload != "150bp_w100_mixed_bins":
+            out["pe_mixed_bins"] = pe_mixed_leg(host, ctx, args, cpu_affinity, args.pe_seeds)
         out["other_paths"] = side_paths(host, local_rank)
         if not args.no_e2e:
             # the same submit path when the caller's memory is NOT registered: host threads gather into pinned staging
@@ -800,6 +900,81 @@ def main():
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def pe_mixed_leg(host, ctx, args, cpu_affinity, n_seeds, steps=3):
+    """BASELINE.json's metric is quoted on 150 bp PE batches (configs[2]: 10 M PE reads, mixed (qlen, tlen) bins through the
+    batch manager).  The same measurement as the headline — inputs resident in HBM, HIP events around every bsw_run — on
+    n_seeds left + right seeds with seed length ~U[19, 60] at a uniform position, 5 % junk reads, Ns: resident batches of
+    32 x 128 Ki seeds (a batch holds < 4 GiB of bases), every chunk its own generator seed, generated side by side on this
+    rank's CPUs while the previous group uploads.  Never part of `value`."""
+    from concurrent.futures import ThreadPoolExecutor
+    wl = "150bp_w100_mixed_bins"
+    spec = dict(WORKLOADS[wl])
+    params = host.default_params(variant=args.variant, zdrop=args.zdrop, w=spec["w"])
+    chunk, per_batch = 131072, 32
+    nchunks = (n_seeds + chunk - 1) // chunk
+    groups = [list(range(i, min(i + per_batch, nchunks))) for i in range(0, nchunks, per_batch)]
+    gb = per_batch * host.synth_arena_bound(chunk, **spec) + 4096
+    arenas = [host.HostArena(gb) for _ in range(2 if len(groups) > 1 else 1)]
+    pool = ThreadPoolExecutor(max_workers=max(1, min(len(cpu_affinity or [0]), 32)))
+    t0 = time.perf_counter()
+
+    def generate(gi):
+        grp, ar = groups[gi], arenas[gi % len(arenas)]
+        sizes = [min(chunk, n_seeds - c * chunk) for c in grp]
+        tg = np.zeros(int(sum(sizes)), dtype=host.TASK)
+        offs = np.concatenate([[0], np.cumsum([host.synth_arena_bound(sz, **spec) for sz in sizes])]).astype(np.int64)
+        starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+        def one(k):
+            t, _ = host.synth_tasks(sizes[k], arena=ar.u8[int(offs[k]):], seed=7000 + grp[k], **spec)
+            tg[int(starts[k]):int(starts[k]) + sizes[k]] = t
+        return tg, [pool.submit(one, k) for k in range(len(grp))]
+
+    batches, sides = [], 0
+    nxt = generate(0)
+    for gi in range(len(groups)):
+        tg, futs = nxt
+        for f in futs:
+            f.result()
+        nxt = generate(gi + 1) if gi + 1 < len(groups) else None
+        batches.append(ctx.upload(params, tg))
+        sides += int((tg["lqlen"] > 0).sum() + (tg["rqlen"] > 0).sum())
+    pool.shutdown()
+    setup_s = time.perf_counter() - t0
+    for ar in arenas:
+        ar.free()
+    for b in batches:
+        ctx.run(b)
+    ctx.sync(); ctx.run_history()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        for b in batches:
+            ctx.run(b)
+    ctx.sync()
+    wall = time.perf_counter() - t1
+    kms = ctx.run_history()
+    step_ms = [float(sum(kms[i:i + len(batches)])) for i in range(0, len(kms), len(batches))]
+    cells, launches = 0, 0
+    for b in batches:
+        r = ctx.download(b)
+        cells += cells_of(r)
+        launches += b.info()["launches"]
+        b.free()
+    ms = float(np.mean(step_ms))
+    gc = cells / (ms * 1e-3) / 1e9
+    pmc, pmc_src = pmc_summary(wl, None)
+    tops = cells * VALU_OPS_PER_CELL / (ms * 1e-3) / 1e12
+    return {"workload": wl, "config": "BASELINE.json configs[2] shape: %d PE seeds (left + right extension each), mixed bins via the batch manager" % n_seeds,
+            "seeds": n_seeds, "extensions": sides, "resident_batches": len(batches), "gcups": round(gc, 1), "ms_per_step": round(ms, 3),
+            "ms_per_step_wall": round(wall / steps * 1e3, 3), "steps": steps, "seeds_per_s": round(n_seeds / (ms * 1e-3), 1),
+            "cells_per_step": cells, "kernel_launches_per_step": launches, "setup_s": round(setup_s, 1),
+            "roofline": {"bound": "valu", "ops_per_cell": VALU_OPS_PER_CELL, "achieved": round(tops, 4), "peak": round(PEAK_VALU_TOPS, 2),
+                         "unit": "T lane-ops/s", "frac": round(tops / PEAK_VALU_TOPS, 5),
+                         "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"), "valu_issue_busy": pmc.get("valu_issue_busy"),
+                         "waves_per_simd_avg": pmc.get("waves_per_simd_avg"),
+                         "counters_source": dict(pmc_src, note="collected on the 1 M-seed instance of this workload (bench.py --workload %s)" % wl)}}
 
 
 def harena_used(tasks):

@@ -1124,6 +1124,9 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         if (pend.active || queued) { errs quiet; (void)sync_stream(ctx, quiet, stream, dev.events[s]); pend.active = false; queued = false; }
         return rc;
     };
+    /* the slot's thread (and the gather threads it starts, which inherit the mask) next to its GPU: the host pass streams the
+     * caller's task array into write-combined pinned staging, and that staging is allocated — first touched — below, from here */
+    pin_this_thread(dev);
     hipError_t he = hipSetDevice(dev.device);
     if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)));
     auto finish = [&]() -> int {                    /* the slot's chunk in flight: wait (watchdog), hand the results over */

@@ -186,6 +186,76 @@ static void ctx_release(bsw_ctx *ctx)
     delete ctx;
 }
 
+/* "0-3,8,10-11" -> set; returns the number of CPUs, < 0 on a malformed list */
+BSW_LOCAL int parse_cpulist(const char *text, cpu_set_t *out)
+{
+    CPU_ZERO(out);
+    int n = 0;
+    const char *p = text;
+    while (*p) {
+        while (*p == ',' || *p == ' ' || *p == '\n' || *p == '\t') ++p;
+        if (!*p) break;
+        char *end = nullptr;
+        const long lo = strtol(p, &end, 10);
+        if (end == p || lo < 0) return -1;
+        long hi = lo;
+        p = end;
+        if (*p == '-') {
+            hi = strtol(p + 1, &end, 10);
+            if (end == p + 1 || hi < lo) return -1;
+            p = end;
+        }
+        for (long c = lo; c <= hi; ++c)
+            if (c < CPU_SETSIZE && !CPU_ISSET((int)c, out)) { CPU_SET((int)c, out); ++n; }
+    }
+    return n;
+}
+
+/* The CPUs next to a GPU: hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<bdf>/local_cpulist (BSW_SYSFS_PCI replaces the
+ * directory: tests), intersected with what the process may run on.  One manager next to its arrays
+ * (batch_manager.v:745-773); SURVEY.md §8e names NUMA-local host threads as the condition for scaling over 8 GPUs. */
+static void locate_device(dev_state &d, int pin)
+{
+    CPU_ZERO(&d.cpus);
+    d.n_cpus = 0;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), d.device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char *c = bdf; *c; ++c) *c = (char)tolower(*c);
+    d.bdf = bdf;
+    const char *root = getenv("BSW_SYSFS_PCI");
+    const std::string dir = std::string(root ? root : "/sys/bus/pci/devices") + "/" + bdf;
+    char buf[4096];
+    if (FILE *f = fopen((dir + "/numa_node").c_str(), "r")) {
+        if (fgets(buf, sizeof(buf), f)) d.numa_node = atoi(buf);
+        fclose(f);
+    }
+    if (pin < 0) return;
+    cpu_set_t local, mine;
+    int nl = 0;
+    if (FILE *f = fopen((dir + "/local_cpulist").c_str(), "r")) {
+        if (fgets(buf, sizeof(buf), f)) nl = parse_cpulist(buf, &local);
+        fclose(f);
+    }
+    if (nl <= 0 || sched_getaffinity(0, sizeof(mine), &mine) != 0) return;
+    CPU_AND(&d.cpus, &local, &mine);
+    d.n_cpus = CPU_COUNT(&d.cpus);          /* 0: the process is confined to CPUs of another node — leave its threads alone */
+}
+
+BSW_LOCAL void pin_this_thread(const dev_state &d)
+{
+    if (d.n_cpus > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &d.cpus);
+}
+
+extern "C" int bsw_device_placement(const bsw_ctx *ctx, int k, char *bdf, size_t bdf_cap, int *numa_node, int *n_cpus)
+{
+    if (!ctx || k < 0 || (size_t)k >= ctx->devs.size()) return BSW_E_INVAL;
+    const dev_state &d = ctx->devs[(size_t)k];
+    if (bdf && bdf_cap) { strncpy(bdf, d.bdf.c_str(), bdf_cap - 1); bdf[bdf_cap - 1] = 0; }
+    if (numa_node) *numa_node = d.numa_node;
+    if (n_cpus) *n_cpus = d.n_cpus;
+    return BSW_OK;
+}
+
 extern "C" int bsw_create(const bsw_config *cfg, bsw_ctx **out) { return bsw_create_sized(cfg, sizeof(bsw_config), out); }
 
 extern "C" int bsw_create_sized(const bsw_config *cfg, size_t cfg_size, bsw_ctx **out)
@@ -231,6 +301,7 @@ extern "C" int bsw_create_sized(const bsw_config *cfg, size_t cfg_size, bsw_ctx 
         dev_state &d = ctx->devs[(size_t)k];
         d.device = c.devices[k];
         if (hipSetDevice(d.device) != hipSuccess) { ctx_release(ctx); return BSW_E_HIP; }
+        locate_device(d, c.pin_threads);
         d.slots.resize((size_t)c.streams);
         for (int s = 0; s < c.streams; ++s) {
             hipStream_t st = nullptr;

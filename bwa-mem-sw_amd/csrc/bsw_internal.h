@@ -27,6 +27,9 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include "bsw_device.h"
 #include "bsw_stage.h"
 
@@ -190,6 +193,12 @@ struct fork_t {
 
 struct dev_state {
     int device = 0;
+    /* where the card sits: PCI address, NUMA node, and the CPUs next to it that this process may use (empty: not known, or
+     * bsw_config.pin_threads = -1) — the slot threads of the device run there and first-touch their pinned staging there */
+    std::string bdf;
+    int numa_node = -1;
+    cpu_set_t cpus;
+    int n_cpus = 0;
     std::vector<hipStream_t> streams;
     std::vector<fork_t> forks;        /* one per stream */
     std::vector<hipEvent_t> events;   /* one per stream, for the watchdog */
@@ -254,6 +263,8 @@ struct bsw_dev_batch {
 };
 
 /* ---- bsw_ctx.hip ---- */
+BSW_LOCAL void pin_this_thread(const dev_state &d);       /* the calling thread onto the device's CPUs (no-op when unknown) */
+BSW_LOCAL int parse_cpulist(const char *text, cpu_set_t *out);
 BSW_LOCAL int wait_event(bsw_ctx *ctx, errs &e, hipEvent_t ev);
 BSW_LOCAL int sync_stream(bsw_ctx *ctx, errs &e, hipStream_t st, hipEvent_t ev);
 BSW_LOCAL bool is_registered(const void *p, size_t len);

@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
 #ifdef BSW_L2_STAMP
         e.score = (int)(l2_acc[wv][0] >> 4); e.qle = (int)(l2_acc[wv][1] >> 4); e.tle = (int)(l2_acc[wv][2] >> 4);
         e.gtle = (int)(l2_acc[wv][3] >> 4); e.gscore = (int)(wl_t1 - wl_t0);      /* (gscore: the prologue, 10 ns ticks) */
+#if BSW_L2_STAMP == 2
+        e.gscore = (int)(l2_acc[wv][4] >> 4);                                     /* (tools/l2_stamps.py: the row tails instead) */
+#endif
         /* wave log (tools/wave_timeline.py): start / end in 10 ns ticks and where the wave ran (HW_ID: wave, SIMD, CU, SE, XCC) */
         e.max_off = (int)(wl_t0 & 0x7fffffffu); e.aw = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffffu);
         e.cells = ((unsigned)__builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | (15 << 11)) & 0xffffu) |

@@ -95,6 +95,7 @@ def lib():
             "bsw_create": (C.c_int, [vp, C.POINTER(vp)]), "bsw_destroy": (None, [vp]),
             "bsw_create_sized": (C.c_int, [vp, sz, C.POINTER(vp)]), "bsw_abi_version": (C.c_int, []),
             "bsw_chain_timeouts": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+            "bsw_device_placement": (C.c_int, [vp, C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "bsw_last_error": (C.c_char_p, [vp]),
             "bsw_submit": (C.c_int, [vp, vp, vp, sz, vp]), "bsw_wait": (C.c_int, [vp]),
             "bsw_submit_packed": (C.c_int, [vp, vp, vp, sz, vp]),
@@ -152,7 +153,7 @@ def lib():
 
 EXPORTS = ["ksw_global2", "ksw_global", "bsw_global_batch", "bsw_align_batch", "ksw_align2", "ksw_align", "ksw_extend2", "ksw_extend", "bsw_set_default_variant", "bsw_scalar_stats", "bsw_host_alloc", "bsw_host_free",
            "bsw_host_register", "bsw_host_unregister", "bsw_batch_order", "bsw_refbatch_submit", "bsw_refbatch_wait", "bsw_default_params", "bsw_default_config",
-           "bsw_device_count", "bsw_create", "bsw_create_sized", "bsw_abi_version", "bsw_chain_timeouts", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
+           "bsw_device_count", "bsw_create", "bsw_create_sized", "bsw_abi_version", "bsw_chain_timeouts", "bsw_device_placement", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
            "bsw_submit_packed", "bsw_upload_packed", "bsw_pack_tasks", "bsw_pack_tasks_bound",
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
@@ -312,6 +313,13 @@ class BswContext:
     def _chk(self, rc, what):
         if rc:
             raise BswError(rc, "%s: %s" % (what, lib().bsw_last_error(self.handle).decode()))
+
+    def placement(self, k=0):
+        """Where device k of the context sits and whether its slot threads are pinned next to it."""
+        buf = C.create_string_buffer(64)
+        node, ncpu = C.c_int(-1), C.c_int(0)
+        self._chk(lib().bsw_device_placement(self.handle, k, buf, 64, C.byref(node), C.byref(ncpu)), "bsw_device_placement")
+        return dict(bdf=buf.value.decode(), numa_node=node.value, pinned_cpus=ncpu.value)
 
     def chain_timeouts(self):
         """Waits of the launch chain that ended at their deadline (0 unless kernels are being run one at a time)."""

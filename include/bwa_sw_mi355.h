@@ -188,6 +188,9 @@ void     bsw_default_config(bsw_config *c);
 int      bsw_device_count(void);                     /* gfx950 devices visible; <=0 if none */
 int      bsw_create(const bsw_config *cfg, bsw_ctx **out);
 int      bsw_create_sized(const bsw_config *cfg, size_t cfg_size, bsw_ctx **out);   /* cfg_size = the CALLER's sizeof(bsw_config) */
+/* Where device k of the context (index into bsw_config.devices[]) sits: PCI address ("0000:c1:00.0"), NUMA node (-1: the
+ * kernel does not say) and how many CPUs next to it the context's slot threads are pinned to (0: not pinned). */
+int      bsw_device_placement(const bsw_ctx *ctx, int k, char *bdf, size_t bdf_cap, int *numa_node, int *n_cpus);
 int      bsw_abi_version(void);                      /* BSW_ABI_VERSION the library was built with */
 /* How many of the launch chain's waiting waves gave up at their 20 ms deadline so far (the chain's flag is a
  * scheduling hint, a follower released early is still correct).  Non-zero where kernels are run one at a time

@@ -88,3 +88,55 @@ def test_bench_gpus_2_without_torchrun_runs_two_ranks():
     assert abs(strong["seeds_per_s"] * strong["ms_per_step"] / 1e3 - 700000) < 350
     one = _bench("--gpus", "1", "--preset", "configs3", "--pool", "700000", "--resident-chunks", "2", *common[3:])
     assert one["n_gpus"] == 1 and one["cells_per_step"] == strong["cells_per_step"]      # same pool, same cells, however it is sharded
+
+
+def test_config3_100m_pool_n1():
+    """BASELINE.json configs[3] at FULL size on one GPU: `bench.py --preset configs3` — 100 M PE mixed-bin seeds, one pool,
+    per-read task shard (all of it on rank 0 here), 24 resident batches of 4.2 M seeds generated on the rank's CPUs.  No oracle
+    finishes 100 M seeds inside a test, so: (1) the exact cell count of a strided sample of chunks (every 97th: 8 chunks,
+    1 M seeds) is re-derived by regenerating those chunks from their generator seeds and running the CPU oracle on them;
+    (2) size-independent properties — every seed of the pool was processed exactly once (seeds/s x step time), cells per
+    seed agree with the sampled chunks' to 1 %, extensions per seed are those of the workload."""
+    import __graft_entry__ as graft
+    import bench
+    line = _bench("--gpus", "1", "--preset", "configs3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-extra", timeout=900)
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and cfg["pool_seeds"] == 100_000_000 and cfg["preset"] == "configs3"
+    assert cfg["resident_batches_per_rank"] == 24
+    assert abs(line["seeds_per_s"] * line["ms_per_step"] / 1e3 - 1e8) < 5e4
+    host, orc = graft.load_package().host, graft.load_oracle()
+    spec = dict(bench.WORKLOADS["150bp_w100_mixed_bins"])
+    p = host.default_params(w=spec["w"])
+    sample = cfg["rank0_chunk_cells_sample"]
+    assert sample["every"] == 97 and len(sample["cells"]) == 8
+    tot_cells = tot_seeds = 0
+    for c, got in sorted(sample["cells"].items(), key=lambda kv: int(kv[0])):
+        t, _ = host.synth_tasks(sample["chunk_seeds"], seed=5000 + int(c), **spec)
+        want = orc.pair_batch_avx2(p, t, nthreads=8)
+        wc = int(want["left"]["cells"].astype(np.int64).sum() + want["right"]["cells"].astype(np.int64).sum())
+        assert got == wc, (c, got, wc)
+        tot_cells += wc; tot_seeds += len(t)
+    per_seed_sample, per_seed_pool = tot_cells / tot_seeds, line["cells_per_step"] / 1e8
+    assert abs(per_seed_pool / per_seed_sample - 1) < 0.01, (per_seed_pool, per_seed_sample)
+    assert 1.6 < line["extensions_per_s"] / line["seeds_per_s"] < 2.1          # left + right side for nearly every seed
+    assert line["value"] > 1000                                                  # GCUPS: the lane kernels ran, not the general path
+
+
+def test_slot_threads_are_pinned_next_to_the_card():
+    """bsw_create finds the card's PCI address, NUMA node and local CPUs (sysfs) and the streaming pipeline's slot threads
+    pin themselves there (bsw_config.pin_threads, default on; -1 leaves them alone); results do not depend on it."""
+    import re
+    import __graft_entry__ as graft
+    host, orc = graft.load_package().host, graft.load_oracle()
+    tasks, arena = host.synth_tasks(30000, seed=9, seed_at_start=0, seed_len_min=19, seed_len_max=60, junk_frac=0.1)
+    p = host.default_params()
+    want = orc.pair_batch(p, tasks, nthreads=8)
+    with host.BswContext(device=0, chunk_tasks=8192) as c:
+        pl = c.placement()
+        assert re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-7]", pl["bdf"]), pl
+        has_sysfs = os.path.exists("/sys/bus/pci/devices/%s/local_cpulist" % pl["bdf"])
+        assert (pl["pinned_cpus"] > 0) == has_sysfs, pl
+        assert c.extend_pairs(p, tasks).tobytes() == want.tobytes()
+    with host.BswContext(device=0, chunk_tasks=8192, pin_threads=False) as c:
+        assert c.placement()["pinned_cpus"] == 0
+        assert c.extend_pairs(p, tasks).tobytes() == want.tobytes()

@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
-"""Section timing of the lane2 row loop from a -DBSW_L2_STAMP build (libbwasw_stamp.so): cycles per wave spent in
-loop top, wave reductions, match words, cell blocks, row tails."""
-import ctypes as C, json, os, sys
+"""Section timing of the lane2 row loop from a `make stamp STAMP_MODE=2` build (libbwasw_stamp.so): cycles per wave spent in
+loop top, wave reductions, match words, cell blocks, row tails — per side, for any bench.py workload.
+Usage: l2_stamps.py [seeds] [workload]"""
+import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["BSW_LIB_PATH"] = os.path.join(ROOT, "bwa-mem-sw_amd", "libbwasw_stamp.so")     # read by host.py when it is imported
 import __graft_entry__ as graft
+import bench
 pkg = graft.load_package()
 host = pkg.host
-host._LIB = os.path.join(os.path.dirname(host._LIB), "libbwasw_stamp.so")
+assert host.lib_path().endswith("libbwasw_stamp.so")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-p = host.default_params()
-tasks, arena = host.synth_tasks(n, seed=1000)
+wl = sys.argv[2] if len(sys.argv) > 2 else "150bp_w100_single_bin"
+spec = dict(bench.WORKLOADS[wl])
+p = host.default_params(w=spec["w"], max_band_try=1)      # (no second band try: the stamped records would send every seed to the redo list)
+tasks, arena = host.synth_tasks(n, seed=1000, **spec)
 with host.BswContext(device=0, kernel=2) as c:
-    b = c.upload(p, tasks); c.run(b); c.sync(); c.run_history(); c.run(b); c.sync(); ms = c.run_history()
+    b = c.upload(p, tasks)
+    for _ in range(3):
+        c.run(b)
+    c.sync(); c.run_history(); c.run(b); c.sync(); ms = c.run_history()
     res = c.download(b)
-r = res["right"]
 names = ["loop top + row_begin", "reductions", "match words + consts", "cell blocks", "row tails"]
-tot = 0
-vals = []
-for f in ("score", "qle", "tle", "gtle", "gscore"):
-    v = r[f].astype(np.float64) * 16
-    vals.append(v.mean()); tot += v.mean()
-print(json.dumps({"kernel_ms": ms, "cycles_per_wave_total": tot, "sections": {k: [round(v), round(v / tot, 3)] for k, v in zip(names, vals)}}))
+out = {"workload": wl, "seeds": n, "kernel_ms": ms}
+for side, qf in (("left", "lqlen"), ("right", "rqlen")):
+    sel = tasks[qf] > 0
+    if not sel.any():
+        continue
+    r = res[side][sel]
+    vals = [float((r[f].astype(np.float64) * 16).mean()) for f in ("score", "qle", "tle", "gtle", "gscore")]
+    tot = sum(vals)
+    out[side] = {"cycles_per_wave_total": round(tot), "sections": {k: [round(v), round(v / tot, 3)] for k, v in zip(names, vals)}}
+print(json.dumps(out))
