@@ -874,8 +874,11 @@ def main():
             ms = float(np.mean(ctx.run_history()))
             r2 = ctx.download(b2)
             g2 = cells_of(r2) / (ms * 1e-3) / 1e9
+            pm2, src2 = pmc_summary(wl, args.tasks)
             extra[wl] = {"gcups": round(g2, 1), "ms_per_step": round(ms, 3), "seeds": args.tasks,
-                         "roofline_frac": round(g2 * 1e9 * VALU_OPS_PER_CELL / 1e12 / PEAK_VALU_TOPS, 4), "kernel_launches_per_step": b2.info()["launches"]}
+                         "roofline_frac": round(g2 * 1e9 * VALU_OPS_PER_CELL / 1e12 / PEAK_VALU_TOPS, 4), "kernel_launches_per_step": b2.info()["launches"],
+                         "valu_insts_per_cell": pm2.get("valu_lane_insts_per_cell"), "valu_issue_busy": pm2.get("valu_issue_busy"),
+                         "counters": src2.get("status")}
             b2.free()
         out["other_workloads"] = extra
         if args.pe_seeds > 0 and args.workload != "150bp_w100_mixed_bins":
