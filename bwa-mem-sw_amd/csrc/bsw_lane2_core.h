@@ -85,20 +85,42 @@ L2_FN int popc(uint32_t x) { return __builtin_popcount(x); }
 L2_FN int clz32(uint32_t x) { return __builtin_clz(x); }
 /* the looped kernel's per-block folds (row maximum, K8 trackers: see lane2l::row_body) as one aligned statement, ordered so
  * that no packed result is read by the instruction behind it */
+template <bool GRID = true>
 L2_FN void fold8(uint32_t &mk2, uint32_t &Fnz, uint32_t &Lnz, uint32_t mkb, uint32_t nz8, uint32_t J0d, uint32_t J0h, uint32_t ONE2)
 {
     uint32_t t0, t1, t2;
-    asm volatile(".p2align 3\n\t"
-                 "v_pk_min_u16 %[t0], %[nz], %[ONE]\n\t"
-                 "v_pk_add_u16 %[t1], %[mkb], %[J0d]\n\t"
-                 "v_pk_mad_u16 %[t0], %[t0], %[J0h], %[nz]\n\t"
-                 "v_pk_max_u16 %[mk2], %[mk2], %[t1]\n\t"
-                 "v_pk_sub_u16 %[t2], %[t0], %[ONE]\n\t"
-                 "v_pk_max_u16 %[L], %[L], %[t0]\n\t"
-                 "v_pk_min_u16 %[F], %[F], %[t2]"
-                 : [mk2] "+v"(mk2), [F] "+v"(Fnz), [L] "+v"(Lnz), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
-                 : [nz] "v"(nz8), [mkb] "v"(mkb), [J0d] "s"(J0d), [J0h] "s"(J0h), [ONE] "s"(ONE2));
+#define BSW_FOLD8_BODY "v_pk_min_u16 %[t0], %[nz], %[ONE]\n\t"         \
+                       "v_pk_add_u16 %[t1], %[mkb], %[J0d]\n\t"        \
+                       "v_pk_mad_u16 %[t0], %[t0], %[J0h], %[nz]\n\t"  \
+                       "v_pk_max_u16 %[mk2], %[mk2], %[t1]\n\t"        \
+                       "v_pk_sub_u16 %[t2], %[t0], %[ONE]\n\t"         \
+                       "v_pk_max_u16 %[L], %[L], %[t0]\n\t"            \
+                       "v_pk_min_u16 %[F], %[F], %[t2]"
+#define BSW_FOLD8_OPS : [mk2] "+v"(mk2), [F] "+v"(Fnz), [L] "+v"(Lnz), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) \
+                      : [nz] "v"(nz8), [mkb] "v"(mkb), [J0d] "s"(J0d), [J0h] "s"(J0h), [ONE] "s"(ONE2)
+    /* (the looped kernel keeps its block loop on the 8-byte fetch grid; the unrolled one does not pad) */
+    if (GRID) asm volatile(".p2align 3\n\t" BSW_FOLD8_BODY BSW_FOLD8_OPS);
+    else asm volatile(BSW_FOLD8_BODY BSW_FOLD8_OPS);
+#undef BSW_FOLD8_BODY
+#undef BSW_FOLD8_OPS
 }
+/* ---- the row scalars of both seeds in one register (pairv below): a few more packed forms, and SDWA forms that read ONE
+ * half / byte of a packed register (gfx9 SDWA: VOP1 / VOP2 only) ---- */
+L2_FN uint32_t pk_subs_sv(uint32_t sa, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "s"(sa), "v"(b)); return d; }   /* scalar - vector, saturating */
+L2_FN uint32_t pk_sub_sv(uint32_t sa, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "s"(sa), "v"(b)); return d; }          /* wrapping */
+L2_FN uint32_t pk_adds(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+L2_FN uint32_t pk_mul_sat(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_mad_u16 %0, %1, %2, 0 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }   /* a * b, 0xffff on overflow */
+L2_FN uint32_t pk_mul_sat_vs(uint32_t a, uint32_t sb) { uint32_t d; asm("v_pk_mad_u16 %0, %1, %2, 0 clamp" : "=v"(d) : "v"(a), "s"(sb)); return d; }
+L2_FN uint32_t min_halves(uint32_t a) { uint32_t d; asm("v_min_u16_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(d) : "v"(a)); return d; }
+L2_FN uint32_t max_halves(uint32_t a) { uint32_t d; asm("v_max_u16_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(d) : "v"(a)); return d; }
+/* lowest set bit of byte K of a (0xffffffff: the byte is 0); v_ffbh of the zero-extended byte K (24 + leading zeros inside the byte, 0xffffffff for 0) */
+template <int K>
+L2_FN uint32_t ffbl_byte(uint32_t a) { uint32_t d; if (K == 0) asm("v_ffbl_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(d) : "v"(a)); else asm("v_ffbl_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(d) : "v"(a)); return d; }
+template <int K>
+L2_FN uint32_t ffbh_byte(uint32_t a) { uint32_t d; if (K == 0) asm("v_ffbh_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(d) : "v"(a)); else asm("v_ffbh_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(d) : "v"(a)); return d; }
+/* a + byte K of b (K = 1 or 3: the high byte of a half) */
+template <int K>
+L2_FN uint32_t add_byte(uint32_t a, uint32_t b) { uint32_t d; if (K == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(a), "v"(b)); else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(a), "v"(b)); return d; }
 /* a wave-uniform value the compiler must re-read here: keeps tests on it from being hoisted out of the row loop */
 L2_FN uint32_t opaque_s(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
 /* the same for a value the compiler may have computed on the vector side although it is wave-uniform */
@@ -138,6 +160,20 @@ L2_FN uint32_t pk_neg(uint32_t a) { return pk_sub(0u, a); }
 L2_FN uint32_t byte_pair_dyn(uint32_t a, uint32_t b, uint32_t k) { return ((a >> (8 * k)) & 0xffu) | (((b >> (8 * k)) & 0xffu) << 16); }
 L2_FN int popc(uint32_t x) { return __builtin_popcount(x); }
 L2_FN int clz32(uint32_t x) { return __builtin_clz(x); }
+L2_FN uint32_t pk_subs_sv(uint32_t sa, uint32_t b) { return pk_subs(sa, b); }
+L2_FN uint32_t pk_sub_sv(uint32_t sa, uint32_t b) { return pk_sub(sa, b); }
+L2_FN uint32_t pk_adds(uint32_t a, uint32_t b) { return pk_adds_vs(a, b); }
+L2_FN uint32_t pk_mul_sat(uint32_t a, uint32_t b) { const uint32_t lo = (uint32_t)lo16(a) * lo16(b), hi = (uint32_t)hi16(a) * hi16(b); return mk2(lo > 0xffffu ? 0xffffu : lo, hi > 0xffffu ? 0xffffu : hi); }
+L2_FN uint32_t pk_mul_sat_vs(uint32_t a, uint32_t sb) { return pk_mul_sat(a, sb); }
+L2_FN uint32_t min_halves(uint32_t a) { return lo16(a) < hi16(a) ? lo16(a) : hi16(a); }
+L2_FN uint32_t max_halves(uint32_t a) { return lo16(a) > hi16(a) ? lo16(a) : hi16(a); }
+template <int K>
+L2_FN uint32_t ffbl_byte(uint32_t a) { return ffbl((a >> (8 * K)) & 0xffu); }
+template <int K>
+L2_FN uint32_t ffbh_byte(uint32_t a) { return ffbh((a >> (8 * K)) & 0xffu); }
+template <int K>
+L2_FN uint32_t add_byte(uint32_t a, uint32_t b) { return a + ((b >> (8 * K)) & 0xffu); }
+template <bool GRID = true>
 L2_FN void fold8(uint32_t &mk2, uint32_t &Fnz, uint32_t &Lnz, uint32_t mkb, uint32_t nz8, uint32_t J0d, uint32_t J0h, uint32_t ONE2)
 {
     const uint32_t key = pk_mad_vsv(pk_min_vs(nz8, ONE2), J0h, nz8);
@@ -164,6 +200,7 @@ struct consts {
     uint32_t OED2s, ED2s, OEI2s, EI2s, ONE2;   /* {oe_del,oe_del} << 8, {e_del,e_del} << 8, the same for insertions, {1,1} */
     uint32_t MC[8];                     /* {a+pb, a+pb} << (8 - c): match bit c of a block byte -> (a + pb) << 8 */
     uint32_t HI2;                       /* 0xff00ff00: the score bytes (kept in a VGPR by the kernel) */
+    uint32_t EDp, EIp, ZD2;             /* row tail (K7): {e_del,e_del}, {e_ins,e_ins} unscaled; {zdrop,zdrop}, 0xffff when zdrop is off */
 };
 
 /* the packed constants from the scalar ones (o_del + e_del < 256, o_ins + e_ins < 256 and a + pb < 256: lane2_params_ok) */
@@ -176,6 +213,9 @@ L2_FN void fill_packed_consts(consts &k)
     k.ONE2 = 0x00010001u;
     for (int c = 0; c < 8; ++c) k.MC[c] = dup16((k.a + k.pb) << (8 - c));
     k.HI2 = 0xff00ff00u;
+    k.EDp = dup16(k.e_del);
+    k.EIp = dup16(k.e_ins);
+    k.ZD2 = k.zdrop > 0 ? dup16(k.zdrop < 0xffff ? k.zdrop : 0xffff) : 0xffffffffu;
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) && defined(BSW_L2_ASM_BODY)
@@ -183,21 +223,121 @@ L2_FN void fill_packed_consts(consts &k)
 #include "bsw_lane2_body_asm.inc"
 #endif
 
-struct seedv {                          /* the scalars of one ksw_extend2 call (K1/K9) */
-    int qlen, tlen, h0, w, beg, end;
-    int mx, max_i, max_j, max_ie, gscore, max_off;
-    unsigned cells;
-    bool alive;
+/* The scalars of the TWO ksw_extend2 calls of a lane (K1/K9), packed like everything else: seed A in the low, seed B in the
+ * high 16 bits.  Round 5: the row head (K3) and tail (K7, K8) used to run per seed in int32 — ~230 VALU instructions per
+ * row behind the cell blocks, a quarter of a short row — and now run once for both seeds in packed 16-bit ops: compare =
+ * saturating subtract + "non-zero -> 0xffff" (v_pk_mad_u16 x, -1, 0 clamp), select = one bit-select.  Everything fits 16
+ * bits: columns < 256, rows < 65535 (BSW_MAX_TLEN), scores < 256 in these classes; the values that start at -1 are kept + 1. */
+struct pairv {
+    uint32_t BEG, END;                  /* [beg, end) of the current row */
+    uint32_t QLEN, TLEN, W, W1, H0;     /* constants of the call; W = min(w, 0xffff), W1 = min(w + 1, 0xffff) */
+    uint32_t MX, MAXI1, MAXJ1, MAXIE1, GS1, MOFF;   /* max, max_i + 1, max_j + 1, max_ie + 1, gscore + 1, max_off */
+    uint32_t ALIVE;                     /* 0xffff in a half whose band try still has rows */
+    uint32_t CELLS16;                   /* cells of the rows since the last flush (< 64 rows x 232 columns) */
+    unsigned cells[2];
 };
 
 struct u4 {                             /* four consecutive 32-bit words (one 128-bit LDS read) */
     uint32_t v[4];
 };
 
-struct rowv {                           /* per-lane values of the current row, both seeds */
-    bool act[2], bite[2];
-    int len[2], zlo[2], zhi[2];
+struct rowp {                           /* per-lane values of the current row, both seeds packed */
+    uint32_t ACT, BITE;                 /* 0xffff per half: the seed has a row i / the band clamp moved its beg */
+    uint32_t ZLO, ZHI;                  /* the columns [zlo, zhi) the clamp dropped */
 };
+
+L2_FN int half_of(uint32_t v, int x) { return (int)((v >> (16 * x)) & 0xffffu); }
+L2_FN void set_half(uint32_t &v, int x, uint32_t val) { v = x ? ((v & 0x0000ffffu) | (val << 16)) : ((v & 0xffff0000u) | (val & 0xffffu)); }
+
+/* one side of one seed into half x (K1: sw_pe_array_sw_extend.v:889,919,1009,929: max = h0, max_i = max_j = -1, max_off = 0) */
+L2_FN void init_pair(pairv &p, int x, int qlen, int tlen, int h0, int w)
+{
+    if (x == 0) { p.BEG = p.END = p.QLEN = p.TLEN = p.W = p.W1 = p.H0 = p.MX = p.MAXI1 = p.MAXJ1 = p.MAXIE1 = p.GS1 = p.MOFF = p.ALIVE = p.CELLS16 = 0; }
+    set_half(p.END, x, (uint32_t)qlen); set_half(p.QLEN, x, (uint32_t)qlen); set_half(p.TLEN, x, (uint32_t)tlen);
+    set_half(p.W, x, (uint32_t)imin(w, 0xffff)); set_half(p.W1, x, (uint32_t)imin(w, 0xfffe) + 1u);
+    set_half(p.H0, x, (uint32_t)h0); set_half(p.MX, x, (uint32_t)h0);
+    set_half(p.ALIVE, x, tlen > 0 ? 0xffffu : 0u);
+    p.cells[x] = 0;
+}
+
+struct ext_out { int mx, max_i, max_j, max_ie, gscore, max_off; unsigned cells; };
+/* K9: the outputs of half x */
+L2_FN ext_out pair_result(const pairv &p, int x)
+{
+    ext_out e;
+    e.mx = half_of(p.MX, x); e.max_i = half_of(p.MAXI1, x) - 1; e.max_j = half_of(p.MAXJ1, x) - 1;
+    e.max_ie = half_of(p.MAXIE1, x) - 1; e.gscore = half_of(p.GS1, x) - 1; e.max_off = half_of(p.MOFF, x);
+    e.cells = p.cells[x] + (unsigned)half_of(p.CELLS16, x);
+    return e;
+}
+
+/* K3 band clamp for both seeds (:1803,1894-1897,1842,1898): beg = max(beg, i - w), end = min(end, i + w + 1, qlen).  A clamp
+ * that moves beg may drop non-zero eh entries: the columns [zlo, zhi) it drops are zeroed by zero_dropped() to keep the
+ * "eh[j] == 0 below beg" invariant.  I2 = {i, i} (wave-uniform). */
+L2_FN void row_begin2(pairv &p, const int i, rowp &r)
+{
+    const uint32_t I2 = dup16(i);
+    if (__builtin_expect((i & 63) == 0, 0)) {        /* (rare) the 16-bit cell counters into the 32-bit ones */
+        p.cells[0] += p.CELLS16 & 0xffffu; p.cells[1] += p.CELLS16 >> 16; p.CELLS16 = 0;
+    }
+    const uint32_t act = p.ALIVE & pk_nzmask(pk_subs_vs(p.TLEN, I2));          /* alive and i < tlen */
+    const uint32_t nb = pk_max(p.BEG, pk_subs_sv(I2, p.W));
+    const uint32_t ne = pk_min(pk_min(p.END, pk_adds_vs(p.W1, I2)), p.QLEN);
+    r.ACT = act;
+    r.BITE = act & pk_nzmask(pk_subs(nb, p.BEG));
+    r.ZLO = p.BEG; r.ZHI = nb;
+    p.BEG = (act & nb) | (~act & p.BEG);
+    p.END = (act & ne) | (~act & p.END);
+    p.CELLS16 += pk_subs(p.END, p.BEG) & act;        /* (no carry between the halves: flushed every 64 rows) */
+}
+
+/* K7 + K8 for both seeds, after the row's cells: h1 = H(i, end - 1) scaled (high byte of each half), mk2 = (row max << 8) |
+ * its column per half (0: no positive cell), Fnz / Lnz = the packed first / last non-zero trackers of the row's blocks:
+ *   Lnz half = (j0 << 8) | bits of the HIGHEST block with a non-zero stored eh entry (j0 = 8 b its first column), 0: none
+ *   Fnz half = the same key of the LOWEST such block, minus 1; 0xffff: none.
+ * (:1829-1833 gscore / max_ie, ties -> later i; :1959,1810,1845 new maximum; zdrop; :1942 m == 0; K8: CPU semantics of
+ * SURVEY.md §8a, quirk Q5 avoided.) */
+template <bool SYM>
+L2_FN void row_tail2(pairv &p, const consts &k, const int i, const uint32_t act, const uint32_t h1, const uint32_t mk2,
+                     const uint32_t Fnz, const uint32_t Lnz)
+{
+    const uint32_t I2 = dup16(i), IP1 = dup16(i + 1);
+    const uint32_t H1P = pk_shr8(h1) + k.ONE2;                           /* eh[end].h + 1 (<= 256: no carry between the halves) */
+    const uint32_t M = pk_shr8(mk2), MJ = mk2 & 0x00ff00ffu, MJ1 = MJ + k.ONE2;
+    /* K7: the row reached the end of the query */
+    const uint32_t atq = act & ~pk_nzmask(pk_max(p.BEG, p.END) ^ p.QLEN);
+    const uint32_t sie = atq & ~pk_nzmask(pk_subs(p.GS1, H1P));          /* ... and h1 >= gscore: ties -> later i */
+    p.MAXIE1 = (sie & IP1) | (~sie & p.MAXIE1);
+    const uint32_t gsm = pk_max(p.GS1, H1P);
+    p.GS1 = (atq & gsm) | (~atq & p.GS1);
+    /* K7: a new maximum; zdrop against the OLD one */
+    const uint32_t gt = act & pk_nzmask(pk_subs(M, p.MX));
+    const uint32_t off = pk_subs_sv(I2, MJ) | pk_subs_vs(MJ, I2);        /* |mj - i| */
+    const uint32_t A = pk_adds(pk_sub_sv(IP1, p.MAXI1), p.MAXJ1);        /* (i - max_i) + (max_j + 1); saturated = far beyond any zdrop */
+    const uint32_t dpos = pk_subs(A, MJ1), dneg = pk_subs(MJ1, A);       /* dd = (i - max_i) - (mj - max_j): its positive / negative part */
+    const uint32_t ad = dpos | dneg;
+    uint32_t prod;
+    if (SYM) prod = pk_mul_sat_vs(ad, k.EDp);
+    else { const uint32_t pos = pk_nzmask(dpos); prod = pk_mul_sat(ad, (pos & k.EDp) | (~pos & k.EIp)); }   /* rows ahead: a deletion's penalty */
+    const uint32_t lhs = pk_subs_vs(pk_subs(p.MX, M), k.ZD2);            /* mx - m - zdrop, 0 when not positive (or zdrop off) */
+    const uint32_t zstop = pk_nzmask(pk_subs(lhs, prod)) & ~gt;
+    const uint32_t stop = ~pk_nzmask(M) | zstop;                         /* (:1942) */
+    const uint32_t mo = pk_max(p.MOFF, off);
+    p.MOFF = (gt & mo) | (~gt & p.MOFF);
+    p.MAXI1 = (gt & IP1) | (~gt & p.MAXI1);
+    p.MAXJ1 = (gt & MJ1) | (~gt & p.MAXJ1);
+    p.MX = (gt & M) | (~gt & p.MX);
+    /* K8 next-row range: first / last non-zero eh entry in [beg, end] */
+    const uint32_t nF = ~Fnz;                                            /* low byte of a half: ~(bits - 1): its trailing zeros = ctz(bits) */
+    const uint32_t f0 = add_byte<1>(ffbl_byte<0>(nF), Fnz), f1 = add_byte<3>(ffbl_byte<2>(nF), Fnz);   /* j0 + ctz(bits); 254 when none */
+    const uint32_t nbeg = pk_min(f0 | (f1 << 16), p.END);                /* (f0, l0 < 2^16: no mask needed) */
+    const uint32_t l0 = add_byte<1>(32u - ffbh_byte<0>(Lnz), Lnz), l1 = add_byte<3>(32u - ffbh_byte<2>(Lnz), Lnz);   /* last + 1 */
+    const uint32_t LN1 = (l0 | (l1 << 16)) & pk_nzmask(Lnz);             /* 0 when none */
+    const uint32_t nend = pk_min(pk_max(LN1, nbeg) + k.ONE2, p.QLEN);    /* min(last + 2, qlen), last = nbeg - 1 when nothing is left */
+    p.BEG = (act & nbeg) | (~act & p.BEG);
+    p.END = (act & nend) | (~act & p.END);
+    p.ALIVE = (act & ~stop) | (~act & p.ALIVE);
+}
 
 struct uni {                            /* wave-uniform values of the current row */
     int jlo, jhi, jem;                  /* min beg, max end, min end over the active seeds of the wave */
@@ -218,55 +358,33 @@ struct lane2 {
 
     struct state {
         uint32_t Pr[QMAX];              /* eh[] row: half = {e:8 | h:8} */
-        seedv s[2];
+        pairv p;                        /* the scalars of both seeds, packed */
     };
 
     /* K2 first row, closed form: eh[0]=h0, eh[j]=max(h0-oe_ins-(j-1)e_ins,0), e=0 (sw_pe_array_sw_extend.v:1979,1957,1974) */
     L2_MFN void init_row(state &S, const consts &k)
     {
+        const int h00 = half_of(S.p.H0, 0), h01 = half_of(S.p.H0, 1);
         sfor<QMAX>([&](auto ci) {
             constexpr int j = decltype(ci)::value;
-            const int v0 = j == 0 ? S.s[0].h0 : imax(S.s[0].h0 - k.oe_ins - (j - 1) * k.e_ins, 0);
-            const int v1 = j == 0 ? S.s[1].h0 : imax(S.s[1].h0 - k.oe_ins - (j - 1) * k.e_ins, 0);
+            const int v0 = j == 0 ? h00 : imax(h00 - k.oe_ins - (j - 1) * k.e_ins, 0);
+            const int v1 = j == 0 ? h01 : imax(h01 - k.oe_ins - (j - 1) * k.e_ins, 0);
             S.Pr[j] = pack2(v0, v1);
         });
     }
 
-    L2_MFN void init_seed(seedv &s, int qlen, int tlen, int h0, int w)
+    L2_MFN void zero_dropped(state &S, const rowp &r, const uni &u)
     {
-        s.qlen = qlen; s.tlen = tlen; s.h0 = h0; s.w = w; s.beg = 0; s.end = qlen;
-        s.mx = h0; s.max_i = s.max_j = s.max_ie = s.gscore = -1; s.max_off = 0; s.cells = 0;
-        s.alive = tlen > 0;
-    }
-
-    /* K3 band clamp (:1803,1894-1897,1842,1898).  A clamp that moves beg may drop non-zero eh entries: the columns
-     * [zlo, zhi) it drops are zeroed by zero_dropped() to keep the "eh[j] == 0 below beg" invariant. */
-    L2_MFN void row_begin(state &S, int i, rowv &r)
-    {
-        sfor<2>([&](auto xi) {
-            constexpr int x = decltype(xi)::value;
-            seedv &s = S.s[x];
-            r.act[x] = s.alive && i < s.tlen;
-            const int nb = imax(s.beg, i - s.w), ne = imin(imin(s.end, i + s.w + 1), s.qlen);
-            r.bite[x] = r.act[x] && nb > s.beg;
-            r.zlo[x] = s.beg; r.zhi[x] = nb;
-            s.beg = r.act[x] ? nb : s.beg;
-            s.end = r.act[x] ? ne : s.end;
-            r.len[x] = imax(s.end - s.beg, 0);
-            s.cells += r.act[x] ? (unsigned)r.len[x] : 0u;
-        });
-    }
-
-    L2_MFN void zero_dropped(state &S, const rowv &r, const uni &u)
-    {
+        const bool b0 = (r.BITE & 0xffffu) != 0, b1 = (r.BITE >> 16) != 0;
+        const int zlo0 = half_of(r.ZLO, 0), zlo1 = half_of(r.ZLO, 1), zhi0 = half_of(r.ZHI, 0), zhi1 = half_of(r.ZHI, 1);
         sfor<QB>([&](auto bi) {
             constexpr int j0 = decltype(bi)::value * 8;
             if (j0 + 8 <= u.zl || j0 >= u.zh) return;
             sfor<8>([&](auto ci) {
                 constexpr int J = j0 + decltype(ci)::value;
                 uint32_t keep = 0xffffffffu;
-                if (r.bite[0] && J >= r.zlo[0] && J < r.zhi[0]) keep &= 0xffff0000u;
-                if (r.bite[1] && J >= r.zlo[1] && J < r.zhi[1]) keep &= 0x0000ffffu;
+                if (b0 && J >= zlo0 && J < zhi0) keep &= 0xffff0000u;
+                if (b1 && J >= zlo1 && J < zhi1) keep &= 0x0000ffffu;
                 S.Pr[J] &= keep;
             });
         });
@@ -415,29 +533,29 @@ struct lane2 {
      * qp(x, b, rm): per-base match words of seed x, kp(b, kw): keep-table entry (see match_words); wn(c): N planes of both seeds interleaved per
      * 16-column chunk (low half seed A). */
     template <class QP, class KP, class WN>
-    L2_MFN void row_body(state &S, const consts &k, const int i, const rowv &r, const uni &u, const int (&tb)[2],
+    L2_MFN void row_body(state &S, const consts &k, const int i, const rowp &r, const uni &u, const int (&tb)[2],
                                const QP &qp, const KP &kp, const WN &wn)
     {
+        pairv &p = S.p;
         if (__builtin_expect(u.anybite, 0)) zero_dropped(S, r, u);   /* (rare; 136 masked moves kept out of the hot path's layout) */
         uint32_t rmA[NW], rmB[NW];
-        match_words(qp, kp, 0, tb[0], S.s[0].beg, rmA);
-        match_words(qp, kp, 1, tb[1], S.s[1].beg, rmB);
+        match_words(qp, kp, 0, tb[0], (int)(p.BEG & 0xffffu), rmA);
+        match_words(qp, kp, 1, tb[1], (int)(p.BEG >> 16), rmB);
         /* a row against a target N scores -pn everywhere (mat[4][.], :1915-1940) */
         /* (the match multiplier stays a + pb: against a target N no match bit is set) */
         const int pbA = tb[0] < 4 ? k.pb : k.pn, pbB = tb[1] < 4 ? k.pb : k.pn;
         const uint32_t Bv2 = pack2(pbA, pbB) << 8, D2 = pack2(pbA - k.pn, pbB - k.pn) << 8;
-        const uint32_t END2 = pack2(S.s[0].end, S.s[1].end);
-        /* K4 column 0 (:1795-1796,1835), CPU semantics: only when beg == 0 */
-        const int hi0 = S.s[0].beg == 0 ? imax(S.s[0].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
-        const int hi1 = S.s[1].beg == 0 ? imax(S.s[1].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
-        uint32_t h1 = pack2(hi0, hi1) << 8, f = 0;          /* scaled, like every score inside the row */
+        const uint32_t END2 = p.END;
+        /* K4 column 0 (:1795-1796,1835), CPU semantics: only when beg == 0; h0 - (o_del + e_del (i + 1)), both seeds at once */
+        const uint32_t h1c = pk_subs_vs(p.H0, dup16(imin(k.o_del + k.e_del * (i + 1), 0xffff)));
+        uint32_t h1 = pk_shl8(h1c & ~pk_nzmask(p.BEG)), f = 0;      /* scaled, like every score inside the row */
         L2_STAMP(2);
 #if defined(BSW_L2_PRIO) && defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_s_setprio(0);                      /* (experiment) the block phase yields to a wave in its serial row head / tail */
 #endif
-        uint32_t mkg[NG], nzc[NC];
+        uint32_t mkg[NG];
         sfor<NG>([&](auto gi) { mkg[decltype(gi)::value] = 0; });
-        sfor<NC>([&](auto ci) { nzc[decltype(ci)::value] = 0; });
+        uint32_t Fnz = 0xffffffffu, Lnz = 0;                /* K8: packed first / last non-zero trackers (row_tail2) */
 
         const int blo = u.jlo >> 3, bhi = u.jhi >> 3, bem = u.jem >> 3;      /* block granularity of the dispatch */
         const uint32_t nblk = opaque_s(u.nblk);
@@ -525,9 +643,9 @@ struct lane2 {
                 const uint32_t ENDr = pk_subs_vs(END2, dup16(j0));      /* max(end - j0, 0): column constants stay block-relative */
                 run8(yes_t{}, no_t{}, 0u, ENDr, pk_nzmask(d0));
             }
-            /* fold the block into its 64-column group / 16-column chunk (column offsets only touch the low key bits) */
-            mkg[g] = pk_max(mkg[g], mkb + (uint32_t)(j0 & 63) * 0x00010001u);
-            nzc[c] |= (b & 1) ? (nz8 << 8) : nz8;
+            /* fold the block: its row-max key into its 64-column group (column offsets only touch the low key bits), its
+             * non-zero bits into the first / last trackers (one statement of seven packed ops, none reading its predecessor) */
+            fold8<false>(mkg[g], Fnz, Lnz, mkb, nz8, (uint32_t)(j0 & 63) * 0x00010001u, (uint32_t)(j0 << 8) * 0x00010001u, k.ONE2);
         });
 
         L2_STAMP(3);
@@ -541,55 +659,8 @@ struct lane2 {
             constexpr int g = decltype(gi)::value + 1;
             mk2 = pk_max(mk2, mkg[g] + (uint32_t)(64 * g) * 0x00010001u);
         });
-        /* ---- row tail per seed (K7, K8) ---- */
-        sfor<2>([&](auto xi) {
-            constexpr int x = decltype(xi)::value;
-            /* computed for every seed and committed by selects on `act`: a branch around it would copy the seed state
-             * into fresh registers on one side and back on the other */
-            const bool act = r.act[x];
-            seedv &s = S.s[x];
-            constexpr int sh = 16 * x;
-            const int h1x = (int)((h1 >> (sh + 8)) & 0xffu);
-            const int mk = (int)((mk2 >> sh) & 0xffffu);     /* (m << 8) | mj; m == 0: no positive cell */
-            /* K7, branch-free: a data-dependent if/else here costs an exec-mask region plus register copies of the seed
-             * state on both sides; selects do not. */
-            const bool atq = act & (imax(s.beg, s.end) == s.qlen);   /* ties -> later i (:1829-1833) */
-            s.max_ie = (atq & (h1x >= s.gscore)) ? i : s.max_ie;
-            s.gscore = atq ? imax(s.gscore, h1x) : s.gscore;
-            const int m = mk >> 8, mj = mk & 255;
-            const bool gt = act & (m > s.mx);
-            const int doff = mj - i, off = imax(doff, -doff);
-            const int dd = (i - s.max_i) - (mj - s.max_j), ad = imax(dd, -dd);   /* |di - dj| against the OLD maximum */
-            /* rows ahead of the maximum by more than columns: a deletion's extension penalty, else an insertion's */
-            const int eg = SYM ? k.e_del : (dd > 0 ? k.e_del : k.e_ins);
-            const bool zstop = (!gt) & (k.zdrop > 0) & (s.mx - m - mul24(ad, eg) > k.zdrop);
-            const bool stop = (m == 0) | zstop;              /* (:1942) */
-            s.max_off = gt ? imax(s.max_off, off) : s.max_off;
-            s.max_i = gt ? i : s.max_i;
-            s.max_j = gt ? mj : s.max_j;
-            s.mx = gt ? m : s.mx;
-            /* K8 next-row range (CPU semantics): first / last non-zero eh entry in [beg, end] from the bit masks */
-            /* an empty word gives 0xffffffff from both bit searches: never the unsigned minimum, and negative after
-             * `^ 31 | 32 wd`, never the signed maximum — no compare, no select */
-            uint32_t fnzu = 0xffffffffu;
-            int lnz = -1;
-            sfor<NW>([&](auto wi) {
-                constexpr int wd = decltype(wi)::value;           /* (every word: six straight-line ops beat a skip branch and its register joins) */
-                constexpr int chi = 2 * wd + 1 < NC ? 2 * wd + 1 : 2 * wd;
-                const uint32_t lo = nzc[2 * wd], hic = 2 * wd + 1 < NC ? nzc[chi] : 0u;
-                const uint32_t word = half_pair<x>(lo, hic);
-                const uint32_t cf = ffbl(word) | (uint32_t)(32 * wd);
-                const int cl = (int)((ffbh(word) ^ 31u) | (uint32_t)(32 * wd));
-                fnzu = cf < fnzu ? cf : fnzu;
-                lnz = imax(lnz, cl);
-            });
-            const int fnz = fnzu < (uint32_t)s.end ? (int)fnzu : s.end;
-            const int nbeg = fnz;
-            const int last = lnz >= nbeg ? lnz : nbeg - 1;
-            s.beg = act ? nbeg : s.beg;
-            s.end = act ? imin(last + 2, s.qlen) : s.end;
-            s.alive = act ? !stop : s.alive;
-        });
+        /* ---- row tail (K7, K8), both seeds at once ---- */
+        row_tail2<SYM>(p, k, i, r.ACT, h1, mk2, Fnz, Lnz);
     }
 };
 
@@ -616,19 +687,20 @@ struct lane2l {
     using B = lane2<QB, VM, SYM>;
     static constexpr int QMAX = B::QMAX, NW = B::NW, NC = B::NC, KEEP_NONE = B::KEEP_NONE;
 
-    struct state { seedv s[2]; };
+    struct state { pairv p; };
 
     /* K2 first row, closed form, block by block (sw_pe_array_sw_extend.v:1979,1957,1974) */
     template <class ROW>
     L2_MFN void init_row(const state &S, const consts &k, ROW &row)
     {
+        const int h00 = half_of(S.p.H0, 0), h01 = half_of(S.p.H0, 1);
         for (int b = 0; b < QB; ++b) {
             uint32_t T[8];
             sfor<8>([&](auto ci) {
                 constexpr int c = decltype(ci)::value;
                 const int j = 8 * b + c;
-                const int v0 = j == 0 ? S.s[0].h0 : imax(S.s[0].h0 - k.oe_ins - (j - 1) * k.e_ins, 0);
-                const int v1 = j == 0 ? S.s[1].h0 : imax(S.s[1].h0 - k.oe_ins - (j - 1) * k.e_ins, 0);
+                const int v0 = j == 0 ? h00 : imax(h00 - k.oe_ins - (j - 1) * k.e_ins, 0);
+                const int v1 = j == 0 ? h01 : imax(h01 - k.oe_ins - (j - 1) * k.e_ins, 0);
                 T[c] = pack2(v0, v1);
             });
             row.store8(b, T);
@@ -637,8 +709,10 @@ struct lane2l {
 
     /* the columns a band clamp dropped are zeroed (rare: only rows where the clamp moves some seed's beg) */
     template <class ROW>
-    L2_MFN void zero_dropped(const rowv &r, const uni &u, ROW &row)
+    L2_MFN void zero_dropped(const rowp &r, const uni &u, ROW &row)
     {
+        const bool bt0 = (r.BITE & 0xffffu) != 0, bt1 = (r.BITE >> 16) != 0;
+        const int zlo0 = half_of(r.ZLO, 0), zlo1 = half_of(r.ZLO, 1), zhi0 = half_of(r.ZHI, 0), zhi1 = half_of(r.ZHI, 1);
         const int b0 = u.zl >> 3, b1 = (u.zh - 1) >> 3;
         for (int b = b0; b <= b1 && b < QB; ++b) {
             uint32_t T[8];
@@ -647,8 +721,8 @@ struct lane2l {
                 constexpr int c = decltype(ci)::value;
                 const int J = 8 * b + c;
                 uint32_t keep = 0xffffffffu;
-                if (r.bite[0] && J >= r.zlo[0] && J < r.zhi[0]) keep &= 0xffff0000u;
-                if (r.bite[1] && J >= r.zlo[1] && J < r.zhi[1]) keep &= 0x0000ffffu;
+                if (bt0 && J >= zlo0 && J < zhi0) keep &= 0xffff0000u;
+                if (bt1 && J >= zlo1 && J < zhi1) keep &= 0x0000ffffu;
                 T[c] &= keep;
             });
             row.store8(b, T);
@@ -657,22 +731,22 @@ struct lane2l {
 
     /* One DP row for both seeds (see lane2::row_body for the arithmetic; the cell is the same function). */
     template <class QP, class KP, class WN, class ROW>
-    L2_MFN void row_body(state &S, const consts &k, const int i, const rowv &r, const uni &u, const int (&tb)[2],
+    L2_MFN void row_body(state &S, const consts &k, const int i, const rowp &r, const uni &u, const int (&tb)[2],
                          const QP &qp, const KP &kp, const WN &wn, ROW &row)
     {
+        pairv &p = S.p;
         if (u.anybite) zero_dropped(r, u, row);
         {
             uint32_t rmA[NW], rmB[NW];
-            B::match_words(qp, kp, 0, tb[0], S.s[0].beg, rmA);
-            B::match_words(qp, kp, 1, tb[1], S.s[1].beg, rmB);
+            B::match_words(qp, kp, 0, tb[0], (int)(p.BEG & 0xffffu), rmA);
+            B::match_words(qp, kp, 1, tb[1], (int)(p.BEG >> 16), rmB);
             sfor<NW>([&](auto wi) { constexpr int wd = decltype(wi)::value; row.put_rm(wd, rmA[wd], rmB[wd]); });
         }
         const int pbA = tb[0] < 4 ? k.pb : k.pn, pbB = tb[1] < 4 ? k.pb : k.pn;
         const uint32_t Bv2 = pack2(pbA, pbB) << 8, D2 = pack2(pbA - k.pn, pbB - k.pn) << 8;
-        const uint32_t END2 = pack2(S.s[0].end, S.s[1].end);
-        const int hi0 = S.s[0].beg == 0 ? imax(S.s[0].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
-        const int hi1 = S.s[1].beg == 0 ? imax(S.s[1].h0 - (k.o_del + k.e_del * (i + 1)), 0) : 0;
-        uint32_t h1 = pack2(hi0, hi1) << 8, f = 0;
+        const uint32_t END2 = p.END;
+        const uint32_t h1c = pk_subs_vs(p.H0, dup16(imin(k.o_del + k.e_del * (i + 1), 0xffff)));     /* K4, both seeds at once */
+        uint32_t h1 = pk_shl8(h1c & ~pk_nzmask(p.BEG)), f = 0;
         L2_STAMP(2);
         uint32_t mk2 = 0;                                   /* running row max: (m << 8) | absolute column, per half */
         uint32_t Fnz = 0xffffffffu, Lnz = 0;                /* K8: packed first / last non-zero column trackers */
@@ -750,39 +824,7 @@ struct lane2l {
             for (; b <= bhi; ++b) step(b, edge_t{}, allnq_t{});
         }
         L2_STAMP(3);
-        sfor<2>([&](auto xi) {
-            constexpr int x = decltype(xi)::value;
-            const bool act = r.act[x];
-            seedv &s = S.s[x];
-            constexpr int sh = 16 * x;
-            const int h1x = (int)((h1 >> (sh + 8)) & 0xffu);
-            const int mk = (int)((mk2 >> sh) & 0xffffu);
-            const bool atq = act & (imax(s.beg, s.end) == s.qlen);
-            s.max_ie = (atq & (h1x >= s.gscore)) ? i : s.max_ie;
-            s.gscore = atq ? imax(s.gscore, h1x) : s.gscore;
-            const int m = mk >> 8, mj = mk & 255;
-            const bool gt = act & (m > s.mx);
-            const int doff = mj - i, off = imax(doff, -doff);
-            const int dd = (i - s.max_i) - (mj - s.max_j), ad = imax(dd, -dd);
-            const int eg = SYM ? k.e_del : (dd > 0 ? k.e_del : k.e_ins);
-            const bool zstop = (!gt) & (k.zdrop > 0) & (s.mx - m - mul24(ad, eg) > k.zdrop);
-            const bool stop = (m == 0) | zstop;
-            s.max_off = gt ? imax(s.max_off, off) : s.max_off;
-            s.max_i = gt ? i : s.max_i;
-            s.max_j = gt ? mj : s.max_j;
-            s.mx = gt ? m : s.mx;
-            /* K8 next-row range from the packed trackers */
-            const uint32_t Fx = (Fnz >> sh) & 0xffffu, Lx = (Lnz >> sh) & 0xffffu;
-            const uint32_t fb = (Fx & 0xffu) + 1u;                                  /* the first non-empty block's bits */
-            const uint32_t fnzu = Fx == 0xffffu ? 0xffffffffu : (Fx >> 8) + (uint32_t)popc(~fb & (fb - 1u));
-            const int lnz = Lx == 0 ? -1 : (int)(Lx >> 8) + (31 - clz32(Lx & 0xffu));
-            const int fnz = fnzu < (uint32_t)s.end ? (int)fnzu : s.end;
-            const int nbeg = fnz;
-            const int last = lnz >= nbeg ? lnz : nbeg - 1;
-            s.beg = act ? nbeg : s.beg;
-            s.end = act ? imin(last + 2, s.qlen) : s.end;
-            s.alive = act ? !stop : s.alive;
-        });
+        row_tail2<SYM>(p, k, i, r.ACT, h1, mk2, Fnz, Lnz);        /* K7, K8 for both seeds at once */
     }
 };
 

@@ -49,20 +49,20 @@ __device__ __forceinline__ int wave_max2(int x)
     x = max(x, dpp2<0x143, 0xc>(INT_MIN, x));
     return __builtin_amdgcn_readlane(x, 63);
 }
-/* three wave-wide signed maxima at once, the three DPP chains interleaved by hand: every step reads a register written
- * three instructions earlier, so none of the two wait states a DPP read of a fresh VALU result needs is an s_nop (the
- * compiler's version ran the chains one after the other through one register, 6 dependent steps + 5 s_nop 1 each) */
-__device__ __forceinline__ void wave_max3(int &a, int &b, int &c)
+/* wave-wide unsigned MIN of a, MAX of b, MIN of c, the three DPP chains interleaved by hand: every step reads a register written three
+ * instructions earlier, so none of the two wait states a DPP read of a fresh VALU result needs is an s_nop (the compiler's
+ * version ran the chains one after the other through one register, 6 dependent steps + 5 s_nop 1 each).  Lanes without a
+ * source keep their value: the identity of min and max alike.  (s_nop 1 first: the hazard recogniser does not look inside an
+ * asm statement, and a, b, c are computed just before it.) */
+__device__ __forceinline__ void wave_min_max_min(uint32_t &a, uint32_t &b, uint32_t &c)
 {
-#define BSW_DPP3(ctl) "v_max_i32_dpp %[a], %[a], %[a] " ctl "\n\tv_max_i32_dpp %[b], %[b], %[b] " ctl "\n\tv_max_i32_dpp %[c], %[c], %[c] " ctl "\n\t"
-    /* (s_nop 1 first: a DPP read of a VGPR needs two wait states behind the VALU write of it, and the hazard recogniser does
-     * not look inside an asm statement — a, b, c are computed just before it) */
-    asm volatile("s_nop 1\n\t" BSW_DPP3("row_shr:1 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:2 row_mask:0xf bank_mask:0xf")
-                 BSW_DPP3("row_shr:4 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:8 row_mask:0xf bank_mask:0xf")
-                 BSW_DPP3("row_bcast:15 row_mask:0xa bank_mask:0xf") BSW_DPP3("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
+#define BSW_DPP3U(ctl) "v_min_u32_dpp %[a], %[a], %[a] " ctl "\n\tv_max_u32_dpp %[b], %[b], %[b] " ctl "\n\tv_min_u32_dpp %[c], %[c], %[c] " ctl "\n\t"
+    asm volatile("s_nop 1\n\t" BSW_DPP3U("row_shr:1 row_mask:0xf bank_mask:0xf") BSW_DPP3U("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 BSW_DPP3U("row_shr:4 row_mask:0xf bank_mask:0xf") BSW_DPP3U("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 BSW_DPP3U("row_bcast:15 row_mask:0xa bank_mask:0xf") BSW_DPP3U("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
                  : [a] "+v"(a), [b] "+v"(b), [c] "+v"(c));
-#undef BSW_DPP3
-    a = __builtin_amdgcn_readlane(a, 63); b = __builtin_amdgcn_readlane(b, 63); c = __builtin_amdgcn_readlane(c, 63);
+#undef BSW_DPP3U
+    a = (uint32_t)__builtin_amdgcn_readlane((int)a, 63); b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63); c = (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
 }
 
 /* every 4th bit of a 64-bit word (bit `b` of each nibble) gathered into 16 contiguous bits */
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         }
         if (!valid[x]) tlen = 0;
         ntw[x] = (tlen + 15) >> 4;
-        L::init_seed(S.s[x], qlen, tlen, h0, min(P.w, wlim));
+        l2::init_pair(S.p, x, qlen, tlen, h0, min(P.w, wlim));
         uint32_t mb[4][NW];
 #pragma unroll
         for (int wd = 0; wd < NW; ++wd) {
@@ -206,12 +206,12 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (0 << 11)) & 1u) __builtin_amdgcn_s_sleep(BSW_L2_SKEW);
 #endif
     for (int i = 0;; ++i) {
-        l2::rowv r;
+        l2::rowp r;
 #ifdef BSW_L2_PRIO
         __builtin_amdgcn_s_setprio(BSW_L2_PRIO);
 #endif
-        L::row_begin(S, i, r);
-        if (__builtin_amdgcn_ballot_w64(r.act[0] || r.act[1]) == 0) break;
+        l2::row_begin2(S.p, i, r);
+        if (__builtin_amdgcn_ballot_w64(r.ACT != 0) == 0) break;
         L2_STAMP(0);
         if (__builtin_expect((i & (BSW_L2_TCHUNK * 16 - 1)) == 0, 0)) {   /* stage the next 128 target bases of every seed (one row in 64: out of line) */
             const int wbase = i >> 4;
@@ -239,18 +239,19 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         /* wave-uniform column ranges over the active seeds: blocks outside [jlo, jhi] are skipped, blocks that
          * reach past jem (the smallest `end`) run the masked body */
         l2::uni u;
-        const int b0 = S.s[0].beg, b1 = S.s[1].beg, e0 = S.s[0].end, e1 = S.s[1].end;
         {
-            int ra = max(r.act[0] ? -b0 : INT_MIN, r.act[1] ? -b1 : INT_MIN), rb = max(r.act[0] ? e0 : INT_MIN, r.act[1] ? e1 : INT_MIN),
-                rc = max(r.act[0] ? -e0 : INT_MIN, r.act[1] ? -e1 : INT_MIN);
-            wave_max3(ra, rb, rc);
-            u.jlo = -ra; u.jhi = rb; u.jem = -rc;
+            /* min beg, max end, min end over the ACTIVE seeds: an inactive half reads 0xffff for the minima, 0 for the maximum */
+            const uint32_t nact = ~r.ACT;
+            uint32_t ra = l2::min_halves(S.p.BEG | nact), rb = l2::max_halves(S.p.END & r.ACT), rc = l2::min_halves(S.p.END | nact);
+            wave_min_max_min(ra, rb, rc);
+            u.jlo = (int)ra; u.jhi = (int)rb; u.jem = (int)rc;
         }
-        u.anybite = __builtin_amdgcn_ballot_w64(r.bite[0] || r.bite[1]) != 0;
+        u.anybite = __builtin_amdgcn_ballot_w64(r.BITE != 0) != 0;
         u.zl = 0; u.zh = 0;
         if (__builtin_expect(u.anybite, 0)) {
-            u.zl = -wave_max2(max(r.bite[0] ? -r.zlo[0] : INT_MIN, r.bite[1] ? -r.zlo[1] : INT_MIN));
-            u.zh = wave_max2(max(r.bite[0] ? r.zhi[0] : INT_MIN, r.bite[1] ? r.zhi[1] : INT_MIN));
+            const bool bt0 = (r.BITE & 0xffffu) != 0, bt1 = (r.BITE >> 16) != 0;
+            u.zl = -wave_max2(max(bt0 ? -l2::half_of(r.ZLO, 0) : INT_MIN, bt1 ? -l2::half_of(r.ZLO, 1) : INT_MIN));
+            u.zh = wave_max2(max(bt0 ? l2::half_of(r.ZHI, 0) : INT_MIN, bt1 ? l2::half_of(r.ZHI, 1) : INT_MIN));
         }
         u.nblk = nblk;
         L2_STAMP(1);
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     l2::sfor<2>([&](auto xi) {
         constexpr int x = decltype(xi)::value;
         if (!valid[x]) return;
-        const l2::seedv &s = S.s[x];
+        const l2::ext_out s = l2::pair_result(S.p, x);
         bsw_ext e;
         e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
         e.gscore = s.gscore; e.max_off = s.max_off; e.aw = P.w; e.cells = s.cells;

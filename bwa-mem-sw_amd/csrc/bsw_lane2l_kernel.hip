@@ -50,20 +50,21 @@ __device__ __forceinline__ int wave_max2l(int x)
     x = max(x, dpp2l<0x143, 0xc>(INT_MIN, x));
     return __builtin_amdgcn_readlane(x, 63);
 }
-/* three wave-wide signed maxima at once, the three DPP chains interleaved by hand: every step reads a register written
- * three instructions earlier, so none of the two wait states a DPP read of a fresh VALU result needs is an s_nop (the
- * compiler's version ran the chains one after the other through one register, 6 dependent steps + 5 s_nop 1 each) */
-__device__ __forceinline__ void wave_max3(int &a, int &b, int &c)
+/* wave-wide unsigned MIN of a, MAX of b, MIN of c at once, the three DPP chains interleaved by hand: every step reads a
+ * register written three instructions earlier, so none of the two wait states a DPP read of a fresh VALU result needs is an
+ * s_nop (the compiler's version ran the chains one after the other through one register, 6 dependent steps + 5 s_nop 1
+ * each).  Lanes without a source keep their value: the identity of min and max alike. */
+__device__ __forceinline__ void wave_min_max_min(uint32_t &a, uint32_t &b, uint32_t &c)
 {
-#define BSW_DPP3(ctl) "v_max_i32_dpp %[a], %[a], %[a] " ctl "\n\tv_max_i32_dpp %[b], %[b], %[b] " ctl "\n\tv_max_i32_dpp %[c], %[c], %[c] " ctl "\n\t"
+#define BSW_DPP3U(ctl) "v_min_u32_dpp %[a], %[a], %[a] " ctl "\n\tv_max_u32_dpp %[b], %[b], %[b] " ctl "\n\tv_min_u32_dpp %[c], %[c], %[c] " ctl "\n\t"
     /* (s_nop 1 first: a DPP read of a VGPR needs two wait states behind the VALU write of it, and the hazard recogniser does
      * not look inside an asm statement — a, b, c are computed just before it) */
-    asm volatile("s_nop 1\n\t" BSW_DPP3("row_shr:1 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:2 row_mask:0xf bank_mask:0xf")
-                 BSW_DPP3("row_shr:4 row_mask:0xf bank_mask:0xf") BSW_DPP3("row_shr:8 row_mask:0xf bank_mask:0xf")
-                 BSW_DPP3("row_bcast:15 row_mask:0xa bank_mask:0xf") BSW_DPP3("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
+    asm volatile("s_nop 1\n\t" BSW_DPP3U("row_shr:1 row_mask:0xf bank_mask:0xf") BSW_DPP3U("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 BSW_DPP3U("row_shr:4 row_mask:0xf bank_mask:0xf") BSW_DPP3U("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 BSW_DPP3U("row_bcast:15 row_mask:0xa bank_mask:0xf") BSW_DPP3U("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
                  : [a] "+v"(a), [b] "+v"(b), [c] "+v"(c));
-#undef BSW_DPP3
-    a = __builtin_amdgcn_readlane(a, 63); b = __builtin_amdgcn_readlane(b, 63); c = __builtin_amdgcn_readlane(c, 63);
+#undef BSW_DPP3U
+    a = (uint32_t)__builtin_amdgcn_readlane((int)a, 63); b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63); c = (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
 }
 
 /* every 4th bit of a 64-bit word (bit `b` of each nibble) gathered into 16 contiguous bits */
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
         }
         if (!valid[x]) tlen = 0;
         ntw[x] = (tlen + 15) >> 4;
-        LB::init_seed(S.s[x], qlen, tlen, h0, min(P.w, wlim));
+        l2::init_pair(S.p, x, qlen, tlen, h0, min(P.w, wlim));
         uint32_t mb[4][NW];
         /* all query words are requested before the first is waited for (at one wave per SIMD nothing else hides a round
          * trip to HBM per word); the index is clamped, words past the query are zeroed afterwards */
@@ -304,24 +305,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
     uint64_t tw[2] = {0ull, 0ull};
 
     for (int i = 0;; ++i) {
-        l2::rowv r;
-        {
-            typename LB::state tmp;                               /* row_begin works on the seed scalars only */
-            (void)tmp;
-        }
-        l2::sfor<2>([&](auto xi) {                                /* K3 band clamp: lane2::row_begin on the seed scalars */
-            constexpr int x = decltype(xi)::value;
-            l2::seedv &s = S.s[x];
-            r.act[x] = s.alive && i < s.tlen;
-            const int nb = l2::imax(s.beg, i - s.w), ne = l2::imin(l2::imin(s.end, i + s.w + 1), s.qlen);
-            r.bite[x] = r.act[x] && nb > s.beg;
-            r.zlo[x] = s.beg; r.zhi[x] = nb;
-            s.beg = r.act[x] ? nb : s.beg;
-            s.end = r.act[x] ? ne : s.end;
-            r.len[x] = l2::imax(s.end - s.beg, 0);
-            s.cells += r.act[x] ? (unsigned)r.len[x] : 0u;
-        });
-        if (__builtin_amdgcn_ballot_w64(r.act[0] || r.act[1]) == 0) break;
+        l2::rowp r;
+        l2::row_begin2(S.p, i, r);                                /* K3 band clamp, both seeds at once */
+        if (__builtin_amdgcn_ballot_w64(r.ACT != 0) == 0) break;
         if ((i & (BSW_L2_TCHUNK * 16 - 1)) == 0) {                    /* stage the next 128 target bases of every seed */
             const int wbase = i >> 4;
             uint64_t tv[2][BSW_L2_TCHUNK];
@@ -344,18 +330,19 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
         const int tb[2] = {(int)((tw[0] >> ((i & 15) * 4)) & 7), (int)((tw[1] >> ((i & 15) * 4)) & 7)};
 
         l2::uni u;
-        const int b0 = S.s[0].beg, b1 = S.s[1].beg, e0 = S.s[0].end, e1 = S.s[1].end;
         {
-            int ra = max(r.act[0] ? -b0 : INT_MIN, r.act[1] ? -b1 : INT_MIN), rb = max(r.act[0] ? e0 : INT_MIN, r.act[1] ? e1 : INT_MIN),
-                rc = max(r.act[0] ? -e0 : INT_MIN, r.act[1] ? -e1 : INT_MIN);
-            wave_max3(ra, rb, rc);
-            u.jlo = -ra; u.jhi = rb; u.jem = -rc;
+            /* min beg, max end, min end over the ACTIVE seeds: an inactive half reads 0xffff for the minima, 0 for the maximum */
+            const uint32_t nact = ~r.ACT;
+            uint32_t ra = l2::min_halves(S.p.BEG | nact), rb = l2::max_halves(S.p.END & r.ACT), rc = l2::min_halves(S.p.END | nact);
+            wave_min_max_min(ra, rb, rc);
+            u.jlo = (int)ra; u.jhi = (int)rb; u.jem = (int)rc;
         }
-        u.anybite = __builtin_amdgcn_ballot_w64(r.bite[0] || r.bite[1]) != 0;
+        u.anybite = __builtin_amdgcn_ballot_w64(r.BITE != 0) != 0;
         u.zl = 0; u.zh = 0;
         if (u.anybite) {
-            u.zl = -wave_max2l(max(r.bite[0] ? -r.zlo[0] : INT_MIN, r.bite[1] ? -r.zlo[1] : INT_MIN));
-            u.zh = wave_max2l(max(r.bite[0] ? r.zhi[0] : INT_MIN, r.bite[1] ? r.zhi[1] : INT_MIN));
+            const bool bt0 = (r.BITE & 0xffffu) != 0, bt1 = (r.BITE >> 16) != 0;
+            u.zl = -wave_max2l(max(bt0 ? -l2::half_of(r.ZLO, 0) : INT_MIN, bt1 ? -l2::half_of(r.ZLO, 1) : INT_MIN));
+            u.zh = wave_max2l(max(bt0 ? l2::half_of(r.ZHI, 0) : INT_MIN, bt1 ? l2::half_of(r.ZHI, 1) : INT_MIN));
         }
         u.nblk = nblk;
         L::row_body(S, k, i, r, u, tb, qp, kp, wn, row);
@@ -364,7 +351,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
     l2::sfor<2>([&](auto xi) {
         constexpr int x = decltype(xi)::value;
         if (!valid[x]) return;
-        const l2::seedv &s = S.s[x];
+        const l2::ext_out s = l2::pair_result(S.p, x);
         bsw_ext e;
         e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
         e.gscore = s.gscore; e.max_off = s.max_off; e.aw = P.w; e.cells = s.cells;

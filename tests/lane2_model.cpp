@@ -83,8 +83,8 @@ struct wave_model {
                     wl = mi < md ? mi : md;
                 }
                 if (!a.valid[x]) tlen = 0;
-                L::init_seed(a.S.s[x], qlen, tlen, h0s ? h0s[a.ti[x]] : T.h0, p->w < wl ? p->w : wl);
-                a.SL.s[x] = a.S.s[x];
+                init_pair(a.S.p, x, qlen, tlen, h0s ? h0s[a.ti[x]] : T.h0, p->w < wl ? p->w : wl);
+                a.SL.p = a.S.p;
                 for (int j = 0; j < qlen; ++j) {
                     const int c = q[j] > 4 ? 4 : q[j];
                     if (c & 1) a.qp[x][0][j >> 5] |= 1u << (j & 31);
@@ -99,24 +99,24 @@ struct wave_model {
             if constexpr (LOOP) { memset(&a.row, 0xa5, sizeof(a.row)); LL::init_row(a.SL, k, a.row); }
             else L::init_row(a.S, k);
         }
-        std::vector<rowv> rv(64);
+        std::vector<rowp> rv(64);
         for (int i = 0;; ++i) {
             bool any = false;
             u.jlo = 1 << 20; u.jhi = -1; u.jem = 1 << 20; u.anybite = false; u.zl = 1 << 20; u.zh = -1;
             for (int l = 0; l < 64; ++l) {
-                if constexpr (LOOP) { typename LU::state tmp; tmp.s[0] = ln[l].SL.s[0]; tmp.s[1] = ln[l].SL.s[1]; L::row_begin(tmp, i, rv[l]); ln[l].SL.s[0] = tmp.s[0]; ln[l].SL.s[1] = tmp.s[1]; }
-                else L::row_begin(ln[l].S, i, rv[l]);
+                pairv &pv = LOOP ? ln[l].SL.p : ln[l].S.p;
+                row_begin2(pv, i, rv[l]);
                 for (int x = 0; x < 2; ++x) {
-                    if (!rv[l].act[x]) continue;
+                    if (!half_of(rv[l].ACT, x)) continue;
                     any = true;
-                    const seedv &s = LOOP ? ln[l].SL.s[x] : ln[l].S.s[x];
-                    if (s.beg < u.jlo) u.jlo = s.beg;
-                    if (s.end > u.jhi) u.jhi = s.end;
-                    if (s.end < u.jem) u.jem = s.end;
-                    if (rv[l].bite[x]) {
+                    const int beg = half_of(pv.BEG, x), end = half_of(pv.END, x);
+                    if (beg < u.jlo) u.jlo = beg;
+                    if (end > u.jhi) u.jhi = end;
+                    if (end < u.jem) u.jem = end;
+                    if (half_of(rv[l].BITE, x)) {
                         u.anybite = true;
-                        if (rv[l].zlo[x] < u.zl) u.zl = rv[l].zlo[x];
-                        if (rv[l].zhi[x] > u.zh) u.zh = rv[l].zhi[x];
+                        if (half_of(rv[l].ZLO, x) < u.zl) u.zl = half_of(rv[l].ZLO, x);
+                        if (half_of(rv[l].ZHI, x) > u.zh) u.zh = half_of(rv[l].ZHI, x);
                     }
                 }
             }
@@ -125,7 +125,7 @@ struct wave_model {
                 lane_t &a = ln[l];
                 int tb[2];
                 for (int x = 0; x < 2; ++x) {
-                    int b = rv[l].act[x] ? a.t[x][i] : 0;
+                    int b = half_of(rv[l].ACT, x) ? a.t[x][i] : 0;
                     tb[x] = b > 4 ? 4 : b;
                 }
                 auto qp = [&](int x, int b, uint32_t (&rm)[L::NW]) {
@@ -142,7 +142,7 @@ struct wave_model {
         for (int l = 0; l < 64; ++l)
             for (int x = 0; x < 2; ++x) {
                 if (!ln[l].valid[x]) continue;
-                const seedv &s = LOOP ? ln[l].SL.s[x] : ln[l].S.s[x];
+                const ext_out s = pair_result(LOOP ? ln[l].SL.p : ln[l].S.p, x);
                 bsw_ext &e = out[ln[l].ti[x]];
                 e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
                 e.gscore = s.gscore; e.max_off = s.max_off; e.aw = p->w; e.cells = s.cells;
