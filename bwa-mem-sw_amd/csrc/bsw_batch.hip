@@ -402,6 +402,20 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
             if (J.launches) ++*J.launches;
         }
     }
+    /* Does every lane launch of a part run a kernel that finishes its seeds itself (bsw_fin: the launch that computes a seed's
+     * last side takes the pair-level decision)?  Then bsw_pair_finalize is not launched for it: one launch and a 96-byte
+     * read-modify-write per seed less per step.  One class on round 1's kernel (16-bit rows, odd N scores) keeps the launch. */
+    constexpr int MAXJ = 4;
+    bsw_fin fins[MAXJ];
+    for (int j = 0; j < nj && j < MAXJ; ++j) {
+        const lane_job &J = jobs[j];
+        const batch_plan &pl = *J.pl;
+        bool all = nj <= MAXJ;
+        for (int c = 0; c < nlc && all; ++c)
+            if ((pl.laneL_off[c + 1] - pl.laneL_off[c] || pl.laneR_off[c + 1] - pl.laneR_off[c]) && !bsw::lane_class_finishes(c, *J.P, J.variant)) all = false;
+        fins[j].redo = J.d_order + pl.redo_off; fins[j].redo_cnt = J.d_order + pl.order_len; fins[j].pairs = J.d_pair; fins[j].on = all ? 1 : 0;
+    }
+    auto fin_of = [&](int j) -> const bsw_fin * { return j < MAXJ ? &fins[j] : nullptr; };
     struct link { int job, side, cls; uint32_t off, cnt; };
     constexpr int MAXL = 2 * BSW_MAX_LANE_CLASSES;
     link chain[MAXL];
@@ -447,7 +461,7 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
              * that runs the waiter before the launch raising its word does; results must not change, bsw_chain_timeouts counts */
             static const bool selftest = getenv("BSW_CHAIN_SELFTEST") != nullptr;
             if (i > 0) HIPCHK(e, bsw::launch_wait_count(fk->flag(i - 1), selftest ? 0xffffffffu : target, fk->expired(), ks));
-            HIPCHK(e, bsw::launch_lane(k.cls, J.variant, *J.P, k.side, J.d_seq, J.d_tasks, J.d_order + k.off, k.cnt, J.d_out, ks, i + 1 < nchain ? fk->flag(i) : nullptr, &target));
+            HIPCHK(e, bsw::launch_lane(k.cls, J.variant, *J.P, k.side, J.d_seq, J.d_tasks, J.d_order + k.off, k.cnt, J.d_out, ks, i + 1 < nchain ? fk->flag(i) : nullptr, &target, fin_of(k.job)));
             HIPCHK(e, hipEventRecord(fk->ev_link[i], ks));
             if (J.launches) ++*J.launches;
         }
@@ -485,7 +499,7 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
         for (int c = nlc - 1; c >= 0; --c) {
             const uint32_t cnt = pl.laneL_off[c + 1] - pl.laneL_off[c];
             if (!cnt) continue;
-            HIPCHK(e, bsw::launch_lane(c, variant, P, 0, d_seq, d_tasks, d_order + pl.laneL_off[c], cnt, d_out, lstream[c]));
+            HIPCHK(e, bsw::launch_lane(c, variant, P, 0, d_seq, d_tasks, d_order + pl.laneL_off[c], cnt, d_out, lstream[c], nullptr, nullptr, fin_of(j)));
             if (forked) HIPCHK(e, hipEventRecord(fk1->ev_left[c], lstream[c]));
             if (launches) ++*launches;
         }
@@ -495,7 +509,7 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
             if (forked)
                 for (int lc = 0; lc < nlc; ++lc)
                     if (lstream[lc] && lstream[lc] != rstream[c] && ((pl.dep[lc] >> c) & 1)) HIPCHK(e, hipStreamWaitEvent(rstream[c], fk1->ev_left[lc], 0));
-            HIPCHK(e, bsw::launch_lane(c, variant, P, 1, d_seq, d_tasks, d_order + pl.laneR_off[c], cnt, d_out, rstream[c]));
+            HIPCHK(e, bsw::launch_lane(c, variant, P, 1, d_seq, d_tasks, d_order + pl.laneR_off[c], cnt, d_out, rstream[c], nullptr, nullptr, fin_of(j)));
             if (forked && rstream[c] != s) HIPCHK(e, hipEventRecord(fk1->ev_right[c], rstream[c]));
             if (launches) ++*launches;
         }
@@ -506,13 +520,15 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
             }
         }
         }
-        HIPCHK(e, bsw::launch_finalize(P, d_tasks, d_order + pl.lane_all_off, pl.lane_all_cnt, d_out,
-                                       d_order + pl.redo_off, redo_cnt, d_pair, s));
+        const bool folded = fin_of(j) && fin_of(j)->on;
+        if (!folded)
+            HIPCHK(e, bsw::launch_finalize(P, d_tasks, d_order + pl.lane_all_off, pl.lane_all_cnt, d_out,
+                                           d_order + pl.redo_off, redo_cnt, d_pair, s));
         /* seeds whose first band try was not final: recompute from scratch, one wavefront each */
         HIPCHK(e, bsw::launch_wave(pl.redo_cls, variant, P, d_seq, d_tasks, d_order + pl.redo_off, pl.lane_all_cnt,
                                    redo_cnt, redo_cnt + 1 + BSW_MAX_WAVE_CLASSES, d_out, s));
         if (d_pair) HIPCHK(e, bsw::launch_pairs_from_results(d_order + pl.redo_off, pl.lane_all_cnt, redo_cnt, d_out, d_pair, s));
-        if (launches) *launches += 2;
+        if (launches) *launches += folded ? 1 : 2;
     }
     return BSW_OK;
 }

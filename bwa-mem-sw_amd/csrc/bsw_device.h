@@ -100,6 +100,7 @@ BSW_HD int bsw_seed_lane_bits(const bsw_binparams *bp, int lqlen, int rqlen, int
 {
     if (!bp->lane_on) return 0;
     const int qm = lqlen > rqlen ? lqlen : rqlen;
+    if (qm == 0) return 0;                     /* no side at all: nothing a lane launch would finish (the general kernel writes the neutral record) */
     const int64_t top = (int64_t)h0 + (int64_t)(lqlen + rqlen) * bp->a;   /* no H can exceed this */
     if (top + bp->b <= 255 && qm + 1 <= bp->cols8) return 8;
     if (top < 65000 && qm + 1 <= bp->cols16) return 16;
@@ -118,5 +119,64 @@ BSW_HD int bsw_wave_class_of(const bsw_binparams *bp, int qmax)
         if (qmax + 1 <= bp->wave_cols[c]) return c;
     return -1;
 }
+
+/* ---- the pair-level decision (P1 exit test, P2 clip-vs-extend, P3: sw_pe_array_proc_element.v:1593-1685) for a seed whose
+ * sides came from the lane kernels.  ONE function for its two callers: bsw_pair_finalize (a launch of its own) and the
+ * epilogue of the two-seeds-per-lane kernels (round 5: the launch that computes a seed's LAST side finishes the seed itself —
+ * one launch and a 96-byte read-modify-write per seed less).  L / R: the sides' K9 records (ignored for a side that does not
+ * exist).  A seed whose first band try was not final goes to the redo list instead of getting a record. ---- */
+typedef struct bsw_fin {
+    uint32_t *redo, *redo_cnt;                 /* the chunk's redo list and its length (device words) */
+    bsw_pair *pairs;                           /* BSW_RESULT_PAIR: the dense 32-byte records; else NULL */
+    int on;                                    /* 0: the lane kernels only store their side (bsw_pair_finalize follows) */
+} bsw_fin;
+
+#if defined(__HIPCC__) || defined(__HIP__)
+__device__ __forceinline__ void bsw_pair_decide(const bsw_dparams &P, const bsw_dtask &T, const uint32_t ti, bsw_ext L, bsw_ext R,
+                                                bsw_result *__restrict__ out, uint32_t *__restrict__ redo, uint32_t *__restrict__ redo_cnt,
+                                                bsw_pair *__restrict__ pairs)
+{
+    const int thr = (P.w >> 1) + (P.w >> 2);
+    bool retry = false;
+    int score = T.init_score, truesc, qb, rb, qe, re;
+    bsw_ext Z;
+    Z.score = 0; Z.qle = Z.tle = Z.gtle = 0; Z.gscore = 0; Z.max_off = 0; Z.aw = P.w; Z.cells = 0;
+    if (T.lqlen > 0) {
+        if (P.max_band_try > 1 && !(L.score == score || L.max_off < thr)) retry = true;
+        score = L.score;
+        if (L.gscore <= 0 || L.gscore <= score - P.pen_clip5) { qb = T.qbeg - L.qle; rb = -L.tle; truesc = score; }
+        else { qb = 0; rb = -L.gtle; truesc = L.gscore; }
+    } else {
+        score = truesc = T.h0; qb = 0; rb = 0;
+        L = Z;
+    }
+    const int sc0 = score;
+    if (T.rqlen > 0) {
+        if (P.max_band_try > 1 && !(R.score == sc0 || R.max_off < thr)) retry = true;
+        score = R.score;
+        if (R.gscore <= 0 || R.gscore <= score - P.pen_clip3) { qe = R.qle; re = R.tle; truesc += score - sc0; }
+        else { qe = T.rqlen; re = R.gtle; truesc += R.gscore - sc0; }
+    } else {
+        qe = 0; re = 0;
+        R = Z;
+    }
+    if (retry) {
+        redo[atomicAdd(redo_cnt, 1u)] = ti;
+        return;
+    }
+    if (pairs) {
+        /* BSW_RESULT_PAIR: the RTL's 5-word record alone (sw_pe_array_proc_element.v:1662-1665), 32 bytes into the dense
+         * array that crosses PCIe; the per-side records stay where the lane kernels left them */
+        bsw_pair pr;
+        pr.tag = T.tag; pr.qb = qb; pr.qe = qe; pr.rb = rb; pr.re = re; pr.score = score; pr.truesc = truesc; pr.w = P.w;
+        pairs[ti] = pr;
+    } else {
+        bsw_result r;
+        r.tag = T.tag; r.qb = qb; r.qe = qe; r.rb = rb; r.re = re; r.score = score; r.truesc = truesc; r.w = P.w;
+        r.left = L; r.right = R;
+        out[ti] = r;
+    }
+}
+#endif
 
 #endif

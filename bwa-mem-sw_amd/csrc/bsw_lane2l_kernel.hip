@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
                                                               const uint64_t *__restrict__ seq,
                                                               const bsw_dtask *__restrict__ tasks,
                                                               const uint32_t *__restrict__ order, const uint32_t n,
-                                                              bsw_result *__restrict__ out, uint32_t *tail_flag)
+                                                              bsw_result *__restrict__ out, uint32_t *tail_flag, const bsw_fin fin)
 {
     /* *tail_flag counts the workgroups that have a slot.  When it reaches gridDim.x every slot that frees up stays free, and
      * whoever waits for that (the next launch of the chunk's chain) may have them.  A count, not "the last
@@ -360,6 +360,18 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
         e.cells = ((unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) | ((unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);
         e.gscore = (int)__builtin_popcount(nblk);                           /* blocks with a query N in this wave */
 #endif
+        if (fin.on) {
+            /* the launch that computes a seed's LAST side finishes the seed: clip-vs-extend decision, band-retry test, the
+             * whole record (or the redo list) — what bsw_pair_finalize did in a launch of its own (bsw_device.h) */
+            const bsw_dtask T = tasks[ti[x]];
+            if (side == 1 || T.rqlen == 0) {
+                bsw_ext Lx = e;
+                if (side == 1 && T.lqlen > 0) Lx = out[ti[x]].left;
+                if (fin.pairs) { if (side == 0) out[ti[x]].left = e; else out[ti[x]].right = e; }      /* (pair format: the side records stay in scratch) */
+                bsw_pair_decide(P, T, ti[x], Lx, e, out, fin.redo, fin.redo_cnt, fin.pairs);
+                return;
+            }
+        }
         if (side == 0) out[ti[x]].left = e; else out[ti[x]].right = e;
     });
 }
@@ -367,18 +379,20 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
 /* the 232-column class (250 bp reads) at one wave per SIMD; BSW_LANE2L_NARROW=1 also routes the 136-column class here
  * (experiments: the unrolled kernel is faster there) */
 hipError_t launch_lane2l(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
-                         const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target)
+                         const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target, const bsw_fin *finp)
 {
+    bsw_fin fin;
+    if (finp) fin = *finp; else { fin.redo = fin.redo_cnt = nullptr; fin.pairs = nullptr; fin.on = 0; }
     if (n == 0) return tail_flag ? hipMemsetD32Async((hipDeviceptr_t)tail_flag, 1, 1, s) : hipSuccess;
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins, vm = variant == BSW_VARIANT_M;
     const dim3 grid((n + 511u) / 512u), block(256);
     if (tail_flag && tail_target) *tail_target = grid.x;              /* the flag's value once every workgroup has started */
 #define BSW_L2L_GO(QB, WPS)                                                                                                     \
     do {                                                                                                                        \
-        if (!vm && sym) hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag);   \
-        else if (!vm) hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, false, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag);    \
-        else if (sym) hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag);      \
-        else hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag);              \
+        if (!vm && sym) hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);   \
+        else if (!vm) hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, false, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);    \
+        else if (sym) hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);      \
+        else hipLaunchKernelGGL((bsw_lane2l_kernel<QB, WPS, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);              \
     } while (0)
     if (qb == 17) BSW_L2L_GO(17, 1);
     else BSW_L2L_GO(29, 1);

@@ -339,44 +339,8 @@ __global__ __launch_bounds__(256) void bsw_pair_finalize(const bsw_dparams P, co
     if (slot >= n) return;
     const uint32_t ti = order[slot];
     const bsw_dtask T = tasks[ti];
-    bsw_result r = out[ti];
-    const int thr = (P.w >> 1) + (P.w >> 2);
-    bool retry = false;
-    int score = T.init_score, truesc, qb, rb, qe, re;
-    if (T.lqlen > 0) {
-        if (P.max_band_try > 1 && !(r.left.score == score || r.left.max_off < thr)) retry = true;
-        score = r.left.score;
-        if (r.left.gscore <= 0 || r.left.gscore <= score - P.pen_clip5) { qb = T.qbeg - r.left.qle; rb = -r.left.tle; truesc = score; }
-        else { qb = 0; rb = -r.left.gtle; truesc = r.left.gscore; }
-    } else {
-        score = truesc = T.h0; qb = 0; rb = 0;
-        r.left.score = 0; r.left.qle = r.left.tle = r.left.gtle = 0; r.left.gscore = 0; r.left.max_off = 0;
-        r.left.aw = P.w; r.left.cells = 0;
-    }
-    const int sc0 = score;
-    if (T.rqlen > 0) {
-        if (P.max_band_try > 1 && !(r.right.score == sc0 || r.right.max_off < thr)) retry = true;
-        score = r.right.score;
-        if (r.right.gscore <= 0 || r.right.gscore <= score - P.pen_clip3) { qe = r.right.qle; re = r.right.tle; truesc += score - sc0; }
-        else { qe = T.rqlen; re = r.right.gtle; truesc += r.right.gscore - sc0; }
-    } else {
-        qe = 0; re = 0;
-        r.right.score = 0; r.right.qle = r.right.tle = r.right.gtle = 0; r.right.gscore = 0; r.right.max_off = 0;
-        r.right.aw = P.w; r.right.cells = 0;
-    }
-    if (retry) {
-        redo[atomicAdd(redo_cnt, 1u)] = ti;
-        return;
-    }
-    r.tag = T.tag; r.qb = qb; r.qe = qe; r.rb = rb; r.re = re; r.score = score; r.truesc = truesc; r.w = P.w;
-    if (pairs) {
-        /* BSW_RESULT_PAIR: the RTL's 5-word record alone (sw_pe_array_proc_element.v:1662-1665), 32 bytes into the dense
-         * array that crosses PCIe; the per-side records stay where the lane kernels left them */
-        bsw_pair pr;
-        pr.tag = r.tag; pr.qb = r.qb; pr.qe = r.qe; pr.rb = r.rb; pr.re = r.re; pr.score = r.score; pr.truesc = r.truesc; pr.w = r.w;
-        pairs[ti] = pr;
-    } else
-        out[ti] = r;
+    const bsw_result r = out[ti];
+    bsw_pair_decide(P, T, ti, r.left, r.right, out, redo, redo_cnt, pairs);
 }
 
 /* BSW_RESULT_PAIR: the seeds the general kernels computed (their lists in `order`; n_dev != NULL: the redo list, counted on
@@ -463,28 +427,17 @@ bool lane_class_signals_tail(int cls) { int n; return cls >= 0 && lane_classes(&
  * row in AccVGPRs (232 columns, one wave per SIMD) */
 bool lane2_params_ok(const bsw_dparams &P, int variant);
 hipError_t launch_lane2(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
-                        uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target);
+                        uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target, const bsw_fin *fin);
 hipError_t launch_lane2l(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
-                         const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target);
+                         const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target, const bsw_fin *fin);
 
 static hipError_t launch_lane_k(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
-                                const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *&tail_flag, uint32_t *tail_target);
+                                const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *&tail_flag, uint32_t *tail_target, const bsw_fin *fin);
 
-hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
-                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target)
+/* which kernel serves the class under these parameters: 2 = bsw_lane2_kernel, 3 = bsw_lane2l_kernel, 1 = round 1's
+ * one-seed-per-lane kernel (16-bit rows, N scores outside the packed range, gap penalties >= 256) */
+static int lane_kernel_of(int cls, const bsw_dparams &P, int variant)
 {
-    if (tail_target) *tail_target = 1u;
-    hipError_t e = launch_lane_k(cls, variant, P, side, seq, tasks, order, n, out, s, tail_flag, tail_target);
-    /* nobody took the flag (an empty launch, a kernel that does not signal): it is raised behind the launch instead, so
-     * that whoever waits for it never waits forever */
-    if (e == hipSuccess && tail_flag) e = hipMemsetD32Async((hipDeviceptr_t)tail_flag, 1, 1, s);
-    return e;
-}
-
-static hipError_t launch_lane_k(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
-                                const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *&tail_flag, uint32_t *tail_target)
-{
-    if (n == 0) return hipSuccess;
     int ncls;
     const lane_class_t &C = lane_classes(&ncls)[cls];
     if (C.kind != K_LANE16 && lane2_params_ok(P, variant)) {
@@ -492,10 +445,41 @@ static hipError_t launch_lane_k(int cls, int variant, const bsw_dparams &P, int 
          * 136-column class through the looped kernel too (measurements; the unrolled kernel instantiated for 232 columns is
          * instruction-cache bound at one wave per SIMD: profiles/r3/lane2_wide_*) */
         static const bool nol = getenv("BSW_NO_LANE2L") != nullptr, narrow = getenv("BSW_LANE2L_NARROW") != nullptr;
-        if (C.kind == K_LANE2L_29) {
-            if (!nol) { uint32_t *tf = tail_flag; tail_flag = nullptr; return launch_lane2l(29, P, variant, side, seq, tasks, order, n, out, s, tf, tail_target); }
-        } else if (C.kind == K_LANE2_17 && narrow) return launch_lane2l(17, P, variant, side, seq, tasks, order, n, out, s, nullptr, nullptr);
-        else { uint32_t *tf = tail_flag; tail_flag = nullptr; return launch_lane2(C.qb, P, variant, side, seq, tasks, order, n, out, s, tf, tail_target); }
+        if (C.kind == K_LANE2L_29) return nol ? 1 : 3;
+        return (C.kind == K_LANE2_17 && narrow) ? 3 : 2;
+    }
+    return 1;
+}
+/* the class's kernel finishes a seed in the epilogue of its last side (bsw_fin): the two-seeds-per-lane kernels do */
+bool lane_class_finishes(int cls, const bsw_dparams &P, int variant)
+{
+    static const bool off = getenv("BSW_NO_FOLD") != nullptr;         /* (measurements: bsw_pair_finalize as a launch of its own) */
+    return !off && lane_kernel_of(cls, P, variant) != 1;
+}
+
+hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
+                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target, const bsw_fin *fin)
+{
+    if (tail_target) *tail_target = 1u;
+    hipError_t e = launch_lane_k(cls, variant, P, side, seq, tasks, order, n, out, s, tail_flag, tail_target, fin);
+    /* nobody took the flag (an empty launch, a kernel that does not signal): it is raised behind the launch instead, so
+     * that whoever waits for it never waits forever */
+    if (e == hipSuccess && tail_flag) e = hipMemsetD32Async((hipDeviceptr_t)tail_flag, 1, 1, s);
+    return e;
+}
+
+static hipError_t launch_lane_k(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
+                                const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *&tail_flag, uint32_t *tail_target, const bsw_fin *fin)
+{
+    if (n == 0) return hipSuccess;
+    int ncls;
+    const lane_class_t &C = lane_classes(&ncls)[cls];
+    const int kern = lane_kernel_of(cls, P, variant);
+    if (kern != 1) {
+        uint32_t *tf = tail_flag;
+        tail_flag = nullptr;                                           /* (these kernels raise the flag themselves) */
+        if (kern == 3) return launch_lane2l(C.kind == K_LANE2L_29 ? 29 : 17, P, variant, side, seq, tasks, order, n, out, s, tf, tail_target, fin);
+        return launch_lane2(C.qb, P, variant, side, seq, tasks, order, n, out, s, tf, tail_target, fin);
     }
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins;
     switch (C.fb) {

@@ -29,8 +29,12 @@ int lane_class_bits(int cls);
 bool lane_class_signals_tail(int cls);    /* its launch raises launch_lane's tail_flag when the last workgroup starts */
 /* tail_flag != NULL: *tail_flag (a device word, zero before the launch) reaches *tail_target when every workgroup of the
  * launch has started — or, from a kernel that cannot say so, when the launch is done */
+/* fin != NULL && fin->on: the launch that computes a seed's last side also takes the pair-level decision and writes the
+ * whole record / the redo list (every class of the chunk must say lane_class_finishes) */
 hipError_t launch_lane(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
-                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag = nullptr, uint32_t *tail_target = nullptr);
+                       const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag = nullptr, uint32_t *tail_target = nullptr,
+                       const bsw_fin *fin = nullptr);
+bool lane_class_finishes(int cls, const bsw_dparams &P, int variant);
 /* pairs != NULL (BSW_RESULT_PAIR): the pair-level record goes to pairs[task], 32 bytes, instead of back into out[task] */
 hipError_t launch_wait_count(const uint32_t *flag, uint32_t target, uint32_t *expired, hipStream_t s);    /* one sleeping wave until *flag >= target or 20 ms */
 hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const uint32_t *order, uint32_t n,

@@ -20,7 +20,8 @@ int lane_class_bits(int c) { return kLb[c]; }
 hipError_t launch_wave(int, int, const bsw_dparams &, const uint64_t *, const bsw_dtask *, const uint32_t *, uint32_t, const uint32_t *, uint32_t *, bsw_result *, hipStream_t) { return hipSuccess; }
 bool lane_class_signals_tail(int) { return false; }
 hipError_t launch_wait_count(const uint32_t *, uint32_t, uint32_t *, hipStream_t) { return hipSuccess; }
-hipError_t launch_lane(int, int, const bsw_dparams &, int, const uint64_t *, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, hipStream_t, uint32_t *, uint32_t *) { return hipSuccess; }
+hipError_t launch_lane(int, int, const bsw_dparams &, int, const uint64_t *, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, hipStream_t, uint32_t *, uint32_t *, const bsw_fin *) { return hipSuccess; }
+bool lane_class_finishes(int, const bsw_dparams &, int) { return true; }
 hipError_t launch_finalize(const bsw_dparams &, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, uint32_t *, uint32_t *, bsw_pair *, hipStream_t) { return hipSuccess; }
 hipError_t launch_pairs_from_results(const uint32_t *, uint32_t, const uint32_t *, const bsw_result *, bsw_pair *, hipStream_t) { return hipSuccess; }
 hipError_t launch_pack(const uint8_t *, const bsw_dtask *, const bsw_rawoff *, uint32_t, uint32_t, int, const uint8_t *, int64_t, const bsw_refx *, uint64_t *, hipStream_t) { return hipSuccess; }

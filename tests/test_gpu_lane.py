@@ -225,7 +225,7 @@ for variant, gaps in ((0, {}), (1, dict(o_del=5, e_del=2, o_ins=7, e_ins=1))):
         b = c.upload(p, tasks); c.run(b); c.sync()
         got, launches = c.download(b), b.info()["launches"]
         b.free()
-    assert launches == 6, launches              # left + right x (72-column class, 136-column class) + finalize + redo list
+    assert launches == 5, launches              # left + right x (72-column class, 136-column class) + the redo list
     assert_same(got, orc.pair_batch(p, tasks, nthreads=8), tasks)
 print("ok")
 """
@@ -259,7 +259,7 @@ for variant, gaps in ((0, {}), (1, dict(o_del=5, e_del=2, o_ins=7, e_ins=1))):
             b = c.upload(p, tasks); c.run(b); c.run(b); c.sync()
             got, launches = c.download(b), b.info()["launches"]
             b.free()
-            assert launches == %(launches)d, launches           # left + right x the lane classes in use + finalize + redo list
+            assert launches == %(launches)d, launches           # left + right x the lane classes in use + the redo list (the last side finishes its seeds: no finalize launch)
             assert_same(got, want, tasks)
         got = c.extend_pairs(p, tasks)              # the synchronous chunk path shares stream 0 and its chain
         assert_same(got, want, tasks)
@@ -282,7 +282,7 @@ def test_lane_launches_as_a_chain_on_250_bp_reads(mode):
         env["BSW_FORK"] = mode
     if mode == "chain3":
         env["BSW_NARROW_SHARE"] = "0"
-    out = subprocess.run([sys.executable, "-c", CHAIN_SNIPPET % dict(root=root, launches=8 if mode == "chain3" else 6)], env=env,
+    out = subprocess.run([sys.executable, "-c", CHAIN_SNIPPET % dict(root=root, launches=7 if mode == "chain3" else 5)], env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-4000:]
 
@@ -303,7 +303,7 @@ with host.BswContext(device=0, kernel=host.KERNEL_LANE, timeout_ms=60000) as c:
         b = c.upload(p, tasks); c.run(b); c.sync()
         got, launches = c.download(b), b.info()["launches"]
         b.free()
-        assert launches == 6, launches               # the chain is ON: four lane launches + finalize + redo list
+        assert launches == 5, launches               # the chain is ON: four lane launches + the redo list
         assert_same(got, want, tasks)
     got = c.extend_pairs(p, tasks)
     assert_same(got, want, tasks)
