@@ -89,3 +89,65 @@ def test_three_wave_kernel_spills_only_outside_its_row_loop():
         assert vg and int(vg.group(1)) <= 168, vg and vg.group(1)
         seen += 1
     assert seen == 4                                           # variant H / M x shared / separate gap penalties
+
+
+def _quad_listing():
+    src = os.path.join(ROOT, "bwa-mem-sw_amd", "csrc", "bsw_quad_kernel.hip")
+    return subprocess.check_output(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function",
+                                    "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", src, "-o", "-"], stderr=subprocess.DEVNULL, text=True)
+
+
+def test_quad_kernel_dpp_reads_keep_their_wait_states_and_its_spills_stay_out_of_the_rows():
+    """bsw_quad_kernel's hand-written DPP sequences (row_scan_max, shr1_max, bcast15_max, row_max4, the packed min / max
+    reduction) sit in asm statements the hazard recogniser does not look into: a DPP read of a VGPR needs TWO wait states
+    behind the VALU instruction that wrote it, and only the statements' own s_nops / instruction order provide them.  A
+    compiler or flag change that puts a VALU write of the source directly in front of one of them would break the kernel
+    silently (round 4's advisor).  Audit: for every v_*_dpp of every instantiation, no VALU instruction among the two wait
+    states in front of it writes its DPP source.  And the spills the launch bounds cost (3 / 4 waves per SIMD) must sit in the
+    rare try / side bookkeeping loop, never on the path every DP row takes."""
+    out = _quad_listing()
+    kernels = list(re.finditer(r"^(_ZN3bsw15bsw_quad_kernelILi(\d+)ELi(\d+)E\w+):.*?s_endpgm", out, re.S | re.M))
+    assert len(kernels) == 8                                    # 2 / 4 / 6 / 8 stripes x variant H / M
+    for m in kernels:
+        body = [l for l in m.group(0).split("\n")]
+        ins = []                                                # (line index, mnemonic, operands)
+        for i, l in enumerate(body):
+            t = l.strip()
+            if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+                continue
+            mm = re.match(r"([a-z_0-9]+)\s*(.*)", t)
+            if mm:
+                ins.append((i, mm.group(1), mm.group(2)))
+        ndpp = 0
+        for k, (i, op, args) in enumerate(ins):
+            if not (op.startswith("v_") and ("_dpp" in op or "row_" in args or "quad_perm" in args)):
+                continue
+            ndpp += 1
+            regs = [a.strip() for a in args.split(",")]
+            src = regs[1].split()[0]                            # vDST, vSRC0 (the operand the DPP control applies to), ...
+            if not src.startswith("v"):
+                continue
+            wait, j = 0, k - 1
+            while j >= 0 and wait < 2:
+                _, pop, pargs = ins[j]
+                if pop == "s_nop":
+                    wait += int(pargs.split()[0]) + 1
+                else:
+                    pdst = pargs.split(",")[0].strip()
+                    assert not (pop.startswith("v_") and pdst == src), (m.group(1)[:40], body[i].strip(), "written by", pop, pargs)
+                    wait += 1
+                j -= 1
+        assert ndpp > 50, (m.group(1), ndpp)
+        # spills: none in a basic block of the row path — the blocks that hold a stripe's F scan (row_shr:8), the row head's
+        # target fetch (ds_bpermute) or the row tail's four reductions (row_ror:8); the bookkeeping's blocks may have them
+        blocks, cur = [], []
+        for l in body:
+            if re.match(r"^\.LBB\d+_\d+:", l) or l.startswith("; %bb."):
+                blocks.append(cur); cur = []
+            cur.append(l)
+        blocks.append(cur)
+        row_blocks = [b for b in blocks if any(("row_shr:8" in x or "ds_bpermute" in x or "row_ror:8" in x) and not x.lstrip().startswith(";") for x in b)]
+        assert len(row_blocks) >= 3, (m.group(1), len(row_blocks))
+        for b in row_blocks:
+            bad = [x.strip() for x in b if "scratch_" in x]
+            assert not bad, (m.group(1)[:40], bad[:4])
