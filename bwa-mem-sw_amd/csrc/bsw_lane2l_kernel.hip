@@ -303,11 +303,58 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
     };
     const auto wn = [&](int c) { return lds_wn[wv][c][lane]; };
     uint64_t tw[2] = {0ull, 0ull};
+#ifndef BSW_L2L_NO_PREFETCH
+    /* ONE ROW AHEAD (round 5).  At one wave per SIMD nothing hides an LDS round trip, and every row started with one: target
+     * base -> the query's per-base match words.  Neither depends on the row before it, so row i + 1's target bases are taken
+     * and its match words requested while row i is still in front of its cell blocks; row i + 1 finds them in registers
+     * (16 + 16 of the 256 architectural VGPRs this kernel has to itself).  Only the keep-table entry, which needs the
+     * row's own beg, is still read inside the row. */
+    uint32_t rmN[2][NW];
+    int tbN[2] = {0, 0};
+    const auto fetch_row = [&](const int in) {
+        if ((in & (BSW_L2_TCHUNK * 16 - 1)) == 0) {                   /* stage the next 128 target bases of every seed */
+            const int wbase = in >> 4;
+            uint64_t tv[2][BSW_L2_TCHUNK];
+            l2::sfor<2>([&](auto xi) {
+                constexpr int x = decltype(xi)::value;
+                const int last = max(ntw[x] - 1, 0);
+#pragma unroll
+                for (int q = 0; q < BSW_L2_TCHUNK; ++q) tv[x][q] = seq[t_off[x] + (uint32_t)min(wbase + q, last)];
+            });
+            l2::sfor<2>([&](auto xi) {
+                constexpr int x = decltype(xi)::value;
+#pragma unroll
+                for (int q = 0; q < BSW_L2_TCHUNK; ++q) lds_t[wv][x][q][lane] = tv[x][q];
+            });
+        }
+        if ((in & 15) == 0) {
+            tw[0] = lds_t[wv][0][(in >> 4) & (BSW_L2_TCHUNK - 1)][lane];
+            tw[1] = lds_t[wv][1][(in >> 4) & (BSW_L2_TCHUNK - 1)][lane];
+        }
+        tbN[0] = (int)((tw[0] >> ((in & 15) * 4)) & 7); tbN[1] = (int)((tw[1] >> ((in & 15) * 4)) & 7);
+        qp(0, tbN[0] & 3, rmN[0]);
+        qp(1, tbN[1] & 3, rmN[1]);
+    };
+    fetch_row(0);
+#endif
 
     for (int i = 0;; ++i) {
         l2::rowp r;
         l2::row_begin2(S.p, i, r);                                /* K3 band clamp, both seeds at once */
         if (__builtin_amdgcn_ballot_w64(r.ACT != 0) == 0) break;
+#ifndef BSW_L2L_NO_PREFETCH
+        const int tb[2] = {tbN[0], tbN[1]};
+        uint32_t rmC[2][NW];
+#pragma unroll
+        for (int wd = 0; wd < NW; ++wd) { rmC[0][wd] = rmN[0][wd]; rmC[1][wd] = rmN[1][wd]; }
+        fetch_row(i + 1);
+        const auto qpc = [&](int x, int, uint32_t (&rm)[NW]) {
+#pragma unroll
+            for (int wd = 0; wd < NW; ++wd) rm[wd] = rmC[x][wd];
+        };
+        /* (the keep-table entries requested here too, in front of the wave reductions instead of behind them: 2 170 GCUPS
+         * either way on 250 bp reads, gpurun_out/s8 — not kept) */
+#else
         if ((i & (BSW_L2_TCHUNK * 16 - 1)) == 0) {                    /* stage the next 128 target bases of every seed */
             const int wbase = i >> 4;
             uint64_t tv[2][BSW_L2_TCHUNK];
@@ -328,6 +375,8 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
             tw[1] = lds_t[wv][1][(i >> 4) & (BSW_L2_TCHUNK - 1)][lane];
         }
         const int tb[2] = {(int)((tw[0] >> ((i & 15) * 4)) & 7), (int)((tw[1] >> ((i & 15) * 4)) & 7)};
+        const auto &qpc = qp;
+#endif
 
         l2::uni u;
         {
@@ -345,7 +394,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
             u.zh = wave_max2l(max(bt0 ? l2::half_of(r.ZHI, 0) : INT_MIN, bt1 ? l2::half_of(r.ZHI, 1) : INT_MIN));
         }
         u.nblk = nblk;
-        L::row_body(S, k, i, r, u, tb, qp, kp, wn, row);
+        L::row_body(S, k, i, r, u, tb, qpc, kp, wn, row);
     }
 
     l2::sfor<2>([&](auto xi) {
