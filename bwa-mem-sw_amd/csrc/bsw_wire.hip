@@ -28,11 +28,15 @@ extern "C" int bsw_refbatch_submit(bsw_ctx *ctx, const uint32_t *in_words, uint3
  * 16 batches = ~13 k seeds stay below the lane kernels' minimum batch on purpose: a lane launch costs one wave's full
  * duration (1.6 ms per side) however few seeds it holds, the wave-per-seed kernel finishes such a group sooner. */
 #define REFBATCH_GROUP 16
+#define REFBATCH_GROUP_DEEP 64
 #define REFBATCH_SLOTS 4
 static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int zdrop, stage_t &st, hipStream_t s, size_t *n_out)
 {
     errs &e = ctx->err;
     *n_out = 0;
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = dbg ? tnow() : 0;
     const uint32_t *W0 = ctx->ref_queue[q0].in;
     bsw_params p;
     bsw_default_params(&p);                       /* matrix a=1,b=4,N=-1 is hard-wired (sw_extend.v:1915-1940) */
@@ -51,9 +55,14 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
         return BSW_OK;
     }
     const size_t nb = q1 - q0, wire_words = nb * (size_t)BSW_REFBATCH_IN_WORDS;
+    /* Task batches that sit in memory from bsw_host_alloc / bsw_host_register are DMA'd where they are — the reference's
+     * batch manager reads the host's pinned workspace itself (batch_manager.v:745-773) — instead of being copied into the
+     * slot's pinned staging first (16 MB of memcpy per 64 batches: 0.6 ms of a group's 0.8 ms on the host) */
+    bool direct = true;
+    for (size_t q = q0; q < q1 && direct; ++q) direct = is_registered(ctx->ref_queue[q].in, BSW_REFBATCH_IN_WORDS * sizeof(uint32_t));
     hipError_t he;
     if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_woff.reserve(n + 1)) != hipSuccess ||
-        (he = st.h_out.reserve(n + 1)) != hipSuccess || (he = st.h_raw.reserve(wire_words * 4 + RAW_SLACK)) != hipSuccess)
+        (he = st.h_out.reserve(n + 1)) != hipSuccess || (!direct && (he = st.h_raw.reserve(wire_words * 4 + RAW_SLACK)) != hipSuccess))
         return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
     /* headers -> task records (host: 8 words per task) */
     chunk_info ci;
@@ -63,25 +72,44 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
     uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0};
     uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0;
     uint64_t acc = 0;
-    /* pass 1 (cheap): where every batch's tasks and sequence words start */
+    /* pass 1: where every batch's tasks and sequence words start (the batches' word counts side by side, then a prefix sum) */
     std::vector<uint64_t> wbase(nb + 1, 0), tbase(nb + 1, 0);
-    for (size_t q = q0; q < q1; ++q) {
-        const uint32_t *W = ctx->ref_queue[q].in;
-        const uint32_t nt = W[2];
-        uint64_t words = 0;
-        for (uint32_t i = 0; i < nt; ++i) {
-            const uint32_t *H = &W[8 + 8 * i];
-            const int lq = (int)(H[0] & 0xff), lt = (int)((H[0] >> 16) & 0x7ff), rq = (int)(H[1] & 0xff), rt = (int)((H[1] >> 16) & 0x7ff);
-            words += (lq ? nwords(lq) + nwords(lt) : 0) + (rq ? nwords(rq) + nwords(rt) : 0);
-        }
-        wbase[q - q0 + 1] = wbase[q - q0] + words;
-        tbase[q - q0 + 1] = tbase[q - q0] + nt;
+    /* ONE thread walks a group of up to 128 batches faster than several do (64 batches = 52 k headers: 0.36 ms on one thread,
+     * 0.95 / 0.50 / 0.40 ms on 2 / 4 / 8 freshly started ones, profiles/r5/wire_format_group_sweep.txt) — and then needs no
+     * first pass at all: the offsets run along */
+    const size_t nth = nb <= 128 ? 1 : std::max<size_t>(1, std::min<size_t>((size_t)ctx->cfg.pack_threads, nb / 32));
+    if (nth > 1) {
+        auto count = [&](size_t t) {
+            for (size_t q = q0 + t; q < q1; q += nth) {
+                const uint32_t *W = ctx->ref_queue[q].in;
+                const uint32_t nt = W[2];
+                uint64_t words = 0;
+                for (uint32_t i = 0; i < nt && 8 + 8 * (uint64_t)i + 1 < BSW_REFBATCH_IN_WORDS; ++i) {
+                    const uint32_t *H = &W[8 + 8 * i];
+                    const int lq = (int)(H[0] & 0xff), lt = (int)((H[0] >> 16) & 0x7ff), rq = (int)(H[1] & 0xff), rt = (int)((H[1] >> 16) & 0x7ff);
+                    words += (lq ? nwords(lq) + nwords(lt) : 0) + (rq ? nwords(rq) + nwords(rt) : 0);
+                }
+                wbase[q - q0 + 1] = words;
+                tbase[q - q0 + 1] = nt;
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nth; ++t) th.emplace_back(count, t);
+        count(0);
+        for (auto &x : th) x.join();
+        for (size_t k = 1; k <= nb; ++k) { wbase[k] += wbase[k - 1]; tbase[k] += tbase[k - 1]; }
     }
-    acc = wbase[nb];
+    const double t_b = dbg ? tnow() : 0;
     /* pass 2 (parallel over batches): records, class counts, and the batch itself into pinned staging */
     struct part { uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0; int rc = 0; errs e; };
-    const size_t nth = std::max<size_t>(1, std::min<size_t>((size_t)ctx->cfg.pack_threads, nb / 4));
     std::vector<part> parts(nth);
+    /* class of a side / a seed by query length, looked up instead of searched per task (wire lengths are 8-bit fields) */
+    uint8_t wcls[256], lcls8[256], lcls16[256];
+    for (int q = 0; q < 256; ++q) {
+        wcls[q] = (uint8_t)bsw_wave_class_of(&bp, q);
+        lcls8[q] = (uint8_t)bsw_side_lane_class(&bp, 8, q);
+        lcls16[q] = (uint8_t)bsw_side_lane_class(&bp, 16, q);
+    }
     auto parse = [&](size_t t) {
         part &pt = parts[t];
         for (size_t q = q0 + t; q < q1; q += nth) {
@@ -89,11 +117,12 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
             const uint32_t nt = W[2];
             uint64_t a2 = wbase[q - q0];
             size_t ti = (size_t)tbase[q - q0];
+            if (nth == 1) tbase[q - q0 + 1] = tbase[q - q0] + nt;
             const int64_t base = nt ? (int64_t)(8 + 8 * nt) - (int64_t)W[8 + 2] : 0;
             for (uint32_t i = 0; i < nt; ++i, ++ti) {
                 const uint32_t *H = &W[8 + 8 * i];
-                bsw_dtask &d = st.h_tasks.p[ti];
-                bsw_wireoff &wo = st.h_woff.p[ti];
+                bsw_dtask d;                          /* built here, stored to the pinned staging in one go below */
+                bsw_wireoff wo;
                 memset(&d, 0, sizeof(d));
                 const int lq = (int)(H[0] & 0xff), lt = (int)((H[0] >> 16) & 0x7ff), rq = (int)(H[1] & 0xff), rt = (int)((H[1] >> 16) & 0x7ff);
                 const int64_t pos = base + (int64_t)H[2];
@@ -118,13 +147,16 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
                 };
                 d.wlim_l = lim(H[5]); d.wlim_r = lim(H[6]);
                 d.h0 = h0; d.init_score = (int)(int16_t)(H[3] & 0xffff); d.qbeg = (int)(H[3] >> 16); d.tag = H[7];
-                const int wc = bsw_wave_class_of(&bp, std::max(lq, rq));
+                const int wc = wcls[std::max(lq, rq)];
                 ++pt.cw_all[wc];
                 const int bits = bsw_seed_lane_bits(&bp, lq, rq, h0);
                 if (!bits) ++pt.cw[wc];
-                else { ++pt.n_lane; if (lq) ++pt.cl[bsw_side_lane_class(&bp, bits, lq)]; if (rq) ++pt.cr[bsw_side_lane_class(&bp, bits, rq)]; }
+                else { const uint8_t *lc = bits == 8 ? lcls8 : lcls16; ++pt.n_lane; if (lq) ++pt.cl[lc[lq]]; if (rq) ++pt.cr[lc[rq]]; }
+                st.h_tasks.p[ti] = d;
+                st.h_woff.p[ti] = wo;
             }
-            memcpy((uint32_t *)st.h_raw.p + (q - q0) * (size_t)BSW_REFBATCH_IN_WORDS, W, BSW_REFBATCH_IN_WORDS * sizeof(uint32_t));
+            if (nth == 1) wbase[q - q0 + 1] = a2;
+            if (!direct) memcpy((uint32_t *)st.h_raw.p + (q - q0) * (size_t)BSW_REFBATCH_IN_WORDS, W, BSW_REFBATCH_IN_WORDS * sizeof(uint32_t));
         }
     };
     {
@@ -133,6 +165,8 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
         parse(0);
         for (auto &x : th) x.join();
     }
+    const double t_c = dbg ? tnow() : 0;
+    acc = wbase[nb];
     for (const part &pt : parts) {
         if (pt.rc) { e = pt.e; return pt.rc; }
         for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) { cw_all[c] += pt.cw_all[c]; cw[c] += pt.cw[c]; }
@@ -164,7 +198,15 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
         (he = st.d_order.reserve(order_capacity(n))) != hipSuccess || (he = st.d_bins.reserve(BSW_BIN_WORDS)) != hipSuccess ||
         (he = st.d_out.reserve(n + 1)) != hipSuccess)
         return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
-    HIPCHK(e, hipMemcpyAsync(st.d_raw.p, st.h_raw.p, wire_words * 4, hipMemcpyHostToDevice, s));
+    if (!direct) HIPCHK(e, hipMemcpyAsync(st.d_raw.p, st.h_raw.p, wire_words * 4, hipMemcpyHostToDevice, s));
+    else
+        for (size_t q = q0; q < q1;) {                 /* one DMA per run of batches that lie back to back in the caller's memory */
+            size_t r1 = q + 1;
+            while (r1 < q1 && ctx->ref_queue[r1].in == ctx->ref_queue[r1 - 1].in + BSW_REFBATCH_IN_WORDS) ++r1;
+            HIPCHK(e, hipMemcpyAsync(st.d_raw.p + (q - q0) * (size_t)BSW_REFBATCH_IN_WORDS * 4, ctx->ref_queue[q].in,
+                                     (r1 - q) * (size_t)BSW_REFBATCH_IN_WORDS * 4, hipMemcpyHostToDevice, s));
+            q = r1;
+        }
     HIPCHK(e, hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(st.d_woff.p, st.h_woff.p, n * sizeof(bsw_wireoff), hipMemcpyHostToDevice, s));
     HIPCHK(e, bsw::launch_wire_pack((const uint32_t *)st.d_raw.p, st.d_tasks.p, st.d_woff.p, (uint32_t)n, st.d_seq.p, s));
@@ -174,6 +216,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
     /* the result DMA is issued by refbatch_collect once the kernels are done: a copy queued now would sit in its DMA
      * engine's ring until then and hold up the next group's input copies queued behind it */
     *n_out = n;
+    if (dbg) fprintf(stderr, "[bsw] wire:   enqueue: reserve + pass 1 %.3f ms, pass 2 (%zu threads) %.3f, plan + device enqueue %.3f\n", t_b - t_a, nth, t_c - t_b, tnow() - t_c);
     return BSW_OK;
 }
 
@@ -181,16 +224,19 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
 static int refbatch_collect(bsw_ctx *ctx, size_t q0, size_t q1, size_t n, stage_t &st, hipStream_t s, hipEvent_t ev)
 {
     errs &e = ctx->err;
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
     {
+        const auto tk0 = std::chrono::steady_clock::now();
         const int rc0 = sync_stream(ctx, e, s, ev);
         if (rc0) return rc0;
+        if (dbg) fprintf(stderr, "[bsw] wire:   waited %.3f ms for the kernels\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk0).count());
         HIPCHK(e, hipMemcpyAsync(st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
     }
-    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
     const auto tc0 = std::chrono::steady_clock::now();
     int rc = sync_stream(ctx, e, s, ev);
     if (rc) return rc;
-    if (dbg) fprintf(stderr, "[bsw] wire:   waited %.3f ms for the GPU\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+    const auto tc1 = std::chrono::steady_clock::now();
+    if (dbg) fprintf(stderr, "[bsw] wire:   waited %.3f ms for the result DMA\n", std::chrono::duration<double, std::milli>(tc1 - tc0).count());
     const size_t nb = q1 - q0;
     std::vector<size_t> tbase(nb + 1, 0);
     for (size_t q = q0; q < q1; ++q) tbase[q - q0 + 1] = tbase[q - q0] + ctx->ref_queue[q].in[2];
@@ -210,6 +256,7 @@ static int refbatch_collect(bsw_ctx *ctx, size_t q0, size_t q1, size_t n, stage_
     for (auto &x : th) x.join();
     for (int r : trc)
         if (r < 0) return fail(e, r, "result batch encode");
+    if (dbg) fprintf(stderr, "[bsw] wire:   encoded %zu result batches on %zu threads in %.3f ms\n", nb, nth, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
     return BSW_OK;
 }
 
@@ -227,8 +274,13 @@ extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
      * while the others are on the GPU (the reference's manager keeps its four TBB/RBB pairs busy the same way,
      * batch_manager.v:418,745-773). */
     dev_state &dev = ctx->devs[0];
-    static const size_t grp_tune = getenv("BSW_REFBATCH_GROUP") ? (size_t)std::max(1, atoi(getenv("BSW_REFBATCH_GROUP"))) : (size_t)REFBATCH_GROUP;   /* (measurements) */
-    const size_t grp_env = grp_tune;
+    /* Group size.  A deep queue (>= 96 batches = 79 k seeds) is cut into groups of 64 batches: 52 k PE seeds are past the point
+     * where the two-seeds-per-lane kernels beat the general one (48 k mixed seeds, profiles/r5/crossover_mixed_bins.json), and
+     * two such groups in flight overlap each other's launch floors (128 queued batches: 4.5 ms against 6.6 in groups of 16,
+     * profiles/r5/wire_format_group_sweep.txt).  A shallow queue keeps groups of 16 on the general kernel, which finishes 13 k
+     * seeds sooner than two lane launches of one wave's lifetime each.  BSW_REFBATCH_GROUP overrides (measurements). */
+    static const size_t grp_tune = getenv("BSW_REFBATCH_GROUP") ? (size_t)std::max(1, atoi(getenv("BSW_REFBATCH_GROUP"))) : 0;
+    const size_t grp_env = grp_tune ? grp_tune : (nq >= 96 ? (size_t)REFBATCH_GROUP_DEEP : (size_t)REFBATCH_GROUP);
     const size_t NS = std::max<size_t>(1, std::min<size_t>(REFBATCH_SLOTS, dev.slots.size()));
     const size_t slot_of[REFBATCH_SLOTS] = {0, 1, 2, 3};
     struct flight { bool active = false; size_t q0 = 0, q1 = 0, n = 0; } fl[REFBATCH_SLOTS];

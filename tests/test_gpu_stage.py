@@ -435,3 +435,68 @@ def test_bsw_bench_cli(host, oracle, devflag):
                              sub_rate=0.01, indel_rate=0.001, junk_frac=0.05, n_rate=0.0, a=1, w=100, o=6, e=1)
     wg = oracle.pair_batch(host.default_params(o_del=6, o_ins=4, e_del=1, e_ins=2, variant=1), tg, nthreads=8)
     assert jg["cells"] == int(wg["left"]["cells"].astype(np.int64).sum() + wg["right"]["cells"].astype(np.int64).sum())
+
+
+def test_deep_wire_queue_runs_in_groups_of_64(host, oracle):
+    """A queue of >= 96 task batches is cut into groups of 64 (52 k seeds: the two-seeds-per-lane kernels, two groups in
+    flight) instead of 16 (the general kernel): the same result batches either way, batch by batch, against the oracle —
+    including a last group that takes the queue's remainder (100 batches: 64 + 36) and a header change inside the queue."""
+    pa, pb = host.default_params(zdrop=0), host.default_params(zdrop=0, o_del=5, o_ins=5, w=60)
+    tasks, arena = host.synth_tasks(100 * 819, seed=77, **MIXED)
+    ins, outs, meta, lo, k = [], [], [], 0, 0
+    while lo < len(tasks) and len(ins) < 100:
+        p = pb if k >= 97 else pa
+        words, n = host.refbatch_encode(p, tasks[lo:lo + 819])
+        ins.append(words); outs.append(np.full(host.REFBATCH_OUT_WORDS, 0xdeadbeef, np.uint32)); meta.append((lo, n, p))
+        lo += n; k += 1
+    wa, wb = oracle.pair_batch_avx2(pa, tasks[:lo], nthreads=8), oracle.pair_batch(pb, tasks[:lo], nthreads=8)
+    with host.BswContext(device=0) as c:
+        for a, b in zip(ins, outs):
+            c.refbatch_submit(a, b)
+        assert c.refbatch_wait(0, 0) == len(ins)
+    for (l0, n, p), o in zip(meta, outs):
+        want = (wb if p is pb else wa)[l0:l0 + n]
+        got = host.refbatch_decode_results(o, n)
+        for f in FIELDS:
+            assert (got[f] == want[f]).all(), (l0, f)
+        assert (o[5 * n:] == 0).all()
+
+
+def test_registered_task_batches_are_dmad_where_they_are(host, oracle):
+    """Task batches in memory from bsw_host_alloc skip the copy into pinned staging: one DMA per run of batches that lie back
+    to back (here: 20 contiguous ones, then 10 with gaps between them), mixed with a pageable batch in the same group (the whole
+    group then takes the staging path).  Same result batches as the oracle either way."""
+    p = host.default_params(zdrop=0)
+    tasks, arena = host.synth_tasks(31 * 819, seed=88, **MIXED)
+    W = host.REFBATCH_IN_WORDS
+    ar = host.HostArena(45 * W * 4)
+    view = ar.view(np.uint32, 45 * W).reshape(45, W)
+    slots = list(range(20)) + list(range(21, 41, 2))                    # 20 back to back, 10 every other slot
+    ins, outs, meta, lo = [], [], [], 0
+    for sl in slots:
+        words, n = host.refbatch_encode(p, tasks[lo:lo + 819])
+        view[sl] = words
+        ins.append(view[sl]); outs.append(np.zeros(host.REFBATCH_OUT_WORDS, np.uint32)); meta.append((lo, n)); lo += n
+    want = oracle.pair_batch(p, tasks[:lo], nthreads=8)
+    with host.BswContext(device=0) as c:
+        for rep in range(2):
+            extra = []
+            if rep == 1:                                                 # a pageable batch joins the last group
+                words, n = host.refbatch_encode(p, tasks[lo:lo + 819])
+                extra = [(words, np.zeros(host.REFBATCH_OUT_WORDS, np.uint32), (lo, n))]
+            for o in outs:
+                o[:] = 0xdeadbeef
+            for a, b in zip(ins, outs):
+                c.refbatch_submit(a, b)
+            for a, b, _ in extra:
+                c.refbatch_submit(a, b)
+            assert c.refbatch_wait(0, 0) == len(ins) + len(extra)
+            for (l0, n), o in zip(meta, outs):
+                got = host.refbatch_decode_results(o, n)
+                for f in FIELDS:
+                    assert (got[f] == want[l0:l0 + n][f]).all(), (rep, l0, f)
+            for a, b, (l0, n) in extra:
+                got = host.refbatch_decode_results(b, n)
+                w2 = oracle.pair_batch(p, tasks[l0:l0 + n], nthreads=8)
+                assert (got["score"] == w2["score"]).all() and (got["truesc"] == w2["truesc"]).all()
+    ar.free()
