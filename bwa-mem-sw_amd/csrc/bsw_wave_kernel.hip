@@ -337,6 +337,10 @@ hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_
      * up to 256 columns through it whatever the size (tests, measurements), BSW_QUAD=0 none. */
     static const int quad_mode = getenv("BSW_QUAD") ? atoi(getenv("BSW_QUAD")) : -1;
     const int cols = kWaveClasses[cls] * 64;
+    /* (round 5 measured a third general kernel — one wavefront per seed whose lanes FOLLOW the live band, the eh[] row in LDS:
+     * tools/experiments/bsw_band_kernel.hip, bit-exact, 95 VALU lane-instructions per cell against 129 here — at 6.49 ms per
+     * 131 072 seeds of 131 x 257 against 7.00 here and 4.57 for the four-seed kernel, slower on PE mixed seeds and on a lone
+     * scalar call: profiles/r5/general_kernels_band_experiment.txt.  Not built into the library.) */
     const bool quad = next_slot && cols <= 256 && (quad_mode == 1 || (quad_mode < 0 && cols >= 192 && !n_dev && n >= 8192u));
     if (quad) return launch_quad(cols, variant, P, seq, tasks, order, n, n_dev, next_slot, out, s);
     switch (kWaveClasses[cls]) {
