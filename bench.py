@@ -375,6 +375,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 250 bp and mixed-bin side measurements (N=1 only, outside the timed region)")
     ap.add_argument("--pe-seeds", type=int, default=10_000_000, help="seeds of the 150 bp PE mixed-bin measurement beside the headline (BASELINE configs[2]: 10 M; 0 = skip)")
+    ap.add_argument("--e2e-slots", type=int, default=4, help="slot threads (= streams) of the single-submit PCIe-inclusive legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bsw_submit (PCIe-inclusive) measurement")
     ap.add_argument("--e2e-reps", type=int, default=5, help="bsw_submit passes timed (median reported)")
     ap.add_argument("--ref-mbp", type=int, default=64, help="synthetic genome size (Mbp) of the device-resident-reference e2e leg; 0 = skip")
@@ -605,7 +606,7 @@ def main():
     # ---- the same seeds through bsw_submit: host buffers in (registered arena), host buffers out ----
     e2e_dt = None
     if not args.no_e2e:
-        sctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=4, pack_threads=4, chunk_tasks=chunk)
+        sctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=chunk)
         sctx.extend_pairs(params, tasks, out=out_buf)            # warm up: staging allocations, code load
         e2e_runs = []
         for _ in range(args.e2e_reps):
@@ -633,7 +634,7 @@ def main():
         ptasks, _w = host.pack_tasks(tasks, parena.view(np.uint64, need // 8 + 1))
         # 96 Ki chunks: with half the bytes per seed the input DMAs are short and smaller chunks start the GPU sooner
         # (sweep: profiles/r3/e2e_packed_sweep.txt)
-        pctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=4, pack_threads=4, chunk_tasks=98304)
+        pctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=98304)
         pctx.extend_pairs_packed(params, ptasks, out=out_buf)
         runs = []
         for _ in range(args.e2e_reps):
@@ -652,7 +653,7 @@ def main():
         # the same submit handing back the RTL's 5-word record alone (BSW_RESULT_PAIR: 32 of the 96 result bytes per seed)
         pout = host.HostArena(max(n_local, 1) * host.PAIR.itemsize)
         pair_buf = pout.view(host.PAIR, max(n_local, 1))[:n_local]
-        qctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=4, pack_threads=4, chunk_tasks=98304, result_format=host.RESULT_PAIR)
+        qctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=98304, result_format=host.RESULT_PAIR)
         qctx.extend_pairs_packed(params, ptasks, out=pair_buf)
         qruns = []
         for _ in range(args.e2e_reps):
@@ -673,7 +674,7 @@ def main():
         lp = args.ref_mbp * 1_000_000
         hreads = host.HostArena(spec["read_len"] * n_local + 4096)
         pac, rtasks, _ = host.synth_ref_tasks(n_local, lp, params, arena=hreads.u8, seed=3000 + rank, **spec)
-        rctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=4, pack_threads=4, chunk_tasks=chunk)
+        rctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=chunk)
         gref = rctx.ref_upload(pac, lp)
         rctx.submit_ref(params, gref, rtasks, out=out_buf); rctx.wait()         # warm up
         runs = []

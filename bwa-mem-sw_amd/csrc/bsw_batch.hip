@@ -1218,7 +1218,8 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
          * device the input DMAs are short and that wait is what the pipeline loses (+7 % when the slot thread issues the
          * result DMA itself once the kernels are done); with 448 B per seed of input the link is busy anyway and the
          * extra host round trip per chunk costs more than it saves (-6 %), so there the copy is queued right away. */
-        const bool late = rtasks != nullptr;
+        static const int late_env = getenv("BSW_LATE_RESULT") ? atoi(getenv("BSW_LATE_RESULT")) : -1;     /* (measurements) */
+        const bool late = late_env >= 0 ? late_env != 0 : rtasks != nullptr;
         if (!late) he = hipMemcpyAsync(pend.direct ? (void *)co : (void *)st.h_out.p, d_res(), n * rec, hipMemcpyDeviceToHost, stream);
         else he = hipEventRecord(dev.events[s], stream);
         if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(he)));

@@ -17,12 +17,17 @@ need = int(host.lib().bsw_pack_tasks_bound(tasks.ctypes.data, len(tasks)))
 pa = host.HostArena(need + 64)
 ptasks, _w = host.pack_tasks(tasks, pa.view(np.uint64, need // 8 + 1))
 print("GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES"), flush=True)
-for streams, chunk in [(4, 98304), (5, 98304), (6, 98304), (8, 98304), (6, 65536), (8, 65536), (8, 49152), (6, 131072)]:
-    with host.BswContext(device=0, streams=streams, chunk_tasks=chunk) as ctx:
+pin = None if len(sys.argv) < 2 else (sys.argv[1] == "pin")
+print("pin_threads =", pin, flush=True)
+for streams, chunk in [(4, 98304), (3, 98304), (4, 98304), (3, 98304), (4, 131072), (3, 131072), (4, 98304), (3, 98304), (4, 131072), (3, 131072)]:
+    with host.BswContext(device=0, streams=streams, chunk_tasks=chunk, pin_threads=pin) as ctx:
+        if streams == 2:
+            print("placement", ctx.placement(), "main thread may run on", len(os.sched_getaffinity(0)), "CPUs", flush=True)
         ctx.extend_pairs_packed(p, ptasks, out=obuf)
-        best = 1e9
-        for _ in range(5):
+        ts = []
+        for _ in range(7):
             t0 = time.perf_counter()
             ctx.extend_pairs_packed(p, ptasks, out=obuf)
-            best = min(best, time.perf_counter() - t0)
-    print("slots %d chunk %6d: %.2f ms = %.1f M seeds/s" % (streams, chunk, best * 1e3, n / best / 1e6), flush=True)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+    print("slots %d chunk %6d: best %.2f ms median %.2f ms = %.1f M seeds/s (median)" % (streams, chunk, ts[0] * 1e3, ts[3] * 1e3, n / ts[3] / 1e6), flush=True)
