@@ -437,7 +437,12 @@ def main():
     # ---- is this rank next to ITS card?  (the launcher assumed render-node order = HIP order; bwa_mem_sw.v:162 /
     # batch_manager.v:343-348: one manager next to its arrays) ----
     props = torch.cuda.get_device_properties(local_rank)
-    my_bdf = device_bdf(props)
+    try:
+        my_bdf = device_bdf(props)
+    except AttributeError:                           # a torch build whose device properties carry no PCI address: nothing to check
+        class _NoPci:
+            pci_domain_id = pci_bus_id = pci_device_id = 0
+        props, my_bdf = _NoPci(), "unknown"
     try:
         my_node = int(open("/sys/bus/pci/devices/%s/numa_node" % my_bdf).read().strip())
     except (OSError, ValueError):

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
 pkg = graft.load_package()
 host = pkg.host
-host._LIB = os.path.join(os.path.dirname(host._LIB), "libbwasw_stamp.so")
+assert host.lib_path().endswith("libbwasw_stamp.so"), "run with BSW_LIB_PATH=.../libbwasw_stamp.so (make stamp STAMP_MODE=1)"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 mixed = len(sys.argv) > 2 and sys.argv[2] == "mixed"
 p = host.default_params(max_band_try=1)
