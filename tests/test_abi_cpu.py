@@ -247,3 +247,25 @@ def test_narrow_lane_class_is_a_per_chunk_decision(host):
         assert seg[base + 1] == seg[base]
         t = tasks[order[seg[base + 1]:seg[base + 2]]]
         assert len(t) == int(((tasks[qf] > 0) & eight_bit(tasks)).sum()) and (t[qf] < 72).any() and (t[qf] >= 72).any()
+
+
+def test_abi_version_and_sized_create(host):
+    """ABI 5: bsw_config has no size field, so a caller built against an older, shorter struct passes ITS sizeof to
+    bsw_create_sized (fields it does not know keep their defaults); sizes that cannot be a bsw_config of any ABI are refused
+    before anything touches the GPU; bsw_default_config turns the slot-thread pinning on; the Python mirror agrees with the
+    header about the version."""
+    import ctypes as C
+    import re
+    L = host.lib()
+    hdr = open(os.path.join(ROOT, "include", "bwa_sw_mi355.h")).read()
+    assert L.bsw_abi_version() == int(re.search(r"#define BSW_ABI_VERSION (\d+)", hdr).group(1)) == 5
+    cfg = np.zeros(1, dtype=host.CONFIG)
+    L.bsw_default_config(cfg.ctypes.data)
+    assert cfg["pin_threads"][0] == 1 and cfg["timeout_ms"][0] == 120000 and cfg["result_format"][0] == host.RESULT_FULL
+    h = C.c_void_p()
+    for bad in (0, 8, host.CONFIG.itemsize + 8, 4096):
+        assert L.bsw_create_sized(cfg.ctypes.data, bad, C.byref(h)) == -2 and not h.value          # BSW_E_INVAL
+    import torch
+    if not torch.cuda.is_available():       # the accepted sizes get as far as the device check (ABI 3: 96 bytes, ABI 4/5: 104)
+        for ok in (96, host.CONFIG.itemsize):
+            assert L.bsw_create_sized(cfg.ctypes.data, ok, C.byref(h)) == -1 and not h.value        # BSW_E_NODEVICE

@@ -19,7 +19,8 @@ while lo < len(tasks) and len(ins) < nb:
     if reg:
         wview[len(ins)] = w; w = wview[len(ins)]
     ins.append(w); outs.append(np.zeros(host.REFBATCH_OUT_WORDS, np.uint32)); lo += n
-with host.BswContext(device=0, pack_threads=pt) as c:
+kern = int(os.environ.get("WIRE_KERNEL", "0"))                    # 2: lane bins forced whatever the group size
+with host.BswContext(device=0, pack_threads=pt, kernel=kern) as c:
     ts = []
     for rep in range(7):
         t0 = time.perf_counter()
@@ -28,5 +29,5 @@ with host.BswContext(device=0, pack_threads=pt) as c:
         c.refbatch_wait(0, 0)
         ts.append(time.perf_counter() - t0)
 ts = sorted(ts[1:])
-print(json.dumps({"input": "registered" if reg else "pageable", "group": os.environ.get("BSW_REFBATCH_GROUP", "default"), "pack_threads": pt, "batches": nb, "seeds": lo,
+print(json.dumps({"kernel": kern, "input": "registered" if reg else "pageable", "group": os.environ.get("BSW_REFBATCH_GROUP", "default"), "pack_threads": pt, "batches": nb, "seeds": lo,
                   "ms_min_median": [round(ts[0] * 1e3, 3), round(ts[len(ts) // 2] * 1e3, 3)], "M_seeds_per_s_best": round(lo / ts[0] / 1e6, 2)}))
