@@ -375,6 +375,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 250 bp and mixed-bin side measurements (N=1 only, outside the timed region)")
     ap.add_argument("--pe-seeds", type=int, default=10_000_000, help="seeds of the 150 bp PE mixed-bin measurement beside the headline (BASELINE configs[2]: 10 M; 0 = skip)")
+    ap.add_argument("--packed-chunk", type=int, default=114688, help="seeds per chunk of the packed-input single-submit legs (112 Ki: 9 chunks per 1 M seeds; re-swept with round 5 kernels, profiles/r5/e2e_packed_chunk_sweep.txt: 64 / 80 / 96 / 112 / 128 / 160 Ki -> 103 / 113 / 115 / 123 / 122 / 95 M seeds/s)")
     ap.add_argument("--e2e-slots", type=int, default=4, help="slot threads (= streams) of the single-submit PCIe-inclusive legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bsw_submit (PCIe-inclusive) measurement")
     ap.add_argument("--e2e-reps", type=int, default=5, help="bsw_submit passes timed (median reported)")
@@ -640,7 +641,7 @@ def main():
         ptasks, _w = host.pack_tasks(tasks, parena.view(np.uint64, need // 8 + 1))
         # 96 Ki chunks: with half the bytes per seed the input DMAs are short and smaller chunks start the GPU sooner
         # (sweep: profiles/r3/e2e_packed_sweep.txt)
-        pctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=98304)
+        pctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.packed_chunk)
         for _ in range(2):
             pctx.extend_pairs_packed(params, ptasks, out=out_buf)
         runs = []
@@ -660,7 +661,7 @@ def main():
         # the same submit handing back the RTL's 5-word record alone (BSW_RESULT_PAIR: 32 of the 96 result bytes per seed)
         pout = host.HostArena(max(n_local, 1) * host.PAIR.itemsize)
         pair_buf = pout.view(host.PAIR, max(n_local, 1))[:n_local]
-        qctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=98304, result_format=host.RESULT_PAIR)
+        qctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.packed_chunk, result_format=host.RESULT_PAIR)
         for _ in range(2):
             qctx.extend_pairs_packed(params, ptasks, out=pair_buf)
         qruns = []
