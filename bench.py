@@ -376,6 +376,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the 250 bp and mixed-bin side measurements (N=1 only, outside the timed region)")
     ap.add_argument("--pe-seeds", type=int, default=10_000_000, help="seeds of the 150 bp PE mixed-bin measurement beside the headline (BASELINE configs[2]: 10 M; 0 = skip)")
     ap.add_argument("--packed-chunk", type=int, default=114688, help="seeds per chunk of the packed-input single-submit legs (112 Ki: 9 chunks per 1 M seeds; re-swept with round 5 kernels, profiles/r5/e2e_packed_chunk_sweep.txt: 64 / 80 / 96 / 112 / 128 / 160 Ki -> 103 / 113 / 115 / 123 / 122 / 95 M seeds/s)")
+    ap.add_argument("--e2e-chunk", type=int, default=131072, help="seeds per chunk of the byte-input and device-reference single-submit legs")
     ap.add_argument("--e2e-slots", type=int, default=4, help="slot threads (= streams) of the single-submit PCIe-inclusive legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bsw_submit (PCIe-inclusive) measurement")
     ap.add_argument("--e2e-reps", type=int, default=5, help="bsw_submit passes timed (median reported)")
@@ -612,7 +613,7 @@ def main():
     # ---- the same seeds through bsw_submit: host buffers in (registered arena), host buffers out ----
     e2e_dt = None
     if not args.no_e2e:
-        sctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=chunk)
+        sctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.e2e_chunk)
         for _ in range(2):                                       # warm up twice: staging allocations and code load, then the pipeline's steady layout (the first timed pass after ONE warm-up ran 16 ms against 10.4)
             sctx.extend_pairs(params, tasks, out=out_buf)
         e2e_runs = []
@@ -683,7 +684,7 @@ def main():
         lp = args.ref_mbp * 1_000_000
         hreads = host.HostArena(spec["read_len"] * n_local + 4096)
         pac, rtasks, _ = host.synth_ref_tasks(n_local, lp, params, arena=hreads.u8, seed=3000 + rank, **spec)
-        rctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=chunk)
+        rctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.e2e_chunk)
         gref = rctx.ref_upload(pac, lp)
         for _ in range(2):                                                      # warm up
             rctx.submit_ref(params, gref, rtasks, out=out_buf); rctx.wait()

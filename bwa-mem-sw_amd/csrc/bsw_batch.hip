@@ -1214,12 +1214,15 @@ static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp,
         pend.direct = is_registered(co, n * rec);
         if (!pend.direct && (he = st.h_out.reserve(n)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
         /* A result copy queued behind its kernels sits at the head of its DMA engine's ring until they finish and holds up
-         * the copies queued to that engine after it (profiles/r2/wire_submit_timeline.txt).  With the reference on the
-         * device the input DMAs are short and that wait is what the pipeline loses (+7 % when the slot thread issues the
-         * result DMA itself once the kernels are done); with 448 B per seed of input the link is busy anyway and the
-         * extra host round trip per chunk costs more than it saves (-6 %), so there the copy is queued right away. */
+         * the copies queued to that engine after it (profiles/r2/wire_submit_timeline.txt): the slot thread issues the result
+         * DMA itself once the chunk's kernels are done (it waits for them anyway before it reuses the staging).  Round 2 did
+         * that for the device-reference path only (+7 %) and queued the copy right away for byte and packed input (the host
+         * round trip cost 6 % then).  Re-measured with round 5's kernels (profiles/r5/e2e_late_result_dma.txt): the single
+         * submits are unchanged in the median, the byte path loses its outliers — one pass in five took 16 - 18 ms instead of
+         * 10.4 when an input DMA landed behind a waiting result copy: max / min 1.05 - 1.07 instead of 1.2 - 1.8 — and a stream of
+         * packed submits kept two deep goes from 110 - 113 to 128 - 134 M seeds/s.  BSW_LATE_RESULT=0: the old behaviour. */
         static const int late_env = getenv("BSW_LATE_RESULT") ? atoi(getenv("BSW_LATE_RESULT")) : -1;     /* (measurements) */
-        const bool late = late_env >= 0 ? late_env != 0 : rtasks != nullptr;
+        const bool late = late_env >= 0 ? late_env != 0 : true;
         if (!late) he = hipMemcpyAsync(pend.direct ? (void *)co : (void *)st.h_out.p, d_res(), n * rec, hipMemcpyDeviceToHost, stream);
         else he = hipEventRecord(dev.events[s], stream);
         if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(he)));
