@@ -590,7 +590,13 @@ def main():
 
     # streams kept two deep: two contexts; slots per context and chunk size per input format from the sweeps in
     # profiles/r3/e2e_hw_queues.txt (the HIP runtime maps streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default)
-    STREAM_CFG = {"bytes": (2, 2 * chunk), "packed": (4, 131072), "ref": (2, chunk)}
+    # (re-swept with round 5's kernels and the late result DMAs, profiles/r5/e2e_stream_cfg_sweep.txt: two contexts of TWO slots each —
+    # four streams, one per hardware queue — beat two of four: packed 146 vs 124, device reference 142 vs 123 M seeds/s)
+    STREAM_CFG = {"bytes": (2, 2 * chunk), "packed": (2, 131072), "ref": (2, chunk)}
+    for kind in list(STREAM_CFG):                     # (measurements) BENCH_STREAM_PACKED="slots,chunk" etc.
+        ov = os.environ.get("BENCH_STREAM_" + kind.upper())
+        if ov:
+            STREAM_CFG[kind] = tuple(int(x) for x in ov.split(","))
     def stream_threads(kind):
         return "%d slot threads (2 contexts x %d slots, %d-seed chunks)" % (2 * STREAM_CFG[kind][0], STREAM_CFG[kind][0], STREAM_CFG[kind][1])
 
