@@ -901,6 +901,7 @@ def main():
             extra[wl] = {"gcups": round(g2, 1), "ms_per_step": round(ms, 3), "seeds": args.tasks,
                          "roofline_frac": round(g2 * 1e9 * VALU_OPS_PER_CELL / 1e12 / PEAK_VALU_TOPS, 4), "kernel_launches_per_step": b2.info()["launches"],
                          "valu_insts_per_cell": pm2.get("valu_lane_insts_per_cell"), "valu_issue_busy": pm2.get("valu_issue_busy"),
+                         "traffic": (int((2 * pm2["FETCH_SIZE_KiB"] + pm2["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in pm2 else None),
                          "counters": src2.get("status")}
             b2.free()
         out["other_workloads"] = extra
@@ -1000,6 +1001,7 @@ def pe_mixed_leg(host, ctx, args, cpu_affinity, n_seeds, steps=3):
                          "unit": "T lane-ops/s", "frac": round(tops / PEAK_VALU_TOPS, 5),
                          "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"), "valu_issue_busy": pmc.get("valu_issue_busy"),
                          "waves_per_simd_avg": pmc.get("waves_per_simd_avg"),
+                         "traffic_per_1M_seed_step": (int((2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in pmc else None),
                          "counters_source": dict(pmc_src, note="collected on the 1 M-seed instance of this workload (bench.py --workload %s)" % wl)}}
 
 

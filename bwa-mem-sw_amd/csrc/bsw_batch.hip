@@ -394,13 +394,38 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
          * [1 + BSW_MAX_WAVE_CLASSES] the redo launch's — zeroed here, on the stream, before anything counts in them */
         uint32_t *redo_cnt = J.d_order + pl.order_len;
         HIPCHK(e, hipMemsetAsync(redo_cnt, 0, (2 + BSW_MAX_WAVE_CLASSES) * sizeof(uint32_t), s));
-        for (int c = 0; c < nc; ++c) {
+        /* The general-kernel classes of a part side by side (round 5).  A batch below the lane kernels' threshold is a few
+         * thousand wavefronts in two or three classes (PE seeds: 64 / 128 / 192 columns); launched one after the other each class
+         * leaves most of the machine idle for one wave's lifetime.  With idle streams at hand (the fork set of stream 0: resident
+         * batches, synchronous chunks) class k goes to stream k, the slot stream joins them: 13 k PE mixed seeds 0.77 -> 0.55 ms
+         * (profiles/r5/crossover_mixed_bins_general_forked.json).  The reference's task_parse keeps its 20 PEs busy from any batch
+         * (sw_pe_array_task_parse.v:1600-1648). */
+        int nwave = 0;
+        for (int c = 0; c < nc; ++c) nwave += pl.wave_start[c + 1] - pl.wave_start[c] ? 1 : 0;
+        static const bool no_wfork = getenv("BSW_NO_WAVE_FORK") != nullptr;        /* (measurements) */
+        const bool wfork = !no_wfork && nwave >= 2 && fk && fk->ok && fk->naux > 0 && (fk->mode == 1 || fk->mode == 2);
+        bool used[BSW_FORK_AUX] = {false};
+        if (wfork) {
+            HIPCHK(e, hipEventRecord(fk->ev_fork, s));                  /* the input DMAs, pack, bins and the zeroed counters */
+            for (int a = 0; a < fk->naux; ++a) HIPCHK(e, hipStreamWaitEvent(fk->aux[a], fk->ev_fork, 0));
+        }
+        int k = 0;
+        for (int c = nc - 1; c >= 0; --c) {                             /* widest class first: its waves run longest */
             const uint32_t cnt = pl.wave_start[c + 1] - pl.wave_start[c];
             if (!cnt) continue;
-            HIPCHK(e, bsw::launch_wave(c, J.variant, *J.P, J.d_seq, J.d_tasks, J.d_order + pl.wave_start[c], cnt, nullptr, redo_cnt + 1 + c, J.d_out, s));
-            if (J.d_pair) HIPCHK(e, bsw::launch_pairs_from_results(J.d_order + pl.wave_start[c], cnt, nullptr, J.d_out, J.d_pair, s));
+            hipStream_t ws = s;
+            if (wfork && k > 0) { const int a = (k - 1) % fk->naux; ws = fk->aux[a]; used[a] = true; }
+            ++k;
+            HIPCHK(e, bsw::launch_wave(c, J.variant, *J.P, J.d_seq, J.d_tasks, J.d_order + pl.wave_start[c], cnt, nullptr, redo_cnt + 1 + c, J.d_out, ws));
+            if (J.d_pair) HIPCHK(e, bsw::launch_pairs_from_results(J.d_order + pl.wave_start[c], cnt, nullptr, J.d_out, J.d_pair, ws));
             if (J.launches) ++*J.launches;
         }
+        if (wfork)
+            for (int a = 0; a < fk->naux; ++a)
+                if (used[a]) {
+                    HIPCHK(e, hipEventRecord(fk->ev_left[a], fk->aux[a]));
+                    HIPCHK(e, hipStreamWaitEvent(s, fk->ev_left[a], 0));
+                }
     }
     /* Does every lane launch of a part run a kernel that finishes its seeds itself (bsw_fin: the launch that computes a seed's
      * last side takes the pair-level decision)?  Then bsw_pair_finalize is not launched for it: one launch and a 96-byte

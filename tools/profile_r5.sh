@@ -9,9 +9,9 @@ cd $R
 rm -rf gpurun_out/r5prof
 tools/profile.sh r5prof/head > /dev/null
 echo head done
-tools/profile_quick.sh r5prof/mixed --workload 150bp_w100_mixed_bins > /dev/null
+TRAFFIC=1 tools/profile_quick.sh r5prof/mixed --workload 150bp_w100_mixed_bins > /dev/null
 echo mixed done
-tools/profile_quick.sh r5prof/w250 --workload 250bp_w500 > /dev/null
+TRAFFIC=1 tools/profile_quick.sh r5prof/w250 --workload 250bp_w500 > /dev/null
 echo w250 done
 if [ -z "$QUICK" ]; then
 tools/profile_quick.sh r5prof/c72 --spec seed_len_min=79 --spec seed_len_max=79 > /dev/null
