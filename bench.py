@@ -12,6 +12,10 @@ Prints ONE JSON line on rank 0.  `value` = DP cells actually evaluated (exactly 
 algorithm iterates them) / wall time / 1e9, summed over ranks, inputs already in HBM.
 `e2e` = the same batch pushed through bsw_submit (host buffers in, host buffers out: DMA out of
 registered host memory, packing and binning on the GPU) — PCIe-inclusive, never `value`.
+`pe_mixed_bins` (N=1) = the workload BASELINE.json's metric names — 150 bp PE seeds, left + right
+extension each, mixed (qlen, tlen) bins through the batch manager — at configs[2] size (10 M seeds,
+--pe-seeds), resident in HBM, with its own roofline object and the counters of that workload's own
+rocprofv3 passes (profiles/pmc_latest.json holds one entry per workload).  Never part of `value`.
 """
 import argparse
 import json
