@@ -26,7 +26,19 @@
 #include <stdlib.h>
 
 #include "bsw_device.h"
-#define L2_STAMP(k) ((void)0)
+#ifdef BSW_L2L_STAMP
+/* profiling build only (make stampl; tools/l2_stamps.py): per-wave cycle accumulators of the row-loop sections (s_memtime), reported
+ * through the result records instead of the alignment results */
+#define BSW_L2_STAMP 2
+__shared__ unsigned long long l2l_acc[4][8];
+__shared__ unsigned long long l2l_last[4];
+__device__ void bsw_l2_stamp(int k)
+{
+    const int wv = threadIdx.x >> 6;
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) { l2l_acc[wv][k] += t - l2l_last[wv]; l2l_last[wv] = t; }
+}
+#endif
 #define BSW_L2_ASM_BODY 1       /* block bodies as hand-scheduled asm (bsw_lane2_body_asm.inc) */
 #define BSW_L2_GRID 1           /* ... in their 64-bit-aligned encoding: one wave per SIMD sees every fetch bubble */
 #include "bsw_lane2_core.h"
@@ -338,10 +350,14 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
     fetch_row(0);
 #endif
 
+#ifdef BSW_L2L_STAMP
+    if (lane == 0) { for (int q = 0; q < 8; ++q) l2l_acc[wv][q] = 0; l2l_last[wv] = __builtin_amdgcn_s_memtime(); }
+#endif
     for (int i = 0;; ++i) {
         l2::rowp r;
         l2::row_begin2(S.p, i, r);                                /* K3 band clamp, both seeds at once */
         if (__builtin_amdgcn_ballot_w64(r.ACT != 0) == 0) break;
+        L2_STAMP(0);
 #ifndef BSW_L2L_NO_PREFETCH
         const int tb[2] = {tbN[0], tbN[1]};
         uint32_t rmC[2][NW];
@@ -394,7 +410,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
             u.zh = wave_max2l(max(bt0 ? l2::half_of(r.ZHI, 0) : INT_MIN, bt1 ? l2::half_of(r.ZHI, 1) : INT_MIN));
         }
         u.nblk = nblk;
+        L2_STAMP(1);
         L::row_body(S, k, i, r, u, tb, qpc, kp, wn, row);
+        L2_STAMP(4);
     }
 
     l2::sfor<2>([&](auto xi) {
@@ -404,6 +422,10 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
         bsw_ext e;
         e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
         e.gscore = s.gscore; e.max_off = s.max_off; e.aw = P.w; e.cells = s.cells;
+#ifdef BSW_L2L_STAMP
+        e.score = (int)(l2l_acc[wv][0] >> 4); e.qle = (int)(l2l_acc[wv][1] >> 4); e.tle = (int)(l2l_acc[wv][2] >> 4);
+        e.gtle = (int)(l2l_acc[wv][3] >> 4); e.gscore = (int)(l2l_acc[wv][4] >> 4);
+#endif
 #ifdef BSW_L2L_WAVELOG
         e.max_off = (int)(wl_t0 & 0x7fffffffu); e.aw = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffffu);
         e.cells = ((unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) | ((unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);
