@@ -263,6 +263,7 @@ for variant, gaps in ((0, {}), (1, dict(o_del=5, e_del=2, o_ins=7, e_ins=1))):
             assert_same(got, want, tasks)
         got = c.extend_pairs(p, tasks)              # the synchronous chunk path shares stream 0 and its chain
         assert_same(got, want, tasks)
+        assert c.chain_timeouts() == 0              # in normal operation no waiting wave ever reaches its 20 ms deadline
 print("ok")
 """
 
