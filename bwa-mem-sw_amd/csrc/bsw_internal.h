@@ -160,9 +160,11 @@ struct stage_t {
     dbuf<uint64_t> d_blob;
     dbuf<bsw_refx> d_desc;
     dbuf<bsw_wireoff> d_woff;
-    void set_pinned(bool on) { h_raw.pinned = h_tasks.pinned = h_roff.pinned = h_out.pinned = h_desc.pinned = h_woff.pinned = h_blob.pinned = on; }
-    void release_host() { h_raw.release(); h_tasks.release(); h_roff.release(); h_out.release(); h_desc.release(); h_woff.release(); h_blob.release(); }
-    void release_transient_dev() { d_raw.release(); d_roff.release(); d_bins.release(); d_desc.release(); d_woff.release(); d_blob.release(); }
+    hbuf<uint32_t> h_wout;            /* wire format: the group's 16 KiB result batches as the device wrote them */
+    dbuf<uint32_t> d_wout;
+    void set_pinned(bool on) { h_raw.pinned = h_tasks.pinned = h_roff.pinned = h_out.pinned = h_desc.pinned = h_woff.pinned = h_blob.pinned = h_wout.pinned = on; }
+    void release_host() { h_raw.release(); h_tasks.release(); h_roff.release(); h_out.release(); h_desc.release(); h_woff.release(); h_blob.release(); h_wout.release(); }
+    void release_transient_dev() { d_raw.release(); d_roff.release(); d_bins.release(); d_desc.release(); d_woff.release(); d_blob.release(); d_wout.release(); }
     void release()
     {
         release_host();

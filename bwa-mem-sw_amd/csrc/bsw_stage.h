@@ -12,9 +12,10 @@
 #define BSW_BIN_LANEALL (BSW_BIN_WAVE0 + BSW_MAX_WAVE_CLASSES)
 #define BSW_BIN_WORDS   (BSW_BIN_LANEALL + 8)
 
-/* where a task's nibble stream starts inside the uploaded wire batches, and the four lengths in stream order */
+/* where a task's nibble stream starts inside the uploaded wire batches (256 batches x 65 536 words x 8 nibbles = 2^27), where
+ * its 5-word record goes inside the group's result batches, and the four lengths in stream order */
 typedef struct bsw_wireoff {
-    uint64_t nib;
+    uint32_t nib, out_word;
     uint16_t lqlen, rqlen, ltlen, rtlen;
 } bsw_wireoff;
 
@@ -45,6 +46,8 @@ hipError_t launch_pairs_from_results(const uint32_t *order, uint32_t n, const ui
 hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t bias, uint32_t n, int rev_left,
                        const uint8_t *pac, int64_t l_pac, const bsw_refx *refx, uint64_t *seq, hipStream_t s);
 hipError_t launch_wire_pack(const uint32_t *wire, const bsw_dtask *tasks, const bsw_wireoff *woffs, uint32_t n, uint64_t *seq, hipStream_t s);
+/* the group's 16 KiB result batches, written on the device: wout[woffs[t].out_word .. + 4] = R0..R4 of task t, the rest zero */
+hipError_t launch_wire_results(const bsw_result *out, const bsw_wireoff *woffs, uint32_t n, uint32_t *wout, size_t wout_words, hipStream_t s);
 int global_class_count();
 int global_class_cols(int cls);
 hipError_t launch_global(int cls, const bsw_dparams &P, const uint64_t *seq, const bsw_gdtask *tasks, const uint32_t *order, uint32_t n,

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void bsw_wire_pack_kernel(const uint32_t *__re
     const bsw_wireoff W = woffs[ti];
     int len;
     uint32_t woff;
-    uint64_t nib;                                           /* stream order: leftQ, rightQ, leftT, rightT */
+    uint32_t nib;                                           /* stream order: leftQ, rightQ, leftT, rightT */
     switch (which) {
     case 0: len = T.lqlen; woff = T.lq_off; nib = W.nib; break;
     case 1: len = T.lqlen ? T.ltlen : 0; woff = T.lt_off; nib = W.nib + W.lqlen + W.rqlen; break;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void bsw_wire_pack_kernel(const uint32_t *__re
     }
     const int nw = (len + 15) >> 4;
     for (int k = l16; k < nw; k += 16) {
-        const uint64_t nb = nib + 16u * (uint64_t)k;
+        const uint32_t nb = nib + 16u * (uint32_t)k;
         const uint32_t *q = wire + (nb >> 3);
         const uint32_t sh = (uint32_t)(nb & 7u) * 4u;
         /* after rev_nibbles, base j of a wire word sits in bits [4j,4j+3] — the seq layout */
@@ -318,6 +318,22 @@ __global__ __launch_bounds__(256) void bsw_wire_pack_kernel(const uint32_t *__re
         v = (v & ~(big * 0xFull)) | (big << 2);
         seq[woff + (uint32_t)k] = v;
     }
+}
+
+/* ---- results -> the reference's 16 KiB result batches (F1): five words per task (rbb.v:59, proc_element.v:1662-1665,1190-1199),
+ * the encoding of bsw_refbatch_encode_results, written where the task's batch and position say ---- */
+__global__ __launch_bounds__(256) void bsw_wire_results_kernel(const bsw_result *__restrict__ out, const bsw_wireoff *__restrict__ woffs,
+                                                               const uint32_t n, uint32_t *__restrict__ wout)
+{
+    const uint32_t ti = blockIdx.x * 256u + threadIdx.x;
+    if (ti >= n) return;
+    const uint4 a = *(const uint4 *)&out[ti], b = *((const uint4 *)&out[ti] + 1);      /* tag qb qe rb | re score truesc w */
+    uint32_t *R = wout + woffs[ti].out_word;
+    R[0] = a.x;
+    R[1] = (a.z << 16) | (a.y & 0xffffu);
+    R[2] = (b.x << 16) | (a.w & 0xffffu);
+    R[3] = (b.z << 16) | (b.y & 0xffffu);
+    R[4] = b.w;
 }
 
 /* ---- launchers ---- */
@@ -334,6 +350,14 @@ hipError_t launch_wire_pack(const uint32_t *wire, const bsw_dtask *tasks, const 
     if (n == 0) return hipSuccess;
     const uint32_t groups = n * 4u;
     hipLaunchKernelGGL(bsw_wire_pack_kernel, dim3((groups + 15u) / 16u), dim3(256), 0, s, wire, tasks, woffs, n, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_wire_results(const bsw_result *out, const bsw_wireoff *woffs, uint32_t n, uint32_t *wout, size_t wout_words, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(wout, 0, wout_words * sizeof(uint32_t), s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(bsw_wire_results_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, out, woffs, n, wout);
     return hipGetLastError();
 }
 

@@ -30,9 +30,8 @@ extern "C" int bsw_refbatch_submit(bsw_ctx *ctx, const uint32_t *in_words, uint3
 #define REFBATCH_GROUP 16
 #define REFBATCH_GROUP_DEEP 64
 #define REFBATCH_SLOTS 4
-static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int zdrop, stage_t &st, hipStream_t s, size_t *n_out)
+static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int variant, int zdrop, stage_t &st, hipStream_t s, size_t *n_out)
 {
-    errs &e = ctx->err;
     *n_out = 0;
     static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -61,9 +60,19 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
     bool direct = true;
     for (size_t q = q0; q < q1 && direct; ++q) direct = is_registered(ctx->ref_queue[q].in, BSW_REFBATCH_IN_WORDS * sizeof(uint32_t));
     hipError_t he;
-    if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_woff.reserve(n + 1)) != hipSuccess ||
-        (he = st.h_out.reserve(n + 1)) != hipSuccess || (!direct && (he = st.h_raw.reserve(wire_words * 4 + RAW_SLACK)) != hipSuccess))
+    if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_woff.reserve(n + 1)) != hipSuccess || (!direct && (he = st.h_raw.reserve(wire_words * 4 + RAW_SLACK)) != hipSuccess))
         return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+    /* The batches themselves start crossing PCIe BEFORE the headers are parsed when they can be DMA'd in place: 16 MB per 64
+     * batches = 0.3 ms that used to follow the 0.35 ms parse now runs beside it (profiles/r5/wire_format_timeline.txt) */
+    if ((he = st.d_raw.reserve(wire_words * 4 + RAW_SLACK)) != hipSuccess) return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    if (direct)
+        for (size_t q = q0; q < q1;) {                 /* one DMA per run of batches that lie back to back in the caller's memory */
+            size_t r1 = q + 1;
+            while (r1 < q1 && ctx->ref_queue[r1].in == ctx->ref_queue[r1 - 1].in + BSW_REFBATCH_IN_WORDS) ++r1;
+            HIPCHK(e, hipMemcpyAsync(st.d_raw.p + (q - q0) * (size_t)BSW_REFBATCH_IN_WORDS * 4, ctx->ref_queue[q].in,
+                                     (r1 - q) * (size_t)BSW_REFBATCH_IN_WORDS * 4, hipMemcpyHostToDevice, s));
+            q = r1;
+        }
     /* headers -> task records (host: 8 words per task) */
     chunk_info ci;
     rc = fill_binparams(e, &p, ctx->cfg.kernel, ci.bp);
@@ -132,7 +141,8 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
                 }
                 const int h0 = (int)(H[4] & 0xff);
                 if (h0 <= 0) { pt.rc = fail(pt.e, BSW_E_INVAL, "task batch: task %u has h0 <= 0", i); return; }
-                wo.nib = ((uint64_t)(q - q0) * BSW_REFBATCH_IN_WORDS + (uint64_t)pos) * 8u;
+                wo.nib = (uint32_t)(((uint64_t)(q - q0) * BSW_REFBATCH_IN_WORDS + (uint64_t)pos) * 8u);
+                wo.out_word = (uint32_t)((q - q0) * (size_t)BSW_REFBATCH_OUT_WORDS + 5u * i);
                 wo.lqlen = (uint16_t)lq; wo.rqlen = (uint16_t)rq; wo.ltlen = (uint16_t)lt; wo.rtlen = (uint16_t)rt;
                 if (lq) { d.lq_off = (uint32_t)a2; a2 += nwords(lq); d.lt_off = (uint32_t)a2; a2 += nwords(lt); }
                 if (rq) { d.rq_off = (uint32_t)a2; a2 += nwords(rq); d.rt_off = (uint32_t)a2; a2 += nwords(rt); }
@@ -193,70 +203,51 @@ static int refbatch_enqueue(bsw_ctx *ctx, size_t q0, size_t q1, int variant, int
     memcpy(bp.laneL_off, pl.laneL_off, sizeof(bp.laneL_off));
     memcpy(bp.laneR_off, pl.laneR_off, sizeof(bp.laneR_off));
     /* device: wire batches -> seq, bins, DP kernels, results */
-    if ((he = st.d_raw.reserve(wire_words * 4 + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve((size_t)acc + 4)) != hipSuccess ||
+    const size_t wout_words = nb * (size_t)BSW_REFBATCH_OUT_WORDS;
+    if ((he = st.d_seq.reserve((size_t)acc + 4)) != hipSuccess ||
         (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_woff.reserve(n + 1)) != hipSuccess ||
         (he = st.d_order.reserve(order_capacity(n))) != hipSuccess || (he = st.d_bins.reserve(BSW_BIN_WORDS)) != hipSuccess ||
-        (he = st.d_out.reserve(n + 1)) != hipSuccess)
+        (he = st.d_out.reserve(n + 1)) != hipSuccess || (he = st.d_wout.reserve(wout_words)) != hipSuccess)
         return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+    if ((he = st.h_wout.reserve(wout_words)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
     if (!direct) HIPCHK(e, hipMemcpyAsync(st.d_raw.p, st.h_raw.p, wire_words * 4, hipMemcpyHostToDevice, s));
-    else
-        for (size_t q = q0; q < q1;) {                 /* one DMA per run of batches that lie back to back in the caller's memory */
-            size_t r1 = q + 1;
-            while (r1 < q1 && ctx->ref_queue[r1].in == ctx->ref_queue[r1 - 1].in + BSW_REFBATCH_IN_WORDS) ++r1;
-            HIPCHK(e, hipMemcpyAsync(st.d_raw.p + (q - q0) * (size_t)BSW_REFBATCH_IN_WORDS * 4, ctx->ref_queue[q].in,
-                                     (r1 - q) * (size_t)BSW_REFBATCH_IN_WORDS * 4, hipMemcpyHostToDevice, s));
-            q = r1;
-        }
     HIPCHK(e, hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(st.d_woff.p, st.h_woff.p, n * sizeof(bsw_wireoff), hipMemcpyHostToDevice, s));
     HIPCHK(e, bsw::launch_wire_pack((const uint32_t *)st.d_raw.p, st.d_tasks.p, st.d_woff.p, (uint32_t)n, st.d_seq.p, s));
     HIPCHK(e, bsw::launch_bin(bp, st.d_seq.p, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
     rc = enqueue_batch(e, dp, variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, pl, st.d_out.p, s, nullptr);
     if (rc) return rc;
-    /* the result DMA is issued by refbatch_collect once the kernels are done: a copy queued now would sit in its DMA
-     * engine's ring until then and hold up the next group's input copies queued behind it */
+    /* the 16 KiB result batches are written on the device (five words of a 96-byte record per task: a fifth of the bytes over
+     * PCIe, no encoding pass on the host).  Their DMA is issued by refbatch_collect_issue — once the kernels are done, or
+     * when no further group follows: a copy queued now would sit in its DMA engine's ring until then and hold up the next
+     * group's input copies queued behind it */
+    HIPCHK(e, bsw::launch_wire_results(st.d_out.p, st.d_woff.p, (uint32_t)n, st.d_wout.p, wout_words, s));
     *n_out = n;
     if (dbg) fprintf(stderr, "[bsw] wire:   enqueue: reserve + pass 1 %.3f ms, pass 2 (%zu threads) %.3f, plan + device enqueue %.3f\n", t_b - t_a, nth, t_c - t_b, tnow() - t_c);
     return BSW_OK;
 }
 
-/* wait for an enqueued group and write its 16 KiB result batches (host threads, one batch at a time each) */
-static int refbatch_collect(bsw_ctx *ctx, size_t q0, size_t q1, size_t n, stage_t &st, hipStream_t s, hipEvent_t ev)
+/* queue the DMA of an enqueued group's result batches behind its kernels (wait_kernels: only once they are done, for a
+ * group that other groups' input copies still follow) */
+static int refbatch_collect_issue(bsw_ctx *ctx, size_t q0, size_t q1, stage_t &st, hipStream_t s, hipEvent_t ev, bool wait_kernels)
 {
     errs &e = ctx->err;
-    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
-    {
-        const auto tk0 = std::chrono::steady_clock::now();
+    if (wait_kernels) {
         const int rc0 = sync_stream(ctx, e, s, ev);
         if (rc0) return rc0;
-        if (dbg) fprintf(stderr, "[bsw] wire:   waited %.3f ms for the kernels\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk0).count());
-        HIPCHK(e, hipMemcpyAsync(st.h_out.p, st.d_out.p, n * sizeof(bsw_result), hipMemcpyDeviceToHost, s));
     }
-    const auto tc0 = std::chrono::steady_clock::now();
-    int rc = sync_stream(ctx, e, s, ev);
+    HIPCHK(e, hipMemcpyAsync(st.h_wout.p, st.d_wout.p, (q1 - q0) * (size_t)BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return BSW_OK;
+}
+
+/* wait for a group's result batches and hand them to the caller's buffers */
+static int refbatch_collect(bsw_ctx *ctx, size_t q0, size_t q1, stage_t &st, hipStream_t s, hipEvent_t ev)
+{
+    errs &e = ctx->err;
+    const int rc = sync_stream(ctx, e, s, ev);
     if (rc) return rc;
-    const auto tc1 = std::chrono::steady_clock::now();
-    if (dbg) fprintf(stderr, "[bsw] wire:   waited %.3f ms for the result DMA\n", std::chrono::duration<double, std::milli>(tc1 - tc0).count());
-    const size_t nb = q1 - q0;
-    std::vector<size_t> tbase(nb + 1, 0);
-    for (size_t q = q0; q < q1; ++q) tbase[q - q0 + 1] = tbase[q - q0] + ctx->ref_queue[q].in[2];
-    const size_t nth = std::max<size_t>(1, std::min<size_t>((size_t)ctx->cfg.pack_threads, nb / 4));
-    std::vector<int> trc(nth, 0);
-    auto enc = [&](size_t t) {
-        for (size_t q = q0 + t; q < q1; q += nth) {
-            const uint32_t nt = ctx->ref_queue[q].in[2];
-            memset(ctx->ref_queue[q].out, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
-            const int r = bsw_refbatch_encode_results(st.h_out.p + tbase[q - q0], nt, ctx->ref_queue[q].out);
-            if (r < 0) trc[t] = r;
-        }
-    };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < nth; ++t) th.emplace_back(enc, t);
-    enc(0);
-    for (auto &x : th) x.join();
-    for (int r : trc)
-        if (r < 0) return fail(e, r, "result batch encode");
-    if (dbg) fprintf(stderr, "[bsw] wire:   encoded %zu result batches on %zu threads in %.3f ms\n", nb, nth, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
+    for (size_t q = q0; q < q1; ++q)
+        memcpy(ctx->ref_queue[q].out, st.h_wout.p + (q - q0) * (size_t)BSW_REFBATCH_OUT_WORDS, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
     return BSW_OK;
 }
 
@@ -274,39 +265,88 @@ extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
      * while the others are on the GPU (the reference's manager keeps its four TBB/RBB pairs busy the same way,
      * batch_manager.v:418,745-773). */
     dev_state &dev = ctx->devs[0];
-    /* Group size.  A deep queue (>= 96 batches = 79 k seeds) is cut into groups of 64 batches: 52 k PE seeds are past the point
-     * where the two-seeds-per-lane kernels beat the general one (48 k mixed seeds, profiles/r5/crossover_mixed_bins.json), and
-     * two such groups in flight overlap each other's launch floors (128 queued batches: 4.5 ms against 6.6 in groups of 16,
-     * profiles/r5/wire_format_group_sweep.txt).  A shallow queue keeps groups of 16 on the general kernel, which finishes 13 k
-     * seeds sooner than two lane launches of one wave's lifetime each.  BSW_REFBATCH_GROUP overrides (measurements). */
+    /* Group size.  A deep queue (>= 96 batches = 79 k seeds) is cut into TWO groups of at least 64 batches: 52 k PE seeds are
+     * past the point where the two-seeds-per-lane kernels beat the general one (48 k mixed seeds,
+     * profiles/r5/crossover_mixed_bins.json), and two groups in flight overlap each other's launch floors.  Not more: a group's
+     * chain (left launch, right launch: one wave's lifetime each) is 2.2 ms however few seeds it holds, and four groups of 64
+     * took 6.3 ms per 256 batches where two of 128 take 4.6 and three of 86 take 4.5 — the fourth slot stream shares a
+     * hardware queue (profiles/r5/wire_format_timeline.txt; r3/e2e_hw_queues.txt).  A shallow queue keeps groups of 16 on the
+     * general kernel, which finishes 13 k seeds sooner than two lane launches.  BSW_REFBATCH_GROUP overrides (measurements). */
     static const size_t grp_tune = getenv("BSW_REFBATCH_GROUP") ? (size_t)std::max(1, atoi(getenv("BSW_REFBATCH_GROUP"))) : 0;
-    const size_t grp_env = grp_tune ? grp_tune : (nq >= 96 ? (size_t)REFBATCH_GROUP_DEEP : (size_t)REFBATCH_GROUP);
+    const size_t grp_env = grp_tune ? grp_tune : (nq >= 96 ? std::max<size_t>(REFBATCH_GROUP_DEEP, (nq + 1) / 2) : (size_t)REFBATCH_GROUP);
     const size_t NS = std::max<size_t>(1, std::min<size_t>(REFBATCH_SLOTS, dev.slots.size()));
     const size_t slot_of[REFBATCH_SLOTS] = {0, 1, 2, 3};
-    struct flight { bool active = false; size_t q0 = 0, q1 = 0, n = 0; } fl[REFBATCH_SLOTS];
+    struct flight { bool active = false, issued = false; size_t q0 = 0, q1 = 0; } fl[REFBATCH_SLOTS];
     static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = tnow();
+    auto issue = [&](size_t sl, bool wait_kernels) -> int {
+        if (!fl[sl].active || fl[sl].issued) return BSW_OK;
+        fl[sl].issued = true;
+        return refbatch_collect_issue(ctx, fl[sl].q0, fl[sl].q1, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], dev.events[slot_of[sl]], wait_kernels);
+    };
     auto collect = [&](size_t sl) -> int {
         if (!fl[sl].active) return BSW_OK;
-        fl[sl].active = false;
         const double t0 = tnow();
-        const int r = refbatch_collect(ctx, fl[sl].q0, fl[sl].q1, fl[sl].n, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], dev.events[slot_of[sl]]);
+        int r = issue(sl, true);
+        fl[sl].active = false;
+        if (!r) r = refbatch_collect(ctx, fl[sl].q0, fl[sl].q1, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], dev.events[slot_of[sl]]);
         if (dbg) fprintf(stderr, "[bsw] wire: collect slot %zu batches [%zu,%zu): +%.3f .. +%.3f ms\n", sl, fl[sl].q0, fl[sl].q1, t0 - t_start, tnow() - t_start);
         return r;
     };
     auto drain = [&]() { for (size_t sl = 0; sl < NS; ++sl) if (fl[sl].active) { errs quiet; (void)sync_stream(ctx, quiet, dev.streams[slot_of[sl]], dev.events[slot_of[sl]]); fl[sl].active = false; } };
-    size_t k = 0;
+    /* the groups, in queue order */
+    struct grp_t { size_t q0, q1; };
+    std::vector<grp_t> groups;
     for (size_t q0 = 0; q0 < nq;) {
         size_t q1 = q0 + 1;
         while (q1 < nq && q1 - q0 < grp_env && ctx->ref_queue[q1].in[0] == ctx->ref_queue[q0].in[0] && ctx->ref_queue[q1].in[1] == ctx->ref_queue[q0].in[1]) ++q1;
         if (nq - q1 < grp_env / 2)                                 /* no runt group at the end of a run */
             while (q1 < nq && ctx->ref_queue[q1].in[0] == ctx->ref_queue[q0].in[0] && ctx->ref_queue[q1].in[1] == ctx->ref_queue[q0].in[1]) ++q1;
+        groups.push_back(grp_t{q0, q1});
+        q0 = q1;
+    }
+    size_t k = 0;
+    /* Big groups that all find a free slot are parsed and enqueued SIDE BY SIDE, one host thread each: a group's chain of
+     * launches cannot start before its headers are parsed (0.36 ms per 64 batches), and parsed one after the other the last
+     * group of a 128 / 256-batch queue started 0.4 / 1.2 ms after the first (profiles/r5/wire_format_timeline.txt).  Small
+     * groups (a shallow queue's 16 batches: 0.09 ms of headers) are not worth a thread start. */
+    if (groups.size() >= 2 && groups.size() <= NS && groups[0].q1 - groups[0].q0 >= 32) {
+        const size_t G = groups.size();
+        std::vector<errs> ge(G);
+        std::vector<int> grc(G, 0);
+        std::vector<size_t> gn(G, 0);
+        const int device = ctx->device0();
+        auto work = [&](size_t g, bool helper) {
+            if (helper && hipSetDevice(device) != hipSuccess) { grc[g] = fail(ge[g], BSW_E_HIP, "hipSetDevice"); return; }
+            const double te = tnow();
+            grc[g] = refbatch_enqueue(ctx, ge[g], groups[g].q0, groups[g].q1, variant, zdrop, dev.slots[slot_of[g]], dev.streams[slot_of[g]], &gn[g]);
+            if (dbg) fprintf(stderr, "[bsw] wire: enqueue slot %zu batches [%zu,%zu) %zu tasks: +%.3f .. +%.3f ms (side by side)\n", g, groups[g].q0, groups[g].q1, gn[g], te - t_start, tnow() - t_start);
+        };
+        {
+            std::vector<std::thread> th;
+            for (size_t g = 1; g < G; ++g) th.emplace_back(work, g, true);
+            work(0, false);
+            for (auto &x : th) x.join();
+        }
+        for (size_t g = 0; g < G; ++g)
+            if (grc[g] == 0 && gn[g]) { fl[g].active = true; fl[g].issued = false; fl[g].q0 = groups[g].q0; fl[g].q1 = groups[g].q1; }
+        for (size_t g = 0; g < G; ++g)
+            if (grc[g]) {                                          /* (as below: every stream that may hold work is drained first) */
+                for (size_t h = 0; h < G; ++h) { errs quiet; (void)sync_stream(ctx, quiet, dev.streams[slot_of[h]], dev.events[slot_of[h]]); fl[h].active = false; }
+                e = ge[g];
+                ctx->ref_queue.clear();
+                return grc[g];
+            }
+        k = G;
+    }
+    for (size_t g = k; g < groups.size(); ++g) {
+        const size_t q0 = groups[g].q0, q1 = groups[g].q1;
         const size_t sl = k++ % NS;
         rc = collect(sl);
         size_t n_enq = 0;
         const double te = tnow();
-        if (!rc) rc = refbatch_enqueue(ctx, q0, q1, variant, zdrop, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], &n_enq);
+        if (!rc) rc = refbatch_enqueue(ctx, e, q0, q1, variant, zdrop, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], &n_enq);
         if (dbg) fprintf(stderr, "[bsw] wire: enqueue slot %zu batches [%zu,%zu) %zu tasks: +%.3f .. +%.3f ms\n", sl, q0, q1, n_enq, te - t_start, tnow() - t_start);
         if (rc) {
             /* a failure half-way through refbatch_enqueue leaves copies out of the queued batches / kernels on this slot's
@@ -314,8 +354,12 @@ extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
             { errs quiet; (void)sync_stream(ctx, quiet, dev.streams[slot_of[sl]], dev.events[slot_of[sl]]); }
             drain(); ctx->ref_queue.clear(); return rc;
         }
-        if (n_enq) { fl[sl].active = true; fl[sl].q0 = q0; fl[sl].q1 = q1; fl[sl].n = n_enq; }
-        q0 = q1;
+        if (n_enq) { fl[sl].active = true; fl[sl].issued = false; fl[sl].q0 = q0; fl[sl].q1 = q1; }
+    }
+    /* nothing follows: every group's result DMA is queued behind its kernels now, no host round trip in between */
+    for (size_t sl = 0; sl < NS; ++sl) {
+        rc = issue((k + sl) % NS, false);
+        if (rc) { drain(); ctx->ref_queue.clear(); return rc; }
     }
     for (size_t sl = 0; sl < NS; ++sl) {
         const size_t s2 = (k + sl) % NS;                                  /* oldest first */

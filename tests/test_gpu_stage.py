@@ -438,9 +438,10 @@ def test_bsw_bench_cli(host, oracle, devflag):
 
 
 def test_deep_wire_queue_runs_in_groups_of_64(host, oracle):
-    """A queue of >= 96 task batches is cut into groups of 64 (52 k seeds: the two-seeds-per-lane kernels, two groups in
-    flight) instead of 16 (the general kernel): the same result batches either way, batch by batch, against the oracle —
-    including a last group that takes the queue's remainder (100 batches: 64 + 36) and a header change inside the queue."""
+    """A queue of >= 96 task batches is cut into groups of >= 64 (52 k seeds: the two-seeds-per-lane kernels, two groups in
+    flight, enqueued side by side) instead of 16 (the general kernel): the same result batches either way, batch by batch,
+    against the oracle — including a last group that takes the queue's remainder (100 batches: 64 + 33 + 3) and a header change
+    inside the queue.  The result batches are written on the device: everything behind a batch's last record is zero."""
     pa, pb = host.default_params(zdrop=0), host.default_params(zdrop=0, o_del=5, o_ins=5, w=60)
     tasks, arena = host.synth_tasks(100 * 819, seed=77, **MIXED)
     ins, outs, meta, lo, k = [], [], [], 0, 0
@@ -454,12 +455,29 @@ def test_deep_wire_queue_runs_in_groups_of_64(host, oracle):
         for a, b in zip(ins, outs):
             c.refbatch_submit(a, b)
         assert c.refbatch_wait(0, 0) == len(ins)
-    for (l0, n, p), o in zip(meta, outs):
-        want = (wb if p is pb else wa)[l0:l0 + n]
-        got = host.refbatch_decode_results(o, n)
-        for f in FIELDS:
-            assert (got[f] == want[f]).all(), (l0, f)
-        assert (o[5 * n:] == 0).all()
+        for (l0, n, p), o in zip(meta, outs):
+            want = (wb if p is pb else wa)[l0:l0 + n]
+            got = host.refbatch_decode_results(o, n)
+            for f in FIELDS:
+                assert (got[f] == want[f]).all(), (l0, f)
+            assert (o[5 * n:] == 0).all()
+        # the big groups of a deep queue are parsed and enqueued side by side on host threads: a malformed batch in the SECOND
+        # group (a helper thread's) is the call's error, nothing stays in flight, and the context keeps working
+        bad = ins[80].copy()
+        bad[8 + 2] = 0x7fffffff
+        for i, (a, b) in enumerate(zip(ins, outs)):
+            c.refbatch_submit(bad if i == 80 else a, b)
+        with pytest.raises(host.BswError, match="malformed task batch"):
+            c.refbatch_wait(0, 0)
+        assert c.refbatch_wait() == 0
+        for o in outs:
+            o[:] = 0xdeadbeef
+        for a, b in zip(ins, outs):
+            c.refbatch_submit(a, b)
+        assert c.refbatch_wait(0, 0) == len(ins)
+        for (l0, n, p), o in zip(meta, outs):
+            got = host.refbatch_decode_results(o, n)
+            assert (got["score"] == (wb if p is pb else wa)[l0:l0 + n]["score"]).all() and (o[5 * n:] == 0).all()
 
 
 def test_registered_task_batches_are_dmad_where_they_are(host, oracle):
