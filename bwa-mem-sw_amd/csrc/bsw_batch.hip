@@ -95,6 +95,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0;
     uint8_t dep[BSW_MAX_LANE_CLASSES] = {0};
     uint64_t lane_work[BSW_MAX_LANE_CLASSES] = {0};          /* sum of query lengths per lane class (narrow_fold) */
+    int h0_lo = INT_MAX, h0_hi = 0;                          /* h0 range of the left sides that go to lane classes (bsw_h0_bucket) */
     auto span = [&](const uint8_t *s, int len) {
         if (len > 0) { if (s < lo) lo = s; if (s + len > hi) hi = s + len; }
     };
@@ -209,6 +210,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
                 if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i);
                 ++cl[c];
                 lane_work[c] += (uint64_t)t.lqlen;
+                h0_lo = std::min(h0_lo, t.h0); h0_hi = std::max(h0_hi, t.h0);
             }
             if (t.rqlen) {
                 const int c = bsw_side_lane_class(&bp, bits, t.rqlen);
@@ -233,6 +235,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         memset(cr, 0, sizeof(cr));
         n_lane = 0;
     }
+    if (bp.lane_on && h0_hi >= h0_lo) bsw_set_h0_buckets(&bp, h0_lo, h0_hi);
     batch_plan &pl = ci.plan;
     pl = batch_plan();
     for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) pl.wave_start[c + 1] = pl.wave_start[c] + cw[c];
@@ -641,8 +644,8 @@ extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, si
     plan_segments(ci.plan, seg);
     if (order) {
         /* the device's rules (bsw_bin_count/scan/scatter) replayed on the host: lists by class, lane sides by
-         * (class, query with / without an N, query length descending); the order inside one query length is task
-         * order here, arbitrary there */
+         * (class, query with / without an N, query length descending, left sides: h0 bucket ascending); the order inside one
+         * bin is task order here, arbitrary there */
         const bsw_binparams &bp = ci.bp;
         std::vector<uint32_t> cur(BSW_BIN_WORDS, 0), hist(BSW_BIN_WAVE0, 0);
         auto has_n = [](const uint8_t *q, int len) {
@@ -656,8 +659,8 @@ extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, si
             const int bits = bsw_seed_lane_bits(&bp, T.lqlen, T.rqlen, T.h0);
             if (!bits) { k0 = BSW_BIN_WAVE0 + bsw_wave_class_of(&bp, std::max(T.lqlen, T.rqlen)); return; }
             k0 = BSW_BIN_LANEALL;
-            if (T.lqlen) k1 = BSW_BIN_SIDE(0, bsw_side_lane_class(&bp, bits, T.lqlen), has_n(tasks[i].lquery, T.lqlen), T.lqlen);
-            if (T.rqlen) k2 = BSW_BIN_SIDE(1, bsw_side_lane_class(&bp, bits, T.rqlen), has_n(tasks[i].rquery, T.rqlen), T.rqlen);
+            if (T.lqlen) k1 = BSW_BIN_L(bits == 16, has_n(tasks[i].lquery, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
+            if (T.rqlen) k2 = BSW_BIN_R(bits == 16, has_n(tasks[i].rquery, T.rqlen), T.rqlen);
         };
         for (size_t i = 0; i < n; ++i) {
             int k0, k1, k2;
@@ -668,11 +671,15 @@ extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, si
         for (int side = 0; side < 2; ++side)
             for (int c = 0; c < bp.n_lane; ++c) {
                 uint32_t run = side ? bp.laneR_off[c] : bp.laneL_off[c];
+                const int bits = bp.lane_bits[c], b16 = bits == 16;
                 for (int hn = 1; hn >= 0; --hn)
                     for (int q = BSW_LANE_QBINS - 1; q >= 0; --q) {
-                        const size_t idx = (size_t)BSW_BIN_SIDE(side, c, hn, q);
-                        cur[idx] = run;
-                        run += hist[idx];
+                        if (bsw_side_lane_class(&bp, bits, q) != c) continue;
+                        for (int hb = 0; hb < (side ? 1 : BSW_H0_BUCKETS); ++hb) {
+                            const size_t idx = (size_t)(side ? BSW_BIN_R(b16, hn, q) : BSW_BIN_L(b16, hn, hb, q));
+                            cur[idx] = run;
+                            run += hist[idx];
+                        }
                     }
             }
         for (int c = 0; c < bp.n_wave; ++c) cur[(size_t)(BSW_BIN_WAVE0 + c)] = bp.wave_start[c];

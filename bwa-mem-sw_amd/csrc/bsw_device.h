@@ -93,7 +93,30 @@ typedef struct bsw_binparams {
     uint32_t wave_start[BSW_MAX_WAVE_CLASSES + 1];
     uint32_t lane_all_off;
     uint32_t laneL_off[BSW_MAX_LANE_CLASSES + 1], laneR_off[BSW_MAX_LANE_CLASSES + 1];
+    /* second sort key of the LEFT sides inside a query length: the seed's h0 in BSW_H0_BUCKETS buckets over the chunk's range
+     * [hb_lo, ...], bucket = ((h0 - hb_lo) * hb_mul) >> 16 (hb_mul = 0: one bucket) */
+    int32_t hb_lo, hb_mul;
 } bsw_binparams;
+
+/* The lanes of a wave walk their rows in lockstep over the UNION of their [beg, end) ranges, and h0 sets how fast a seed's
+ * range opens (end ~ 2 i + h0 - o) and where its beg runs later: seeds of one query length but h0 = 19 .. 60 spread their range ends
+ * over five 8-column blocks.  (A right side's h0 is the left side's score ~ h0 + lqlen = read length - rqlen: the same for
+ * every seed of its query-length bin already.)  PE mixed bins, 1 M seeds, handed over sorted by h0 — the bins fill in arrival order —
+ * ran 2 480 -> 2 542 GCUPS (profiles/r5/h0_second_sort_key.txt). */
+#define BSW_H0_BUCKETS 8
+BSW_HD int bsw_h0_bucket(const bsw_binparams *bp, int h0)
+{
+    int64_t d = (int64_t)h0 - bp->hb_lo;
+    if (d < 0) d = 0;
+    d = (d * bp->hb_mul) >> 16;
+    return d >= BSW_H0_BUCKETS ? BSW_H0_BUCKETS - 1 : (int)d;
+}
+/* hb_lo / hb_mul for a chunk whose left sides have h0 in [lo, hi] */
+BSW_HD void bsw_set_h0_buckets(bsw_binparams *bp, int lo, int hi)
+{
+    bp->hb_lo = lo;
+    bp->hb_mul = hi > lo ? (int32_t)(((int64_t)BSW_H0_BUCKETS << 16) / ((int64_t)hi - lo + 1)) : 0;
+}
 
 /* value width of the lane kernel a seed may use: 0 = wave-per-task kernel */
 BSW_HD int bsw_seed_lane_bits(const bsw_binparams *bp, int lqlen, int rqlen, int h0)

@@ -5,10 +5,15 @@
 #include <hip/hip_runtime.h>
 #include "bsw_device.h"
 
-/* layout of the `bins` scratch array (uint32): per (side, lane class, query holds an N, query length) histogram -> cursor,
- * then one cursor per wave class list, then the cursor of the list of all lane seeds */
-#define BSW_BIN_SIDE(side, cls, has_n, q) ((((side) * BSW_MAX_LANE_CLASSES + (cls)) * 2 + (has_n)) * BSW_LANE_QBINS + (q))
-#define BSW_BIN_WAVE0   (2 * BSW_MAX_LANE_CLASSES * 2 * BSW_LANE_QBINS)
+/* layout of the `bins` scratch array (uint32): histogram -> cursor per
+ *   left sides : (16-bit class?, query holds an N, h0 bucket, query length)
+ *   right sides: (16-bit class?, query holds an N, query length)
+ * (the lane class of a side follows from its width and query length: bsw_side_lane_class), then one cursor per wave class list,
+ * then the cursor of the list of all lane seeds */
+#define BSW_BIN_L(b16, has_n, hb, q) (((((b16) * 2 + (has_n)) * BSW_H0_BUCKETS + (hb)) * BSW_LANE_QBINS) + (q))
+#define BSW_BIN_R0      (2 * 2 * BSW_H0_BUCKETS * BSW_LANE_QBINS)
+#define BSW_BIN_R(b16, has_n, q) (BSW_BIN_R0 + ((b16) * 2 + (has_n)) * BSW_LANE_QBINS + (q))
+#define BSW_BIN_WAVE0   (BSW_BIN_R0 + 2 * 2 * BSW_LANE_QBINS)
 #define BSW_BIN_LANEALL (BSW_BIN_WAVE0 + BSW_MAX_WAVE_CLASSES)
 #define BSW_BIN_WORDS   (BSW_BIN_LANEALL + 8)
 

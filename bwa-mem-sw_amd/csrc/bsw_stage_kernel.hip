@@ -166,8 +166,6 @@ __global__ __launch_bounds__(256) void bsw_pack_kernel(const uint8_t *__restrict
 }
 
 /* ---- binning ---- */
-__device__ __forceinline__ int bin_side(int side, int cls, int has_n, int q) { return BSW_BIN_SIDE(side, cls, has_n, q); }
-
 /* does the packed sequence (16 bases per word, N = 4) hold an N?  (bases past `len` in the last word are not looked at) */
 __device__ __forceinline__ int packed_has_n(const uint64_t *__restrict__ seq, const uint32_t off, const int len)
 {
@@ -193,8 +191,8 @@ __device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const ui
         s.k0 = BSW_BIN_WAVE0 + (c < 0 ? 0 : c);     /* c < 0 cannot happen: the host rejects such seeds */
     } else {
         s.k0 = BSW_BIN_LANEALL;
-        if (T.lqlen) s.k1 = bin_side(0, bsw_side_lane_class(&bp, bits, T.lqlen), packed_has_n(seq, T.lq_off, T.lqlen), T.lqlen);
-        if (T.rqlen) s.k2 = bin_side(1, bsw_side_lane_class(&bp, bits, T.rqlen), packed_has_n(seq, T.rq_off, T.rqlen), T.rqlen);
+        if (T.lqlen) s.k1 = BSW_BIN_L(bits == 16, packed_has_n(seq, T.lq_off, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
+        if (T.rqlen) s.k2 = BSW_BIN_R(bits == 16, packed_has_n(seq, T.rq_off, T.rqlen), T.rqlen);
     }
     return s;
 }
@@ -215,9 +213,10 @@ __global__ __launch_bounds__(256) void bsw_bin_count(const bsw_binparams bp, con
         if (h[b]) atomicAdd(&bins[b], h[b]);
 }
 
-/* one block: per (side, lane class) turn the two query-length histograms into start offsets — the queries with an N,
- * longest first, then the ones without (a wave then holds equal-length queries and the most work starts first: a list
- * that ENDED with the long N queries left a few long waves running alone, 1 743 -> 1 339 GCUPS on the 250 bp workload) */
+/* one block: per (side, lane class) turn the histograms into start offsets — the queries with an N, longest first, then the
+ * ones without (a wave then holds equal-length queries and the most work starts first: a list that ENDED with the long N
+ * queries left a few long waves running alone, 1 743 -> 1 339 GCUPS on the 250 bp workload); inside a query length the left
+ * sides go by h0 bucket */
 __global__ __launch_bounds__(256) void bsw_bin_scan(const bsw_binparams bp, uint32_t *__restrict__ bins)
 {
     __shared__ uint32_t sc[256];
@@ -225,9 +224,16 @@ __global__ __launch_bounds__(256) void bsw_bin_scan(const bsw_binparams bp, uint
     for (int side = 0; side < 2; ++side)
         for (int c = 0; c < bp.n_lane; ++c) {
             uint32_t base = side ? bp.laneR_off[c] : bp.laneL_off[c];
+            const int bits = bp.lane_bits[c], b16 = bits == 16;
+            const bool mine = bsw_side_lane_class(&bp, bits, q) == c;     /* (a folded class has no query length of its own) */
             for (int hn = 1; hn >= 0; --hn) {
-                const int idx = bin_side(side, c, hn, q);
-                const uint32_t v = bins[idx];
+                uint32_t part[BSW_H0_BUCKETS], v = 0;
+                const int nb = side ? 1 : BSW_H0_BUCKETS;
+#pragma unroll
+                for (int hb = 0; hb < BSW_H0_BUCKETS; ++hb) {
+                    part[hb] = (mine && hb < nb) ? bins[side ? BSW_BIN_R(b16, hn, q) : BSW_BIN_L(b16, hn, hb, q)] : 0u;
+                    v += part[hb];
+                }
                 sc[t] = v;
                 __syncthreads();
                 for (int d = 1; d < 256; d <<= 1) {
@@ -236,7 +242,12 @@ __global__ __launch_bounds__(256) void bsw_bin_scan(const bsw_binparams bp, uint
                     sc[t] += add;
                     __syncthreads();
                 }
-                bins[idx] = base + sc[t] - v;
+                uint32_t at = base + sc[t] - v;
+                if (mine) {
+#pragma unroll
+                    for (int hb = 0; hb < BSW_H0_BUCKETS; ++hb)
+                        if (hb < nb) { bins[side ? BSW_BIN_R(b16, hn, q) : BSW_BIN_L(b16, hn, hb, q)] = at; at += part[hb]; }
+                }
                 base += sc[255];
                 __syncthreads();
             }
@@ -245,31 +256,41 @@ __global__ __launch_bounds__(256) void bsw_bin_scan(const bsw_binparams bp, uint
     if (t == 0) bins[BSW_BIN_LANEALL] = bp.lane_all_off;
 }
 
+/* BSW_SCATTER_TPT tasks per thread: the two passes over the cursor table (9 232 words) are shared by 1 024 tasks */
+#define BSW_SCATTER_TPT 4
 __global__ __launch_bounds__(256) void bsw_bin_scatter(const bsw_binparams bp, const uint64_t *__restrict__ seq,
                                                        const bsw_dtask *__restrict__ tasks, const uint32_t n,
                                                        uint32_t *__restrict__ bins, uint32_t *__restrict__ order)
 {
-    __shared__ uint32_t cnt[BSW_BIN_WORDS], base[BSW_BIN_WORDS];
+    __shared__ uint32_t cnt[BSW_BIN_WORDS];               /* first the block's count per list, then — in place — its base in the list */
     for (int b = threadIdx.x; b < BSW_BIN_WORDS; b += 256) cnt[b] = 0;
     __syncthreads();
-    const uint32_t ti = blockIdx.x * 256u + threadIdx.x;
-    seed_bins s;
-    s.k0 = s.k1 = s.k2 = -1;
-    uint32_t r0 = 0, r1 = 0, r2 = 0;
-    if (ti < n) {
-        s = seed_keys(bp, seq, tasks[ti]);
-        r0 = atomicAdd(&cnt[s.k0], 1u);
-        if (s.k1 >= 0) r1 = atomicAdd(&cnt[s.k1], 1u);
-        if (s.k2 >= 0) r2 = atomicAdd(&cnt[s.k2], 1u);
+    seed_bins s[BSW_SCATTER_TPT];
+    uint32_t r0[BSW_SCATTER_TPT], r1[BSW_SCATTER_TPT], r2[BSW_SCATTER_TPT];
+#pragma unroll
+    for (int k = 0; k < BSW_SCATTER_TPT; ++k) {
+        const uint32_t ti = (blockIdx.x * BSW_SCATTER_TPT + k) * 256u + threadIdx.x;
+        s[k].k0 = s[k].k1 = s[k].k2 = -1;
+        r0[k] = r1[k] = r2[k] = 0;
+        if (ti < n) {
+            s[k] = seed_keys(bp, seq, tasks[ti]);
+            r0[k] = atomicAdd(&cnt[s[k].k0], 1u);
+            if (s[k].k1 >= 0) r1[k] = atomicAdd(&cnt[s[k].k1], 1u);
+            if (s[k].k2 >= 0) r2[k] = atomicAdd(&cnt[s[k].k2], 1u);
+        }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < BSW_BIN_WORDS; b += 256)
-        if (cnt[b]) base[b] = atomicAdd(&bins[b], cnt[b]);
+        if (cnt[b]) cnt[b] = atomicAdd(&bins[b], cnt[b]);
     __syncthreads();
-    if (ti < n) {
-        order[base[s.k0] + r0] = ti;
-        if (s.k1 >= 0) order[base[s.k1] + r1] = ti;
-        if (s.k2 >= 0) order[base[s.k2] + r2] = ti;
+#pragma unroll
+    for (int k = 0; k < BSW_SCATTER_TPT; ++k) {
+        const uint32_t ti = (blockIdx.x * BSW_SCATTER_TPT + k) * 256u + threadIdx.x;
+        if (ti < n) {
+            order[cnt[s[k].k0] + r0[k]] = ti;
+            if (s[k].k1 >= 0) order[cnt[s[k].k1] + r1[k]] = ti;
+            if (s[k].k2 >= 0) order[cnt[s[k].k2] + r2[k]] = ti;
+        }
     }
 }
 
@@ -366,10 +387,10 @@ hipError_t launch_bin(const bsw_binparams &bp, const uint64_t *seq, const bsw_dt
     if (n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(bins, 0, BSW_BIN_WORDS * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    uint32_t blocks = (n + 255u) / 256u;
+    const uint32_t blocks = (n + 255u) / 256u, sblocks = (n + 256u * BSW_SCATTER_TPT - 1u) / (256u * BSW_SCATTER_TPT);
     hipLaunchKernelGGL(bsw_bin_count, dim3(blocks > 1024u ? 1024u : blocks), dim3(256), 0, s, bp, seq, tasks, n, bins);
     hipLaunchKernelGGL(bsw_bin_scan, dim3(1), dim3(256), 0, s, bp, bins);
-    hipLaunchKernelGGL(bsw_bin_scatter, dim3(blocks), dim3(256), 0, s, bp, seq, tasks, n, bins, order);
+    hipLaunchKernelGGL(bsw_bin_scatter, dim3(sblocks), dim3(256), 0, s, bp, seq, tasks, n, bins, order);
     return hipGetLastError();
 }
 

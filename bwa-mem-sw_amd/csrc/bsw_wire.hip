@@ -81,6 +81,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0};
     uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0;
     uint64_t acc = 0;
+    int h0_lo = INT_MAX, h0_hi = 0;                /* h0 range of the left sides that go to lane classes (bsw_h0_bucket) */
     /* pass 1: where every batch's tasks and sequence words start (the batches' word counts side by side, then a prefix sum) */
     std::vector<uint64_t> wbase(nb + 1, 0), tbase(nb + 1, 0);
     /* ONE thread walks a group of up to 128 batches faster than several do (64 batches = 52 k headers: 0.36 ms on one thread,
@@ -110,7 +111,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     }
     const double t_b = dbg ? tnow() : 0;
     /* pass 2 (parallel over batches): records, class counts, and the batch itself into pinned staging */
-    struct part { uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0; int rc = 0; errs e; };
+    struct part { uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0; int h0_lo = INT_MAX, h0_hi = 0; int rc = 0; errs e; };
     std::vector<part> parts(nth);
     /* class of a side / a seed by query length, looked up instead of searched per task (wire lengths are 8-bit fields) */
     uint8_t wcls[256], lcls8[256], lcls16[256];
@@ -161,7 +162,12 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
                 ++pt.cw_all[wc];
                 const int bits = bsw_seed_lane_bits(&bp, lq, rq, h0);
                 if (!bits) ++pt.cw[wc];
-                else { const uint8_t *lc = bits == 8 ? lcls8 : lcls16; ++pt.n_lane; if (lq) ++pt.cl[lc[lq]]; if (rq) ++pt.cr[lc[rq]]; }
+                else {
+                    const uint8_t *lc = bits == 8 ? lcls8 : lcls16;
+                    ++pt.n_lane;
+                    if (lq) { ++pt.cl[lc[lq]]; pt.h0_lo = std::min(pt.h0_lo, h0); pt.h0_hi = std::max(pt.h0_hi, h0); }
+                    if (rq) ++pt.cr[lc[rq]];
+                }
                 st.h_tasks.p[ti] = d;
                 st.h_woff.p[ti] = wo;
             }
@@ -182,10 +188,12 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
         for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) { cw_all[c] += pt.cw_all[c]; cw[c] += pt.cw[c]; }
         for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { cl[c] += pt.cl[c]; cr[c] += pt.cr[c]; }
         n_lane += pt.n_lane;
+        h0_lo = std::min(h0_lo, pt.h0_lo); h0_hi = std::max(h0_hi, pt.h0_hi);
     }
     if (ctx->cfg.kernel == BSW_KERNEL_AUTO && !lane_bins_pay(n_lane, cl, cr)) bp.lane_on = 0;
     if (bp.lane_on && narrow_foldable(bp)) narrow_fold(bp, cl, cr, nullptr);     /* (wire-format groups: one launch per side) */
     if (!bp.lane_on) { memcpy(cw, cw_all, sizeof(cw)); memset(cl, 0, sizeof(cl)); memset(cr, 0, sizeof(cr)); n_lane = 0; }
+    if (bp.lane_on && h0_hi >= h0_lo) bsw_set_h0_buckets(&bp, h0_lo, h0_hi);
     batch_plan &pl = ci.plan;
     pl = batch_plan();
     for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) pl.wave_start[c + 1] = pl.wave_start[c] + cw[c];

@@ -183,6 +183,12 @@ def test_batch_plan_bins(host):
                 hn = _gen.query_has_n(tasks, arena, side)[order[seg[base + c]:seg[base + c + 1]]]
                 key = (~hn).astype(np.int64) * 1000 - q.astype(np.int64)
                 assert (np.diff(key) >= 0).all() and (q + 1 <= ncol).all()        # queries with an N first, each part longest first
+                if side == 0:                                                     # ... and inside a length the left sides by h0 bucket
+                    lane_h0 = tasks["h0"][order[seg[9]:seg[13]]].astype(np.int64)
+                    lo, hi = int(lane_h0.min()), int(lane_h0.max())
+                    mul = (8 << 16) // (hi - lo + 1) if hi > lo else 0
+                    hb = np.minimum(((t["h0"].astype(np.int64) - lo) * mul) >> 16, 7)
+                    assert (np.diff(key * 8 + hb) >= 0).all()
                 folded = c == 1 and seg[base + 1] == seg[base]                    # the 72-column class folded into the 136-column one
                 if c > 0 and lane_cols[c - 1][0] == bits and not folded:
                     assert (q + 1 > lane_cols[c - 1][1]).all()                    # ... and not in a narrower class of the same width
