@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void bsw_bin_scan(const bsw_binparams bp, uint
     for (int side = 0; side < 2; ++side)
         for (int c = 0; c < bp.n_lane; ++c) {
             uint32_t base = side ? bp.laneR_off[c] : bp.laneL_off[c];
+            if ((side ? bp.laneR_off[c + 1] : bp.laneL_off[c + 1]) == base) continue;      /* (an empty list: wave-uniform, no barrier skipped by some) */
             const int bits = bp.lane_bits[c], b16 = bits == 16;
             const bool mine = bsw_side_lane_class(&bp, bits, q) == c;     /* (a folded class has no query length of its own) */
             for (int hn = 1; hn >= 0; --hn) {
