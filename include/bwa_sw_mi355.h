@@ -303,7 +303,8 @@ void     bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b);
 /* ---- batch plan (host only, no GPU needed): how the batch manager cuts tasks[0..n) into launches.
  * The device sorts the seeds (bsw_stage_kernel.hip); the host only counts them per class, with the same
  * class functions, to size the launches.  order[] (capacity 4*n+16, may be NULL) receives a launch order
- * built on the host with the device's rules (inside one query length the device's order is arbitrary);
+ * built on the host with the device's rules (lane sides: queries with an N first, each part longest first, left
+ * sides of one length by h0 bucket — 8 buckets over the chunk's h0 range; inside one bin the device's order is arbitrary);
  * seg[] receives BSW_PLAN_SEGS+1 offsets into order[]:
  * segments 0..7 = wave-per-task classes (64,128,192,256,512,1024 columns, then 2 unused), 8 = all lane seeds,
  * 9..16 = lane left sides per lane class, 17..24 = lane right sides per lane class, 25 = redo list space.
