@@ -335,14 +335,14 @@ def cpu_list_str(cpus):
     return ",".join(out)
 
 
-def pmc_summary(workload, tasks):
+def pmc_summary(workload, tasks, key=None):
     """(counters, source) of the committed rocprofv3 PMC passes of this same command (profiles/pmc_latest.json).  The counters
     come from an EARLIER run of this command under rocprofv3 --pmc, not from the run that prints them: they are quoted only
     when the file was collected on the same workload AND the same kernel sources as this tree; otherwise ({}, why)."""
     src = {"file": "profiles/pmc_latest.json", "collected": "earlier rocprofv3 --pmc passes of this command (tools/profile.sh), not this run"}
     try:
         j = json.load(open(PMC_FILE))
-        j = j if "workload" in j else j.get(workload, {})        # one entry per workload (round 4: a single entry)
+        j = j if "workload" in j else (j.get(key) or j.get(workload, {}))        # one entry per workload (round 4: a single entry); key: a pass at another batch size
     except Exception:
         return {}, dict(src, status="absent")
     src["source_hash"] = j.get("source_hash")
@@ -1001,7 +1001,7 @@ def pe_mixed_leg(host, ctx, args, cpu_affinity, n_seeds, steps=3):
         b.free()
     ms = float(np.mean(step_ms))
     gc = cells / (ms * 1e-3) / 1e9
-    pmc, pmc_src = pmc_summary(wl, None)
+    pmc, pmc_src = pmc_summary(wl, None, key=wl + "@4194304")      # the pass on one 32 x 128 Ki-seed resident batch (tools/profile_r5.sh), else the 1 M-seed one
     tops = cells * VALU_OPS_PER_CELL / (ms * 1e-3) / 1e12
     return {"workload": wl, "config": "BASELINE.json configs[2] shape: %d PE seeds (left + right extension each), mixed bins via the batch manager" % n_seeds,
             "seeds": n_seeds, "extensions": sides, "resident_batches": len(batches), "gcups": round(gc, 1), "ms_per_step": round(ms, 3),
@@ -1011,8 +1011,10 @@ def pe_mixed_leg(host, ctx, args, cpu_affinity, n_seeds, steps=3):
                          "unit": "T lane-ops/s", "frac": round(tops / PEAK_VALU_TOPS, 5),
                          "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"), "valu_issue_busy": pmc.get("valu_issue_busy"),
                          "waves_per_simd_avg": pmc.get("waves_per_simd_avg"),
-                         "traffic_per_1M_seed_step": (int((2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in pmc else None),
-                         "counters_source": dict(pmc_src, note="collected on the 1 M-seed instance of this workload (bench.py --workload %s)" % wl)}}
+                         "traffic_per_counted_step": (int((2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in pmc else None),
+                         "counters_source": dict(pmc_src, note="collected on a %d-seed resident batch of this workload (bench.py --workload %s --tasks %d)%s"
+                                                 % (pmc.get("seeds_per_gpu", 0), wl, pmc.get("seeds_per_gpu", 0),
+                                                    ": the size of this leg's batches (32 x 128 Ki seeds)" if pmc.get("seeds_per_gpu") == 4194304 else ""))}}
 
 
 def harena_used(tasks):

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p profiles/r5
-for w in head mixed w250 c72 wave quad; do
+for w in head mixed w250 mixed4m c72 wave quad; do
     d=gpurun_out/r5prof/$w
     [ -d $d ] || continue
     ks=$(ls -t $d/trace/*/*_kernel_stats.csv | head -1)
@@ -15,3 +15,4 @@ cells() { python3 -c "import json,sys; print(int(json.loads(open(sys.argv[1]).re
 python3 tools/make_pmc_latest.py gpurun_out/r5prof/head/summary.json 150bp_w100_single_bin 1000000 $(cells gpurun_out/r5prof/head/bench_trace.json)
 python3 tools/make_pmc_latest.py gpurun_out/r5prof/mixed/summary.json 150bp_w100_mixed_bins 1000000 $(cells gpurun_out/r5prof/mixed/bench_trace.json)
 python3 tools/make_pmc_latest.py gpurun_out/r5prof/w250/summary.json 250bp_w500 1000000 $(cells gpurun_out/r5prof/w250/bench_trace.json)
+[ -d gpurun_out/r5prof/mixed4m ] && python3 tools/make_pmc_latest.py gpurun_out/r5prof/mixed4m/summary.json 150bp_w100_mixed_bins 4194304 $(cells gpurun_out/r5prof/mixed4m/bench_trace.json) 4 150bp_w100_mixed_bins@4194304

@@ -4,7 +4,7 @@ tools/profile.sh / tools/profile_quick.sh output directory (separate rocprofv3 -
 MI355X_MICROARCH.md's gfx950 correction: FETCH_SIZE (KiB) x 2 + WRITE_SIZE (KiB), summed over the DP kernels of one bsw_run
 step.  A step may launch the dominant kernel more than once (PE workloads: left sides, right sides): pmc_summary.py's values
 are means per launch, so they are scaled by launches per step = calls / steps profiled.
-Usage: make_pmc_latest.py <dir | summary.json> <workload> <seeds> <cells per step> [steps profiled = 4]"""
+Usage: make_pmc_latest.py <dir | summary.json> <workload> <seeds> <cells per step> [steps profiled = 4] [key in the file = workload]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = sys.argv[1]
@@ -38,6 +38,6 @@ try:
         allw = {allw["workload"]: allw}
 except Exception:
     allw = {}
-allw[workload] = out
+allw[sys.argv[6] if len(sys.argv) > 6 else workload] = out
 json.dump(allw, open(path, "w"), indent=1)
 print(json.dumps(out))

@@ -13,6 +13,9 @@ TRAFFIC=1 tools/profile_quick.sh r5prof/mixed --workload 150bp_w100_mixed_bins >
 echo mixed done
 TRAFFIC=1 tools/profile_quick.sh r5prof/w250 --workload 250bp_w500 > /dev/null
 echo w250 done
+# the PE leg's batch size (bench.py pe_mixed_bins: resident batches of 32 x 128 Ki seeds)
+TRAFFIC=1 tools/profile_quick.sh r5prof/mixed4m --workload 150bp_w100_mixed_bins --tasks 4194304 > /dev/null
+echo mixed4m done
 if [ -z "$QUICK" ]; then
 tools/profile_quick.sh r5prof/c72 --spec seed_len_min=79 --spec seed_len_max=79 > /dev/null
 BSW_QUAD=0 tools/profile_quick.sh r5prof/wave --kernel 1 --tasks 131072 > /dev/null
