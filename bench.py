@@ -93,9 +93,11 @@ def side_paths(host, device):
         # pinned workspace (batch_manager.v:745-773): the library DMAs them where they are
         warena = host.HostArena(NB * host.REFBATCH_IN_WORDS * 4)
         wview = warena.view(np.uint32, NB * host.REFBATCH_IN_WORDS).reshape(NB, host.REFBATCH_IN_WORDS)
+        oarena = host.HostArena(NB * host.REFBATCH_OUT_WORDS * 4)         # ... and the result batches go back into registered memory (rbb.v:150-166)
+        oview = oarena.view(np.uint32, NB * host.REFBATCH_OUT_WORDS).reshape(NB, host.REFBATCH_OUT_WORDS)
         ins, outs, ends, lo = [], [], [], 0
         while lo < len(wt) and len(ins) < NB:
-            w, k = host.refbatch_encode(pz, wt[lo:lo + 819]); wview[len(ins)] = w; ins.append(wview[len(ins)]); outs.append(np.zeros(host.REFBATCH_OUT_WORDS, np.uint32)); lo += k; ends.append(lo)
+            w, k = host.refbatch_encode(pz, wt[lo:lo + 819]); wview[len(ins)] = w; ins.append(wview[len(ins)]); outs.append(oview[len(outs)]); lo += k; ends.append(lo)
         rate = {}
         for nb in (128, len(ins)):
             best = 1e9
@@ -107,7 +109,13 @@ def side_paths(host, device):
                 best = min(best, time.perf_counter() - t0)
             rate[nb] = round(ends[nb - 1] / best)
         res["wire_format"] = {"seeds_per_s": rate[128], "batches_in_flight": 128, "seeds_per_s_256_in_flight": rate[len(ins)],
-                              "task_batches_in": "registered host memory (DMA'd where they are)", "result_batches": "written on the device"}
+                              "task_batches_in": "registered host memory (DMA'd where they are)", "result_batches": "written on the device, DMA'd into registered host memory"}
+        # (a spot check that the direct path delivers: the first and the last result batch decode to the tags that went in)
+        for bi in (0, len(ins) - 1):
+            n_b = ends[bi] - (ends[bi - 1] if bi else 0)
+            got = host.refbatch_decode_results(outs[bi], n_b)
+            assert (got["tag"] == wt["tag"][ends[bi] - n_b:ends[bi]]).all(), "wire format: result batch %d does not carry its tasks' tags" % bi
+        oarena.free()
         warena.free()
     arena.free()
     return res

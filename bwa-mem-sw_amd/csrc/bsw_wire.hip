@@ -235,27 +235,49 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     return BSW_OK;
 }
 
+/* do the group's result batches all lie in memory the GPU can DMA into (bsw_host_alloc / bsw_host_register)? */
+static bool outs_registered(bsw_ctx *ctx, size_t q0, size_t q1)
+{
+    for (size_t q = q0; q < q1; ++q)
+        if (!is_registered(ctx->ref_queue[q].out, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t))) return false;
+    return true;
+}
+
 /* queue the DMA of an enqueued group's result batches behind its kernels (wait_kernels: only once they are done, for a
- * group that other groups' input copies still follow) */
-static int refbatch_collect_issue(bsw_ctx *ctx, size_t q0, size_t q1, stage_t &st, hipStream_t s, hipEvent_t ev, bool wait_kernels)
+ * group that other groups' input copies still follow).  Result batches in registered memory are written where they are
+ * (one DMA per run that lies back to back) — the reference's manager writes its RBBs into the host's workspace itself
+ * (rbb.v:150-166) —, others go through pinned staging and are copied out by refbatch_collect.  *direct_out says which. */
+static int refbatch_collect_issue(bsw_ctx *ctx, size_t q0, size_t q1, stage_t &st, hipStream_t s, hipEvent_t ev, bool wait_kernels, bool *direct_out)
 {
     errs &e = ctx->err;
     if (wait_kernels) {
         const int rc0 = sync_stream(ctx, e, s, ev);
         if (rc0) return rc0;
     }
-    HIPCHK(e, hipMemcpyAsync(st.h_wout.p, st.d_wout.p, (q1 - q0) * (size_t)BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    const size_t bw = (size_t)BSW_REFBATCH_OUT_WORDS;
+    *direct_out = outs_registered(ctx, q0, q1);
+    if (!*direct_out) {
+        HIPCHK(e, hipMemcpyAsync(st.h_wout.p, st.d_wout.p, (q1 - q0) * bw * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        return BSW_OK;
+    }
+    for (size_t q = q0; q < q1;) {
+        size_t r1 = q + 1;
+        while (r1 < q1 && ctx->ref_queue[r1].out == ctx->ref_queue[r1 - 1].out + bw) ++r1;
+        HIPCHK(e, hipMemcpyAsync(ctx->ref_queue[q].out, st.d_wout.p + (q - q0) * bw, (r1 - q) * bw * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        q = r1;
+    }
     return BSW_OK;
 }
 
 /* wait for a group's result batches and hand them to the caller's buffers */
-static int refbatch_collect(bsw_ctx *ctx, size_t q0, size_t q1, stage_t &st, hipStream_t s, hipEvent_t ev)
+static int refbatch_collect(bsw_ctx *ctx, size_t q0, size_t q1, stage_t &st, hipStream_t s, hipEvent_t ev, bool direct_out)
 {
     errs &e = ctx->err;
     const int rc = sync_stream(ctx, e, s, ev);
     if (rc) return rc;
-    for (size_t q = q0; q < q1; ++q)
-        memcpy(ctx->ref_queue[q].out, st.h_wout.p + (q - q0) * (size_t)BSW_REFBATCH_OUT_WORDS, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
+    if (!direct_out)
+        for (size_t q = q0; q < q1; ++q)
+            memcpy(ctx->ref_queue[q].out, st.h_wout.p + (q - q0) * (size_t)BSW_REFBATCH_OUT_WORDS, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
     return BSW_OK;
 }
 
@@ -284,21 +306,21 @@ extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
     const size_t grp_env = grp_tune ? grp_tune : (nq >= 96 ? std::max<size_t>(REFBATCH_GROUP_DEEP, (nq + 1) / 2) : (size_t)REFBATCH_GROUP);
     const size_t NS = std::max<size_t>(1, std::min<size_t>(REFBATCH_SLOTS, dev.slots.size()));
     const size_t slot_of[REFBATCH_SLOTS] = {0, 1, 2, 3};
-    struct flight { bool active = false, issued = false; size_t q0 = 0, q1 = 0; } fl[REFBATCH_SLOTS];
+    struct flight { bool active = false, issued = false, direct_out = false; size_t q0 = 0, q1 = 0; } fl[REFBATCH_SLOTS];
     static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = tnow();
     auto issue = [&](size_t sl, bool wait_kernels) -> int {
         if (!fl[sl].active || fl[sl].issued) return BSW_OK;
         fl[sl].issued = true;
-        return refbatch_collect_issue(ctx, fl[sl].q0, fl[sl].q1, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], dev.events[slot_of[sl]], wait_kernels);
+        return refbatch_collect_issue(ctx, fl[sl].q0, fl[sl].q1, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], dev.events[slot_of[sl]], wait_kernels, &fl[sl].direct_out);
     };
     auto collect = [&](size_t sl) -> int {
         if (!fl[sl].active) return BSW_OK;
         const double t0 = tnow();
         int r = issue(sl, true);
         fl[sl].active = false;
-        if (!r) r = refbatch_collect(ctx, fl[sl].q0, fl[sl].q1, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], dev.events[slot_of[sl]]);
+        if (!r) r = refbatch_collect(ctx, fl[sl].q0, fl[sl].q1, dev.slots[slot_of[sl]], dev.streams[slot_of[sl]], dev.events[slot_of[sl]], fl[sl].direct_out);
         if (dbg) fprintf(stderr, "[bsw] wire: collect slot %zu batches [%zu,%zu): +%.3f .. +%.3f ms\n", sl, fl[sl].q0, fl[sl].q1, t0 - t_start, tnow() - t_start);
         return r;
     };

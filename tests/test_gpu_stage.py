@@ -493,18 +493,23 @@ def test_deep_wire_queue_runs_in_groups_of_64(host, oracle):
 def test_registered_task_batches_are_dmad_where_they_are(host, oracle):
     """Task batches in memory from bsw_host_alloc skip the copy into pinned staging: one DMA per run of batches that lie back
     to back (here: 20 contiguous ones, then 10 with gaps between them), mixed with a pageable batch in the same group (the whole
-    group then takes the staging path).  Same result batches as the oracle either way."""
+    group then takes the staging path).  Result batches in such memory are DMA'd where they are as well (a group whose result
+    batches are not ALL registered goes through pinned staging).  Same result batches as the oracle either way."""
     p = host.default_params(zdrop=0)
     tasks, arena = host.synth_tasks(31 * 819, seed=88, **MIXED)
     W = host.REFBATCH_IN_WORDS
     ar = host.HostArena(45 * W * 4)
     view = ar.view(np.uint32, 45 * W).reshape(45, W)
     slots = list(range(20)) + list(range(21, 41, 2))                    # 20 back to back, 10 every other slot
+    # the result batches of the first 25 likewise (back to back, then every other slot): written where they are; the rest pageable
+    OW = host.REFBATCH_OUT_WORDS
+    oar = host.HostArena(45 * OW * 4)
+    oview = oar.view(np.uint32, 45 * OW).reshape(45, OW)
     ins, outs, meta, lo = [], [], [], 0
-    for sl in slots:
+    for k, sl in enumerate(slots):
         words, n = host.refbatch_encode(p, tasks[lo:lo + 819])
         view[sl] = words
-        ins.append(view[sl]); outs.append(np.zeros(host.REFBATCH_OUT_WORDS, np.uint32)); meta.append((lo, n)); lo += n
+        ins.append(view[sl]); outs.append(oview[sl] if k < 25 else np.zeros(OW, np.uint32)); meta.append((lo, n)); lo += n
     want = oracle.pair_batch(p, tasks[:lo], nthreads=8)
     with host.BswContext(device=0) as c:
         for rep in range(2):
@@ -523,8 +528,9 @@ def test_registered_task_batches_are_dmad_where_they_are(host, oracle):
                 got = host.refbatch_decode_results(o, n)
                 for f in FIELDS:
                     assert (got[f] == want[l0:l0 + n][f]).all(), (rep, l0, f)
+                assert (o[5 * n:] == 0).all()
             for a, b, (l0, n) in extra:
                 got = host.refbatch_decode_results(b, n)
                 w2 = oracle.pair_batch(p, tasks[l0:l0 + n], nthreads=8)
                 assert (got["score"] == w2["score"]).all() and (got["truesc"] == w2["truesc"]).all()
-    ar.free()
+    ar.free(); oar.free()

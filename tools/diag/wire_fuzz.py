@@ -17,6 +17,9 @@ W = host.REFBATCH_IN_WORDS
 pool, arena = host.synth_tasks(256 * 819, seed=4242, seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.08, n_rate=0.001, indel_rate=0.01)
 reg = host.HostArena(2 * 256 * W * 4)
 rview = reg.view(np.uint32, 2 * 256 * W).reshape(2 * 256, W)
+OW = host.REFBATCH_OUT_WORDS
+oreg = host.HostArena(3 * 256 * OW * 4)                      # result batches in registered memory: DMA'd where they are
+oview = oreg.view(np.uint32, 3 * 256 * OW).reshape(3 * 256, OW)   # slots 0..255 back to back, 256.. every other one
 tot = nb_tot = 0
 with host.BswContext(device=0) as c:
     for r in range(rounds):
@@ -43,7 +46,12 @@ with host.BswContext(device=0) as c:
             if where.startswith("registered"):
                 slot = 2 * k if where == "registered_gaps" else k
                 rview[slot] = words; words = rview[slot]
-            ins.append(words); outs.append(np.full(host.REFBATCH_OUT_WORDS, 0xdeadbeef, np.uint32)); meta.append((lo, n, p)); lo += n
+            omem = str(rng.choice(["pageable", "registered", "registered_gaps"])) if k == 0 or rng.random() < 0.1 else omem
+            if omem == "pageable":
+                o = np.full(host.REFBATCH_OUT_WORDS, 0xdeadbeef, np.uint32)
+            else:
+                o = oview[256 + 2 * k if omem == "registered_gaps" else k]; o[:] = 0xdeadbeef
+            ins.append(words); outs.append(o); meta.append((lo, n, p)); lo += n
         for a, b in zip(ins, outs):
             c.refbatch_submit(a, b)
         assert c.refbatch_wait(variant, 0) == depth

@@ -13,12 +13,14 @@ tasks, arena = host.synth_tasks(nb * 819, seed=51, seed_len_min=19, seed_len_max
 reg = len(sys.argv) > 3 and sys.argv[3] == "registered"          # the task batches back to back in registered host memory (DMA'd where they are)
 warena = host.HostArena(nb * host.REFBATCH_IN_WORDS * 4) if reg else None
 wview = warena.view(np.uint32, nb * host.REFBATCH_IN_WORDS).reshape(nb, host.REFBATCH_IN_WORDS) if reg else None
+oarena = host.HostArena(nb * host.REFBATCH_OUT_WORDS * 4) if reg else None      # registered: the result batches too
+oview = oarena.view(np.uint32, nb * host.REFBATCH_OUT_WORDS).reshape(nb, host.REFBATCH_OUT_WORDS) if reg else None
 ins, outs, lo = [], [], 0
 while lo < len(tasks) and len(ins) < nb:
     w, n = host.refbatch_encode(p, tasks[lo:lo + 819])
     if reg:
         wview[len(ins)] = w; w = wview[len(ins)]
-    ins.append(w); outs.append(np.zeros(host.REFBATCH_OUT_WORDS, np.uint32)); lo += n
+    ins.append(w); outs.append(oview[len(outs)] if reg else np.zeros(host.REFBATCH_OUT_WORDS, np.uint32)); lo += n
 kern = int(os.environ.get("WIRE_KERNEL", "0"))                    # 2: lane bins forced whatever the group size
 with host.BswContext(device=0, pack_threads=pt, kernel=kern) as c:
     ts = []
