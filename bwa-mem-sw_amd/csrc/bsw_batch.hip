@@ -701,13 +701,15 @@ extern "C" void bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b)
     if (!b) return;
     if (ctx) (void)hipSetDevice(ctx->device0());
     b->st.release();
+    delete b->ci;
     delete b;
 }
 
 static void fill_refx(const bsw_ref_task *rt, size_t n, bsw_refx *x);
 
 static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out,
-                         const bsw_ref *ref /* NULL: targets come from the host */, const bsw_ref_task *rtasks, bool packed = false)
+                         const bsw_ref *ref /* NULL: targets come from the host */, const bsw_ref_task *rtasks, bool packed = false,
+                         bool keep_raw = false)
 {
     *out = nullptr;
     errs &e = ctx->err;
@@ -742,7 +744,13 @@ static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *task
     if (!rc) rc = sync_stream(ctx, e, s, ctx->devs[0].events[0]);
     if (rc) { bsw_free_batch(ctx, b); return rc; }
     st.release_host();
-    st.release_transient_dev();
+    if (keep_raw) {                     /* bsw_upload_raw: raw bytes, offsets, bin scratch (and the target coordinates) stay */
+        b->staged = true;
+        b->ci = new chunk_info(ci);
+        b->ref = ref;
+        st.d_woff.release(); st.d_blob.release(); st.d_wout.release();
+    } else
+        st.release_transient_dev();
     *out = b;
     return BSW_OK;
 }
@@ -754,6 +762,18 @@ extern "C" int bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tas
     int rc = busy_check(ctx, "bsw_upload");
     if (rc) return rc;
     return upload_common(ctx, p, tasks, n, out, nullptr, nullptr);
+}
+
+/* bsw_upload that KEEPS what crossed PCIe in HBM (byte-per-base sequences, their offsets) next to the packed form, so that
+ * bsw_run_staged can re-run the device side of the batch manager — pack + bin — in front of the DP kernels: the whole hot
+ * path from "the caller's bytes are in HBM" on, as one timed step. */
+extern "C" int bsw_upload_raw(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!out || (!tasks && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_upload_raw: NULL argument");
+    int rc = busy_check(ctx, "bsw_upload_raw");
+    if (rc) return rc;
+    return upload_common(ctx, p, tasks, n, out, nullptr, nullptr, false, true);
 }
 
 /* bsw_upload for sequences that are 4-bit packed already (see bsw_submit_packed) */
@@ -873,29 +893,44 @@ extern "C" int bsw_extend_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *
     return rc;
 }
 
-extern "C" int bsw_run(bsw_ctx *ctx, bsw_dev_batch *b)
+static int run_common(bsw_ctx *ctx, bsw_dev_batch *b, bool staged, const char *what)
 {
     if (!ctx) return BSW_E_INVAL;
     errs &e = ctx->err;
-    if (!b) return fail(e, BSW_E_INVAL, "bsw_run: NULL argument");
-    int rc = busy_check(ctx, "bsw_run");
+    if (!b) return fail(e, BSW_E_INVAL, "%s: NULL argument", what);
+    if (staged && (!b->staged || !b->ci)) return fail(e, BSW_E_INVAL, "%s: the batch was not uploaded with bsw_upload_raw", what);
+    int rc = busy_check(ctx, what);
     if (rc) return rc;
     HIPCHK(e, hipSetDevice(ctx->device0()));
     hipStream_t s = ctx->stream0();
-    hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
+    hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop, mid = nullptr;
     if (ctx->hist_used < 4096) {
         if (ctx->hist_used == ctx->hist.size()) {
-            hipEvent_t a, c;
-            HIPCHK(e, hipEventCreate(&a));
-            HIPCHK(e, hipEventCreate(&c));
-            ctx->hist.emplace_back(a, c);
+            bsw_ctx::run_ev r;
+            HIPCHK(e, hipEventCreate(&r.e0));
+            HIPCHK(e, hipEventCreate(&r.mid));
+            HIPCHK(e, hipEventCreate(&r.e1));
+            ctx->hist.push_back(r);
         }
-        e0 = ctx->hist[ctx->hist_used].first;
-        e1 = ctx->hist[ctx->hist_used].second;
+        bsw_ctx::run_ev &r = ctx->hist[ctx->hist_used];
+        e0 = r.e0; e1 = r.e1; mid = r.mid;
+        r.staged = staged;
         ++ctx->hist_used;
     }
     HIPCHK(e, hipEventRecord(e0, s));
     b->launches = 0;
+    if (staged && b->n) {
+        const chunk_info &ci = *b->ci;
+        stage_t &st = b->st;
+        if (!ci.packed) {
+            HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, ci.raw_bias, (uint32_t)b->n, ci.rev_left ? 1 : 0,
+                                       nullptr, 0, nullptr, st.d_seq.p, s));
+            ++b->launches;
+        }
+        HIPCHK(e, bsw::launch_bin(ci.bp, st.d_seq.p, st.d_tasks.p, (uint32_t)b->n, st.d_bins.p, st.d_order.p, s));
+        b->launches += 3;
+    }
+    if (mid) HIPCHK(e, hipEventRecord(mid, s));
     rc = enqueue_batch(e, b->P, b->variant, b->st.d_seq.p, b->st.d_tasks.p, b->st.d_order.p, b->plan, b->st.d_out.p, s, &b->launches, fork_for(ctx, s));
     if (rc) return rc;
     HIPCHK(e, hipEventRecord(e1, s));
@@ -903,6 +938,13 @@ extern "C" int bsw_run(bsw_ctx *ctx, bsw_dev_batch *b)
     ctx->timed = true;
     return BSW_OK;
 }
+
+extern "C" int bsw_run(bsw_ctx *ctx, bsw_dev_batch *b) { return run_common(ctx, b, false, "bsw_run"); }
+
+/* the device side of the batch manager (pack: byte per base -> 16 bases per uint64; bin: the counting sort into launch
+ * lists) AND the DP kernels of a batch uploaded with bsw_upload_raw, on the library's stream: what a chunk of bsw_submit
+ * runs on the GPU once its bytes have landed (tbb.v:110-123 -> sw_pe_array_task_parse.v:1600-1648 -> the PEs) */
+extern "C" int bsw_run_staged(bsw_ctx *ctx, bsw_dev_batch *b) { return run_common(ctx, b, true, "bsw_run_staged"); }
 
 extern "C" int bsw_sync(bsw_ctx *ctx)
 {
@@ -923,18 +965,28 @@ extern "C" int bsw_last_run_ms(bsw_ctx *ctx, float *ms)
     return BSW_OK;
 }
 
-extern "C" int bsw_run_history(bsw_ctx *ctx, float *ms, int cap)
+/* total_ms[k] = the k-th run since the last call (first event to last); staging_ms[k] (may be NULL) = its pack + bin part,
+ * 0 for a bsw_run */
+extern "C" int bsw_run_history2(bsw_ctx *ctx, float *total_ms, float *staging_ms, int cap)
 {
-    if (!ctx || (!ms && cap > 0)) return BSW_E_INVAL;
+    if (!ctx || (!total_ms && cap > 0)) return BSW_E_INVAL;
     errs &e = ctx->err;
     int rc = bsw_sync(ctx);
     if (rc) return rc;
     int n = 0;
-    for (size_t i = 0; i < ctx->hist_used && n < cap; ++i, ++n)
-        HIPCHK(e, hipEventElapsedTime(&ms[n], ctx->hist[i].first, ctx->hist[i].second));
+    for (size_t i = 0; i < ctx->hist_used && n < cap; ++i, ++n) {
+        const bsw_ctx::run_ev &r = ctx->hist[i];
+        HIPCHK(e, hipEventElapsedTime(&total_ms[n], r.e0, r.e1));
+        if (staging_ms) {
+            staging_ms[n] = 0.f;
+            if (r.staged) HIPCHK(e, hipEventElapsedTime(&staging_ms[n], r.e0, r.mid));
+        }
+    }
     ctx->hist_used = 0;
     return n;
 }
+
+extern "C" int bsw_run_history(bsw_ctx *ctx, float *ms, int cap) { return bsw_run_history2(ctx, ms, nullptr, cap); }
 
 extern "C" int bsw_download(bsw_ctx *ctx, bsw_dev_batch *b, bsw_result *out)
 {

@@ -131,12 +131,21 @@ extern "C" void bsw_default_config(bsw_config *c)
     c->pack_threads = 4;
     c->chunk_tasks = 131072;
     c->n_devices = 0;
-    c->timeout_ms = 120000;
+    c->timeout_ms = 0;                /* 0 = the library default: BSW_TIMEOUT_MS if set, else 120 s (bsw_effective_timeout_ms) */
     c->result_format = BSW_RESULT_FULL;
     c->pin_threads = 1;
 }
 
 extern "C" int bsw_abi_version(void) { return BSW_ABI_VERSION; }
+
+/* the watchdog a context created from `cfg` runs with: an explicit bsw_config.timeout_ms wins, 0 (what bsw_default_config
+ * writes) means BSW_TIMEOUT_MS when that is a positive number, else 120 s.  Host only, no GPU needed. */
+extern "C" int bsw_effective_timeout_ms(const bsw_config *cfg)
+{
+    if (cfg && cfg->timeout_ms > 0) return cfg->timeout_ms;
+    const char *t = getenv("BSW_TIMEOUT_MS");
+    return t && atoi(t) > 0 ? atoi(t) : 120000;
+}
 
 extern "C" int bsw_device_count(void)
 {
@@ -178,7 +187,7 @@ static void ctx_release(bsw_ctx *ctx)
     if (!dead) {
         if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
         if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
-        for (auto &pr : ctx->hist) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto &pr : ctx->hist) { (void)hipEventDestroy(pr.e0); (void)hipEventDestroy(pr.mid); (void)hipEventDestroy(pr.e1); }
         ctx->small.release();
         ctx->g_tasks.release(); ctx->g_z.release(); ctx->g_cig.release(); ctx->g_order.release(); ctx->g_res.release();
         ctx->a_tasks.release(); ctx->a_bl.release(); ctx->a_res.release();
@@ -274,7 +283,7 @@ extern "C" int bsw_create_sized(const bsw_config *cfg, size_t cfg_size, bsw_ctx 
     if (c.pack_threads < 1) c.pack_threads = 1;
     if (c.chunk_tasks == 0) c.chunk_tasks = 131072;
     /* BSW_TIMEOUT_MS is the DEFAULT for hosts that pass no timeout of their own; an explicit bsw_config.timeout_ms wins */
-    if (c.timeout_ms <= 0) { const char *t = getenv("BSW_TIMEOUT_MS"); c.timeout_ms = t && atoi(t) > 0 ? atoi(t) : 120000; }
+    c.timeout_ms = bsw_effective_timeout_ms(&c);
     if (c.n_devices < 0 || c.n_devices > BSW_MAX_DEVICES) return BSW_E_INVAL;
     if (c.result_format != BSW_RESULT_FULL && c.result_format != BSW_RESULT_PAIR) return BSW_E_INVAL;
     if (c.n_devices == 0) { c.n_devices = 1; c.devices[0] = c.device; }

@@ -230,7 +230,8 @@ struct bsw_ctx {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
     /* per-run event pairs since the last bsw_run_history() call (kernel time of every bsw_run) */
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> hist;
+    struct run_ev { hipEvent_t e0 = nullptr, mid = nullptr, e1 = nullptr; bool staged = false; };   /* mid: behind pack + bin (bsw_run_staged) */
+    std::vector<run_ev> hist;
     size_t hist_used = 0;
     hipEvent_t ev_last0 = nullptr, ev_last1 = nullptr;
     errs err;
@@ -253,6 +254,7 @@ struct bsw_ctx {
     hipStream_t stream0() const { return devs[0].streams[0]; }
 };
 
+struct chunk_info;
 struct bsw_dev_batch {
     uint64_t n = 0;
     bsw_dparams P{};
@@ -262,6 +264,11 @@ struct bsw_dev_batch {
     batch_plan plan;
     uint64_t launches = 0;
     uint64_t h2d_bytes = 0;           /* bytes the upload moved over PCIe */
+    /* bsw_upload_raw: the bytes as they crossed PCIe, their offsets and the bin scratch stay in HBM, so that bsw_run_staged can
+     * redo the device side of the batch manager (pack + bin) in front of the DP kernels */
+    bool staged = false;
+    chunk_info *ci = nullptr;         /* (chunk_info is declared below; owned) */
+    const bsw_ref *ref = nullptr;
 };
 
 /* ---- bsw_ctx.hip ---- */

@@ -104,6 +104,9 @@ def lib():
             "bsw_extend_batch": (C.c_int, [vp, vp, vp, sz, vp]),
             "bsw_upload": (C.c_int, [vp, vp, vp, sz, C.POINTER(vp)]),
             "bsw_run": (C.c_int, [vp, vp]), "bsw_sync": (C.c_int, [vp]),
+            "bsw_upload_raw": (C.c_int, [vp, vp, vp, sz, C.POINTER(vp)]), "bsw_run_staged": (C.c_int, [vp, vp]),
+            "bsw_run_history2": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]),
+            "bsw_effective_timeout_ms": (C.c_int, [vp]),
             "bsw_download": (C.c_int, [vp, vp, vp]),
             "bsw_batch_info": (C.c_int, [vp] + [C.POINTER(C.c_uint64)] * 4),
             "bsw_last_run_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
@@ -155,6 +158,7 @@ EXPORTS = ["ksw_global2", "ksw_global", "bsw_global_batch", "bsw_align_batch", "
            "bsw_host_register", "bsw_host_unregister", "bsw_batch_order", "bsw_refbatch_submit", "bsw_refbatch_wait", "bsw_default_params", "bsw_default_config",
            "bsw_device_count", "bsw_create", "bsw_create_sized", "bsw_abi_version", "bsw_chain_timeouts", "bsw_device_placement", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
            "bsw_submit_packed", "bsw_upload_packed", "bsw_pack_tasks", "bsw_pack_tasks_bound",
+           "bsw_upload_raw", "bsw_run_staged", "bsw_run_history2", "bsw_effective_timeout_ms",
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
            "bsw_refbatch_encode_results", "bsw_refbatch_decode_results", "bsw_refbatch_run",
@@ -387,8 +391,26 @@ class BswContext:
         self._chk(lib().bsw_upload(self.handle, params.ctypes.data, tasks.ctypes.data, len(tasks), C.byref(h)), "bsw_upload")
         return DeviceBatch(self, h, len(tasks))
 
+    def upload_raw(self, params, tasks):
+        """bsw_upload_raw: the byte-per-base sequences stay in HBM beside the packed form (for run_staged)."""
+        h = C.c_void_p()
+        self._chk(lib().bsw_upload_raw(self.handle, params.ctypes.data, tasks.ctypes.data, len(tasks), C.byref(h)), "bsw_upload_raw")
+        return DeviceBatch(self, h, len(tasks))
+
     def run(self, batch):
         self._chk(lib().bsw_run(self.handle, batch.handle), "bsw_run")
+
+    def run_staged(self, batch):
+        """pack + bin + DP kernels of a batch from upload_raw (the device side of one bsw_submit chunk)."""
+        self._chk(lib().bsw_run_staged(self.handle, batch.handle), "bsw_run_staged")
+
+    def run_history2(self, cap=4096):
+        """[(total_ms, staging_ms)] of every run since the last call."""
+        a, b = (C.c_float * cap)(), (C.c_float * cap)()
+        n = lib().bsw_run_history2(self.handle, a, b, cap)
+        if n < 0:
+            self._chk(n, "bsw_run_history2")
+        return [(a[i], b[i]) for i in range(n)]
 
     def sync(self):
         self._chk(lib().bsw_sync(self.handle), "bsw_sync")

@@ -139,8 +139,9 @@ typedef struct bsw_config {
      * may appear more than once (more slots on that GPU). */
     int32_t n_devices;
     int32_t devices[BSW_MAX_DEVICES];
-    int32_t timeout_ms;     /* watchdog on every wait for the GPU (def 120000); on expiry the call fails
-                               with BSW_E_HIP and the context is dead (every later call fails fast)  */
+    int32_t timeout_ms;     /* watchdog on every wait for the GPU; 0 (def) = BSW_TIMEOUT_MS from the environment, else 120000
+                               (bsw_effective_timeout_ms); on expiry the call fails with BSW_E_HIP and the context is dead
+                               (every later call fails fast)  */
     int32_t result_format;  /* BSW_RESULT_FULL (def): bsw_result[n]; BSW_RESULT_PAIR: bsw_pair[n] from the bsw_submit* calls */
     int32_t pin_threads;    /* 0 / 1 (def): the slot and gather threads of a device run on the CPUs of that GPU's NUMA node
                                (/sys/bus/pci/devices/<bdf>/local_cpulist, intersected with the process affinity) and their
@@ -192,6 +193,9 @@ int      bsw_create_sized(const bsw_config *cfg, size_t cfg_size, bsw_ctx **out)
  * kernel does not say) and how many CPUs next to it the context's slot threads are pinned to (0: not pinned). */
 int      bsw_device_placement(const bsw_ctx *ctx, int k, char *bdf, size_t bdf_cap, int *numa_node, int *n_cpus);
 int      bsw_abi_version(void);                      /* BSW_ABI_VERSION the library was built with */
+/* The watchdog (ms) a context created from cfg would run with: cfg->timeout_ms when > 0, else the environment variable
+ * BSW_TIMEOUT_MS when it holds a positive number, else 120000.  bsw_default_config writes 0.  Host only. */
+int      bsw_effective_timeout_ms(const bsw_config *cfg);
 /* How many of the launch chain's waiting waves gave up at their 20 ms deadline so far (the chain's flag is a
  * scheduling hint, a follower released early is still correct).  Non-zero where kernels are run one at a time
  * (rocprofv3 --pmc, HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL); 0 in normal operation.  Synchronises the context. */
@@ -286,6 +290,15 @@ kswr_t ksw_align(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, con
 int      bsw_upload(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out);
 int      bsw_upload_packed(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out);   /* 4-bit packed sequences, as bsw_submit_packed */
 int      bsw_run(bsw_ctx *ctx, bsw_dev_batch *b);          /* enqueue kernels only        */
+/* bsw_upload that also KEEPS the byte-per-base sequences (as they crossed PCIe) in HBM, and bsw_run_staged = the whole device
+ * side of one chunk of bsw_submit on such a batch: pack (bytes -> 16 bases per uint64) + bin (counting sort into the launch
+ * lists) + the DP kernels — the batch manager's work from "task batch landed" to "result batch ready" (tbb.v:110-123,
+ * sw_pe_array_task_parse.v:1600-1648, rbb.v:219-224), inputs resident in HBM.  bsw_run on such a batch still runs the DP
+ * kernels alone.  bsw_run_history2 splits every run since the last call into total / pack + bin milliseconds (HIP events on
+ * the library's stream). */
+int      bsw_upload_raw(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_dev_batch **out);
+int      bsw_run_staged(bsw_ctx *ctx, bsw_dev_batch *b);
+int      bsw_run_history2(bsw_ctx *ctx, float *total_ms, float *staging_ms /* may be NULL */, int cap);
 int      bsw_sync(bsw_ctx *ctx);                            /* hipStreamSynchronize        */
 int      bsw_download(bsw_ctx *ctx, bsw_dev_batch *b, bsw_result *out); /* task order      */
 int      bsw_batch_info(const bsw_dev_batch *b, uint64_t *n_tasks, uint64_t *in_bytes, uint64_t *out_bytes, uint64_t *n_launches);
