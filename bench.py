@@ -1,21 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — GCUPS of the seed-extension hot path on N MI355X GPUs (one process per GPU).
 
-A "step" = one pass of the hot path (left+right ksw_extend2 with band retry and the
-mem_chain2aln decision) over one device-resident task batch.  At N=1 the workload is
-BASELINE.json configs[1]: 1M synthetic 150 bp reads, w=100, single (qlen,tlen)=(131,257)
-bin.  --scaling weak (default): every rank owns its own batch of that shape.  --scaling strong:
-ONE pool of --pool seeds is cut into chunks, chunk c belongs to rank c mod N (the per-read task
-shard of SURVEY.md §8e); no data-path collective either way.
+A "step" = one pass of the hot path over one GPU's seeds, inputs resident in HBM as they crossed PCIe (byte per base): the
+device side of the batch manager (pack: bytes -> 16 bases per uint64; bin: the counting sort into the launch lists) and
+the DP kernels (left + right ksw_extend2 with band retry and the mem_chain2aln decision) — bsw_run_staged.  At N=1 the
+workload is the configuration BASELINE.json's metric is quoted on: 150 bp PE seeds, mixed (qlen, tlen) bins through the batch
+manager, configs[2] size (10 M seeds per GPU, resident batches of 32 x 128 Ki seeds).  --scaling weak (default): every rank
+owns its own seeds of that shape.  --scaling strong: ONE pool of --pool seeds is cut into chunks, chunk c belongs to rank
+c mod N (the per-read task shard of SURVEY.md §8e); no data-path collective either way.
 
-Prints ONE JSON line on rank 0.  `value` = DP cells actually evaluated (exactly as the CPU
-algorithm iterates them) / wall time / 1e9, summed over ranks, inputs already in HBM.
-`e2e` = the same batch pushed through bsw_submit (host buffers in, host buffers out: DMA out of
-registered host memory, packing and binning on the GPU) — PCIe-inclusive, never `value`.
-`pe_mixed_bins` (N=1) = the workload BASELINE.json's metric names — 150 bp PE seeds, left + right
-extension each, mixed (qlen, tlen) bins through the batch manager — at configs[2] size (10 M seeds,
---pe-seeds), resident in HBM, with its own roofline object and the counters of that workload's own
-rocprofv3 passes (profiles/pmc_latest.json holds one entry per workload).  Never part of `value`.
+Prints ONE JSON line on rank 0.  `value` = DP cells actually evaluated (exactly as the CPU algorithm iterates them) / wall
+time / 1e9, summed over ranks, WITH the staging kernels in the step; `kernels_only` = the same batches through bsw_run (the DP
+kernels alone: what rounds 1-5 printed as `value`).  `roofline` prices the dominant DP kernel over the DP part of the step
+(HIP events on the library's stream split every step into pack + bin / DP).
+`e2e*` = the same seeds pushed through bsw_submit* (host buffers in, host buffers out) — PCIe-inclusive, never `value`; run
+on every rank (timed between barriers, MAX over ranks), with what the host side cost (bsw_host_stats: CPU seconds of the slot
+threads per million seeds) and how many cores 8 GPUs would need at that rate.
+`other_workloads` (N=1): configs[1] (150 bp single bin, 1 M seeds) and configs[4]'s shape (250 bp, w = 500, 1 M seeds).
 """
 import argparse
 import json
@@ -373,31 +374,68 @@ def cells_of(res):
     return int(res["left"]["cells"].astype(np.int64).sum() + res["right"]["cells"].astype(np.int64).sum())
 
 
+def generate_seeds(host, spec, chunk_ids, sizes, seed_of, threads, arena=None, tag_base=None, chunk=131072):
+    """The seeds of the given chunks, generated side by side on `threads` CPUs (every chunk has its own generator seed;
+    bsw_synth_generate is 4.25 us per mixed-bin seed on one core) straight into ONE registered (DMA-able) arena.
+    Returns (tasks, arena)."""
+    from concurrent.futures import ThreadPoolExecutor
+    bounds = [host.synth_arena_bound(sz, **spec) for sz in sizes]
+    offs = np.concatenate([[0], np.cumsum(bounds)]).astype(np.int64)
+    if arena is None:
+        arena = host.HostArena(int(offs[-1]) + 4096)
+    assert arena.nbytes >= int(offs[-1])
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    tg = np.zeros(int(starts[-1]), dtype=host.TASK)
+
+    def one(k):
+        t, _ = host.synth_tasks(sizes[k], arena=arena.u8[int(offs[k]):], seed=seed_of(chunk_ids[k]), **spec)      # (ctypes releases the GIL)
+        if tag_base is not None:
+            t["tag"] = np.arange(chunk_ids[k] * chunk, chunk_ids[k] * chunk + sizes[k], dtype=np.uint32)
+        else:
+            t["tag"] = np.arange(int(starts[k]), int(starts[k]) + sizes[k], dtype=np.uint32)
+        tg[int(starts[k]):int(starts[k]) + sizes[k]] = t
+
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        for f in [pool.submit(one, k) for k in range(len(sizes))]:
+            f.result()
+    return tg, arena
+
+
+def sides_of(tasks):
+    return int((tasks["lqlen"] > 0).sum() + (tasks["rqlen"] > 0).sum())
+
+
+def nominal_of(tasks):
+    return int((tasks["lqlen"].astype(np.int64) * tasks["ltlen"]).sum() + (tasks["rqlen"].astype(np.int64) * tasks["rtlen"]).sum())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tasks", type=int, default=1_000_000, help="seeds per GPU per step (weak scaling)")
+    ap.add_argument("--tasks", type=int, default=10_000_000, help="seeds per GPU per step (weak scaling); BASELINE configs[2]: 10 M")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--pool", type=int, default=8_000_000, help="--scaling strong: seeds in the one pool all ranks share (BASELINE configs[3]: 100000000)")
-    ap.add_argument("--gen-threads", type=int, default=0, help="--scaling strong: threads that generate this rank's chunks (0 = the rank's CPU set, at most 32)")
+    ap.add_argument("--gen-threads", type=int, default=0, help="threads that generate this rank's chunks (0 = the rank's CPU set, at most 32)")
     ap.add_argument("--sample-stride", type=int, default=97, help="--scaling strong: the line carries the exact cell count of every k-th chunk of rank 0")
-    ap.add_argument("--resident-chunks", type=int, default=32, help="--scaling strong: 128Ki-seed chunks per resident batch")
-    ap.add_argument("--workload", default="150bp_w100_single_bin", choices=sorted(WORKLOADS))
+    ap.add_argument("--resident-chunks", type=int, default=32, help="128Ki-seed chunks per resident batch (a batch holds < 4 GiB of bases)")
+    ap.add_argument("--workload", default="150bp_w100_mixed_bins", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--zdrop", type=int, default=100)
     ap.add_argument("--gaps", default=None, help="o_del,e_del,o_ins,e_ins (default: bwa's 6,1,6,1)")
-    ap.add_argument("--cpu-sample", type=int, default=250_000, help="seeds timed on the CPU oracle (rank 0, N=1): 3 runs of ~9 s on 16 threads")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(affinity, 16): the 1-GPU box's CPU share")
+    ap.add_argument("--kernels-only-steps", type=int, default=-1, help="steps of the second timed region (bsw_run: DP kernels alone); -1 = --steps, 0 = skip")
+    ap.add_argument("--cpu-sample", type=int, default=250_000, help="seeds timed on the scalar CPU oracle (rank 0, N=1): 3 runs of ~9 s on 16 threads")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(affinity, 16): the 1-GPU box's CPU share; an all-core leg is added when the affinity holds more")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the 250 bp and mixed-bin side measurements (N=1 only, outside the timed region)")
-    ap.add_argument("--pe-seeds", type=int, default=10_000_000, help="seeds of the 150 bp PE mixed-bin measurement beside the headline (BASELINE configs[2]: 10 M; 0 = skip)")
-    ap.add_argument("--packed-chunk", type=int, default=114688, help="seeds per chunk of the packed-input single-submit legs (112 Ki: 9 chunks per 1 M seeds; re-swept with round 5 kernels, profiles/r5/e2e_packed_chunk_sweep.txt: 64 / 80 / 96 / 112 / 128 / 160 Ki -> 103 / 113 / 115 / 123 / 122 / 95 M seeds/s)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the single-bin / 250 bp / side-path measurements (N=1 only, outside the timed region)")
+    ap.add_argument("--other-seeds", type=int, default=1_000_000, help="seeds of the other_workloads legs")
+    ap.add_argument("--packed-chunk", type=int, default=114688, help="seeds per chunk of the packed-input single-submit legs (112 Ki; profiles/r5/e2e_packed_chunk_sweep.txt)")
     ap.add_argument("--e2e-chunk", type=int, default=131072, help="seeds per chunk of the byte-input and device-reference single-submit legs")
-    ap.add_argument("--e2e-slots", type=int, default=4, help="slot threads (= streams) of the single-submit PCIe-inclusive legs")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the bsw_submit (PCIe-inclusive) measurement")
+    ap.add_argument("--e2e-slots", type=int, default=4, help="slot threads (= streams) of the PCIe-inclusive legs")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the bsw_submit (PCIe-inclusive) measurements")
     ap.add_argument("--e2e-reps", type=int, default=5, help="bsw_submit passes timed (median reported)")
+    ap.add_argument("--stream-reps", type=int, default=8, help="batches of a stream leg (two submits in flight in ONE context)")
     ap.add_argument("--ref-mbp", type=int, default=64, help="synthetic genome size (Mbp) of the device-resident-reference e2e leg; 0 = skip")
     ap.add_argument("--check", type=int, default=100_000, help="seeds checked bit-exact against the oracle after timing")
     ap.add_argument("--spec", action="append", default=[], help="override a generator field, e.g. --spec n_rate=0 (experiments)")
@@ -414,6 +452,8 @@ def main():
         for key, val in PRESETS[args.preset].items():
             if "--" + key not in given:
                 setattr(args, key, val)
+    if args.kernels_only_steps < 0:
+        args.kernels_only_steps = args.steps
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without torchrun: start N fresh per-GPU ranks BEFORE anything here touches the GPU
@@ -438,7 +478,8 @@ def main():
             dist.destroy_process_group()
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "gpus_flag": args.gpus,
-                              "scaling": args.scaling, "workload": args.workload, "pool": args.pool}), flush=True)
+                              "scaling": args.scaling, "workload": args.workload, "pool": args.pool,
+                              "rank_cpus": os.environ.get("BSW_RANK_CPUS")}), flush=True)
         return
     if args.share_gpu:
         local_rank = 0
@@ -486,74 +527,62 @@ def main():
         spec[key] = type(spec[key])(float(val))
     gaps = dict(zip(("o_del", "e_del", "o_ins", "e_ins"), (int(x) for x in args.gaps.split(",")))) if args.gaps else {}
     params = host.default_params(variant=args.variant, zdrop=args.zdrop, w=spec["w"], **gaps)
+    gen_threads = max(1, min(args.gen_threads or len(cpu_affinity or [0]), 32))
 
-    # ---- this rank's seeds, generated straight into pinned (DMA-able) host memory ----
+    # ---- this rank's seeds, generated straight into pinned (DMA-able) host memory, then resident in HBM AS BYTES ----
     chunk = 131072
     ctx = host.BswContext(device=local_rank, kernel=args.kernel)
+    t_gen0 = time.perf_counter()
+    sample_cells, groups = {}, []
     if args.scaling == "strong":
-        # one pool, chunk c -> rank c mod N; a rank's chunks become resident batches of <= --resident-chunks chunks (a resident
-        # batch holds < 4 GiB of bases), generated, uploaded and dropped on the host one group at a time
+        # one pool, chunk c -> rank c mod N; a rank's chunks become resident batches of <= --resident-chunks chunks, generated,
+        # uploaded and dropped on the host one group at a time (group g+1 is generated while group g uploads)
+        from concurrent.futures import ThreadPoolExecutor
         nchunks = (args.pool + chunk - 1) // chunk
         mine = [c for c in range(nchunks) if c % world == rank]
         groups = [mine[i:i + args.resident_chunks] for i in range(0, len(mine), args.resident_chunks)]
         gb = args.resident_chunks * host.synth_arena_bound(chunk, **spec) + 4096
-        # Every chunk has its own generator seed, so the chunks of a group are generated side by side on this rank's CPUs
-        # (bsw_synth_generate is 4.25 us per mixed-bin seed on one core: 100 M seeds would be 7 minutes of it), and group g+1
-        # is generated into a second arena while group g is uploaded (validate + lay out on the host, pack + bin on the GPU).
-        from concurrent.futures import ThreadPoolExecutor
-        gen_threads = max(1, min(args.gen_threads or len(cpu_affinity or [0]), 32))
         arenas = [host.HostArena(gb) for _ in range(2 if len(groups) > 1 else 1)]
-        harena = arenas[0]
-        pool = ThreadPoolExecutor(max_workers=gen_threads)
+        bg = ThreadPoolExecutor(max_workers=1)
 
-        def generate(gi):
+        def gen_group(gi):
             grp = groups[gi]
-            ar = arenas[gi % len(arenas)]
-            sizes = [min(chunk, args.pool - c * chunk) for c in grp]
-            tg = np.zeros(int(sum(sizes)), dtype=host.TASK)
-            offs = np.concatenate([[0], np.cumsum([host.synth_arena_bound(sz, **spec) for sz in sizes])]).astype(np.int64)
-            starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            return generate_seeds(host, spec, grp, [min(chunk, args.pool - c * chunk) for c in grp], lambda c: 5000 + c, gen_threads,
+                                  arena=arenas[gi % len(arenas)], tag_base=0, chunk=chunk)[0]
 
-            def one(k):
-                c, sz = grp[k], sizes[k]
-                t, _ = host.synth_tasks(sz, arena=ar.u8[int(offs[k]):], seed=5000 + c, **spec)      # (ctypes releases the GIL)
-                t["tag"] = np.arange(c * chunk, c * chunk + sz, dtype=np.uint32)
-                tg[int(starts[k]):int(starts[k]) + sz] = t
-            return tg, [pool.submit(one, k) for k in range(len(grp))]
-
-        batches, n_local, gstats = [], 0, []
-        t_gen0 = time.perf_counter()
-        nxt = generate(0) if groups else None
+        batches, n_local, gstats, tasks = [], 0, [], None
+        nxt = bg.submit(gen_group, 0) if groups else None
         for gi in range(len(groups)):
-            tg, futs = nxt
-            for f in futs:
-                f.result()
-            nxt = generate(gi + 1) if gi + 1 < len(groups) else None     # ... overlaps this group's upload
-            batches.append(ctx.upload(params, tg))                          # inputs resident in HBM before the timed region
+            tg = nxt.result()
+            nxt = bg.submit(gen_group, gi + 1) if gi + 1 < len(groups) else None     # ... overlaps this group's upload
+            batches.append(ctx.upload_raw(params, tg))                                 # inputs resident in HBM before the timed region
             n_local += len(tg)
-            gstats.append((int((tg["lqlen"] > 0).sum() + (tg["rqlen"] > 0).sum()),
-                           int((tg["lqlen"].astype(np.int64) * tg["ltlen"]).sum() + (tg["rqlen"].astype(np.int64) * tg["rtlen"]).sum())))
+            gstats.append((sides_of(tg), nominal_of(tg)))
             if rank == 0 and len(groups) > 1:
                 print("bench.py: rank 0 resident batch %d/%d (%d seeds, %.1f s)" % (len(batches), len(groups), len(tg), time.perf_counter() - t_gen0),
                       file=sys.stderr, flush=True)
-        pool.shutdown()
-        setup_s = time.perf_counter() - t_gen0
+            if len(groups) == 1:
+                tasks = tg                                                              # e2e legs only when the rank's share is one batch
+        bg.shutdown()
+        harena = arenas[0]
         for ar in arenas[1:]:
             ar.free()
-        tasks = tg if len(groups) == 1 else None                            # e2e legs only when the rank's share is one batch
-        hout = host.HostArena(max(n_local if tasks is not None else 1, 1) * host.RESULT.itemsize)
     else:
-        setup_s = None
         n_local = args.tasks
-        harena = host.HostArena(host.synth_arena_bound(max(n_local, 1), **spec) + 4096)
-        hout = host.HostArena(max(n_local, 1) * host.RESULT.itemsize)
-        tasks, _ = host.synth_tasks(n_local, arena=harena.u8, seed=1000 + rank, **spec)
-        batches = [ctx.upload(params, tasks)]        # inputs resident in HBM before the timed region
+        nchunks = max(1, (n_local + chunk - 1) // chunk)
+        ids = list(range(nchunks))
+        tasks, harena = generate_seeds(host, spec, ids, [min(chunk, n_local - c * chunk) for c in ids],
+                                       lambda c: 7000 + 100000 * rank + c, gen_threads)
+        per = args.resident_chunks * chunk
+        batches, gstats = [], []
+        for lo in range(0, max(n_local, 1), per):
+            tg = tasks[lo:lo + per]
+            batches.append(ctx.upload_raw(params, tg))          # inputs resident in HBM before the timed region
+            gstats.append((sides_of(tg), nominal_of(tg)))
+        groups = [list(range(i, min(i + args.resident_chunks, nchunks))) for i in range(0, nchunks, args.resident_chunks)]
+    setup_s = time.perf_counter() - t_gen0
     if tasks is None:
         args.no_e2e = True
-    out_buf = hout.view(host.RESULT, max(n_local, 1))[:n_local] if tasks is not None else None
-    hout2 = host.HostArena(max(n_local, 1) * host.RESULT.itemsize) if (world == 1 and not args.no_e2e) else None
-    out_buf2 = hout2.view(host.RESULT, max(n_local, 1))[:n_local] if hout2 is not None else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -561,25 +590,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        for b in batches:
-            ctx.run(b)
-    ctx.sync()
-    ctx.run_history()                            # reset per-run event history
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        for b in batches:
-            ctx.run(b)
-    ctx.sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms = ctx.run_history()                  # HIP events on the library's own stream, one pair per bsw_run
+    def timed_region(step_fn, steps, warmup):
+        """W warm-up steps, then exactly K steps between barrier + synchronize; (wall seconds, [(total_ms, staging_ms)] per bsw_run*)"""
+        for _ in range(warmup):
+            for b in batches:
+                step_fn(b)
+        ctx.sync()
+        ctx.run_history2()                           # reset the per-run event history
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for b in batches:
+                step_fn(b)
+        ctx.sync()
+        barrier()
+        return time.perf_counter() - t0, ctx.run_history2()
+
+    # ---- the timed step: pack + bin + DP kernels of every resident batch (HIP events on the library's stream split it) ----
+    dt, hist = timed_region(ctx.run_staged, args.steps, args.warmup)
+    nb = len(batches)
+    step_ms = [float(sum(h[0] for h in hist[i:i + nb])) for i in range(0, len(hist), nb)]
+    stage_ms = [float(sum(h[1] for h in hist[i:i + nb])) for i in range(0, len(hist), nb)]
+    dp_ms = [a - b for a, b in zip(step_ms, stage_ms)]
+    # ---- the same batches, DP kernels alone (what rounds 1-5 timed) ----
+    dt_k, kern_ms = None, []
+    if args.kernels_only_steps > 0:
+        dt_k, hk = timed_region(ctx.run, args.kernels_only_steps, min(args.warmup, 1))
+        kern_ms = [float(sum(h[0] for h in hk[i:i + nb])) for i in range(0, len(hk), nb)]
 
     info = {"in_bytes": 0, "out_bytes": 0, "launches": 0}
-    sample_cells = {}
     cells = ext_calls = nominal = 0
-    res = None
+    res_parts = []
     for gi, b in enumerate(batches):
         r = ctx.download(b)
         bi = b.info()
@@ -595,180 +636,161 @@ def main():
                     sample_cells[str(c)] = cells_of(r[lo:lo + sz])
                 lo += sz
         retry = int((r["left"]["aw"] > spec["w"]).sum() + (r["right"]["aw"] > spec["w"]).sum())
+        ext_calls += gstats[gi][0] + retry
+        nominal += gstats[gi][1]
         if tasks is not None:
-            res = r
-            ext_calls += int((tasks["lqlen"] > 0).sum() + (tasks["rqlen"] > 0).sum()) + retry
-            nominal += int((tasks["lqlen"].astype(np.int64) * tasks["ltlen"]).sum() + (tasks["rqlen"].astype(np.int64) * tasks["rtlen"]).sum())
-        else:
-            ext_calls += gstats[gi][0] + retry
-            nominal += gstats[gi][1]
-    n_tasks_local = n_local
-    if len(batches) > 1:                         # kernel time per step = the step's bsw_run calls together
-        kern_ms = [float(sum(kern_ms[i:i + len(batches)])) for i in range(0, len(kern_ms), len(batches))]
+            res_parts.append(r)
+    res = np.concatenate(res_parts) if res_parts else None
+    del res_parts
 
-    # streams kept two deep: two contexts; slots per context and chunk size per input format from the sweeps in
-    # profiles/r3/e2e_hw_queues.txt (the HIP runtime maps streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default)
-    # (re-swept with round 5's kernels and the late result DMAs, profiles/r5/e2e_stream_cfg_sweep.txt: two contexts of TWO slots each —
-    # four streams, one per hardware queue — beat two of four: packed 146 vs 124, device reference 142 vs 123 M seeds/s)
-    STREAM_CFG = {"bytes": (2, 2 * chunk), "packed": (2, 131072), "ref": (2, chunk)}
-    for kind in list(STREAM_CFG):                     # (measurements) BENCH_STREAM_PACKED="slots,chunk" etc.
-        ov = os.environ.get("BENCH_STREAM_" + kind.upper())
-        if ov:
-            STREAM_CFG[kind] = tuple(int(x) for x in ov.split(","))
-    def stream_threads(kind):
-        return "%d slot threads (2 contexts x %d slots, %d-seed chunks)" % (2 * STREAM_CFG[kind][0], STREAM_CFG[kind][0], STREAM_CFG[kind][1])
+    # ---- PCIe-inclusive legs: the same seeds through bsw_submit* (host buffers in, host buffers out), on EVERY rank ----
+    legs = {}                                             # name -> dict(seconds=[per rep], extra fields); times are rank-local
+    stats_legs = {}
 
-    def stream_two_in_flight(make_ctx, submit, reps=8):
-        """A stream of batches, two in flight: two contexts, submit k+2 issued as soon as k is waited for — how an aligner
-        that keeps producing seed batches uses the library.  Seconds per batch."""
-        ca, cb = make_ctx(), make_ctx()
-        sa, sb = submit(ca, out_buf), submit(cb, out_buf2)
-        sa(); ca.wait(); sb(); cb.wait()                          # warm up both
-        t1 = time.perf_counter()
-        sa(); sb()
-        for _ in range(reps - 1):
-            ca.wait(); sa()
-            cb.wait(); sb()
-        ca.wait(); cb.wait()
-        d = (time.perf_counter() - t1) / (2 * reps)
-        same = bool(out_buf.tobytes() == out_buf2.tobytes())
-        return d, same, (ca, cb)
+    def host_cost(c, n_seeds_total, before):
+        st = c.host_stats()
+        d = {k: st[k] - before.get(k, 0) for k in st}
+        cpu_s = (d["slot_cpu_ns"] + d["helper_cpu_ns"]) / 1e9
+        return {"cpu_s_per_M_seeds": round(cpu_s / max(d["seeds"], 1) * 1e6, 4), "slot_threads": st["slot_threads"],
+                "h2d_bytes_per_seed": round(d["h2d_bytes"] / max(d["seeds"], 1), 1), "d2h_bytes_per_seed": round(d["d2h_bytes"] / max(d["seeds"], 1), 1),
+                "seeds_accounted": d["seeds"]}
 
-    # ---- the same seeds through bsw_submit: host buffers in (registered arena), host buffers out ----
-    e2e_dt = None
-    if not args.no_e2e:
-        sctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.e2e_chunk)
-        for _ in range(2):                                       # warm up twice: staging allocations and code load, then the pipeline's steady layout (the first timed pass after ONE warm-up ran 16 ms against 10.4)
-            sctx.extend_pairs(params, tasks, out=out_buf)
-        e2e_runs = []
-        for _ in range(args.e2e_reps):
+    def single_submits(c, call, reps):
+        """`reps` single submits, each between barriers; rank-local seconds (submit -> wait returned)"""
+        for _ in range(2):                                # warm up twice: staging allocations and code load, then the pipeline's steady layout
+            call()
+        before = c.host_stats()
+        runs = []
+        for _ in range(reps):
             barrier()
             t1 = time.perf_counter()
-            got = sctx.extend_pairs(params, tasks, out=out_buf)
-            barrier()
-            e2e_runs.append(time.perf_counter() - t1)
-        e2e_dt = float(np.median(e2e_runs))
-        e2e_same = bool(got.tobytes() == res.tobytes())
-        sctx.close()
-        e2e_stream = None
-        if world == 1:
-            d2, same2, (ca, cb) = stream_two_in_flight(
-                lambda: host.BswContext(device=local_rank, kernel=args.kernel, streams=STREAM_CFG["bytes"][0], pack_threads=2, chunk_tasks=STREAM_CFG["bytes"][1]),
-                lambda c, o: (lambda: c.submit(params, tasks, o)))
-            e2e_stream = (d2, same2 and bool(out_buf.tobytes() == res.tobytes()))
-            ca.close(); cb.close()
+            call()
+            runs.append(time.perf_counter() - t1)
+        barrier()
+        return runs, before
 
-    # ---- the same seeds handed over 4-BIT PACKED (the device layout; bsw_submit_packed): no pack kernel, ~0.6x the PCIe bytes ----
-    packed_leg = None
-    if not args.no_e2e and world == 1:
+    def stream_two_deep(c, submit, bufs, reps):
+        """A stream of batches through ONE context, two submits in flight (ABI 6 tickets): submit k+2 is issued as soon as k has
+        been waited for — how an aligner that keeps producing seed batches uses the library.  Rank-local seconds per batch."""
+        submit(bufs[0]); ta = c.last_ticket
+        c.wait_ticket(ta)                                 # warm up
+        before = c.host_stats()
+        barrier()
+        t1 = time.perf_counter()
+        submit(bufs[0]); ta = c.last_ticket
+        submit(bufs[1]); tb = c.last_ticket
+        for _ in range(reps - 1):
+            c.wait_ticket(ta); submit(bufs[0]); ta = c.last_ticket
+            c.wait_ticket(tb); submit(bufs[1]); tb = c.last_ticket
+        c.wait_ticket(ta); c.wait_ticket(tb)
+        d = (time.perf_counter() - t1) / (2 * reps)
+        barrier()
+        return d, before
+
+    STREAM_CHUNK = {"bytes": 2 * chunk, "packed": 131072, "ref": chunk}
+    for kind in list(STREAM_CHUNK):                       # (measurements) BENCH_STREAM_PACKED=chunk etc.
+        ov = os.environ.get("BENCH_STREAM_" + kind.upper())
+        if ov:
+            STREAM_CHUNK[kind] = int(ov.split(",")[-1])
+    if not args.no_e2e:
+        hout = host.HostArena(max(n_local, 1) * host.RESULT.itemsize)
+        hout2 = host.HostArena(max(n_local, 1) * host.RESULT.itemsize)
+        out_buf = hout.view(host.RESULT, max(n_local, 1))[:n_local]
+        out_buf2 = hout2.view(host.RESULT, max(n_local, 1))[:n_local]
+        # -- byte per base in a registered arena: DMA'd as it is, packed and binned on the GPU
+        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.e2e_chunk) as c:
+            runs, before = single_submits(c, lambda: c.extend_pairs(params, tasks, out=out_buf), args.e2e_reps)
+            legs["e2e"] = {"runs": runs, "same": bool(out_buf.tobytes() == res.tobytes()), "host": host_cost(c, n_local, before)}
+        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=STREAM_CHUNK["bytes"]) as c:
+            d2, before = stream_two_deep(c, lambda o: c.submit(params, tasks, o), (out_buf, out_buf2), args.stream_reps)
+            legs["e2e_stream"] = {"runs": [d2], "same": bool(out_buf.tobytes() == res.tobytes() and out_buf2.tobytes() == res.tobytes()), "host": host_cost(c, n_local, before)}
+        # -- the same seeds handed over 4-BIT PACKED (the device layout; bsw_submit_packed): no pack kernel, ~0.6x the PCIe bytes
         need = int(host.lib().bsw_pack_tasks_bound(tasks.ctypes.data, len(tasks)))
         parena = host.HostArena(need + 64)
         ptasks, _w = host.pack_tasks(tasks, parena.view(np.uint64, need // 8 + 1))
-        # 96 Ki chunks: with half the bytes per seed the input DMAs are short and smaller chunks start the GPU sooner
-        # (sweep: profiles/r3/e2e_packed_sweep.txt)
-        pctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.packed_chunk)
-        for _ in range(2):
-            pctx.extend_pairs_packed(params, ptasks, out=out_buf)
-        runs = []
-        for _ in range(args.e2e_reps):
-            barrier()
-            t1 = time.perf_counter()
-            gotp = pctx.extend_pairs_packed(params, ptasks, out=out_buf)
-            barrier()
-            runs.append(time.perf_counter() - t1)
-        psame = bool(gotp.tobytes() == res.tobytes())
-        pctx.close()
-        d2, same2, (ca, cb) = stream_two_in_flight(
-            lambda: host.BswContext(device=local_rank, kernel=args.kernel, streams=STREAM_CFG["packed"][0], pack_threads=2, chunk_tasks=STREAM_CFG["packed"][1]),
-            lambda c, o: (lambda: c.submit_packed(params, ptasks, o)))
-        pstream = (d2, same2 and bool(out_buf.tobytes() == res.tobytes()))
-        ca.close(); cb.close()
-        # the same submit handing back the RTL's 5-word record alone (BSW_RESULT_PAIR: 32 of the 96 result bytes per seed)
+        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.packed_chunk) as c:
+            runs, before = single_submits(c, lambda: c.extend_pairs_packed(params, ptasks, out=out_buf), args.e2e_reps)
+            legs["packed"] = {"runs": runs, "same": bool(out_buf.tobytes() == res.tobytes()), "host": host_cost(c, n_local, before), "bytes": need}
+        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=STREAM_CHUNK["packed"]) as c:
+            d2, before = stream_two_deep(c, lambda o: c.submit_packed(params, ptasks, o), (out_buf, out_buf2), args.stream_reps)
+            legs["packed_stream"] = {"runs": [d2], "same": bool(out_buf.tobytes() == res.tobytes() and out_buf2.tobytes() == res.tobytes()), "host": host_cost(c, n_local, before)}
+        # -- the same submit handing back the RTL's 5-word record alone (BSW_RESULT_PAIR: 32 of the 96 result bytes per seed)
         pout = host.HostArena(max(n_local, 1) * host.PAIR.itemsize)
         pair_buf = pout.view(host.PAIR, max(n_local, 1))[:n_local]
-        qctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.packed_chunk, result_format=host.RESULT_PAIR)
-        for _ in range(2):
-            qctx.extend_pairs_packed(params, ptasks, out=pair_buf)
-        qruns = []
-        for _ in range(args.e2e_reps):
-            barrier()
-            t1 = time.perf_counter()
-            gotq = qctx.extend_pairs_packed(params, ptasks, out=pair_buf)
-            barrier()
-            qruns.append(time.perf_counter() - t1)
-        qsame = all(bool((gotq[f] == res[f]).all()) for f in host.PAIR.names)
-        qctx.close()
+        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.packed_chunk, result_format=host.RESULT_PAIR) as c:
+            runs, before = single_submits(c, lambda: c.extend_pairs_packed(params, ptasks, out=pair_buf), args.e2e_reps)
+            legs["packed_pairs"] = {"runs": runs, "same": all(bool((pair_buf[f] == res[f]).all()) for f in host.PAIR.names), "host": host_cost(c, n_local, before)}
         pout.free()
-        packed_leg = (float(np.median(runs)), psame, need, pstream, float(np.median(qruns)), qsame, list(runs), list(qruns))
         parena.free()
+        # -- same shape of work, seeds against a DEVICE-RESIDENT reference: only the reads cross PCIe (SURVEY.md §8f F3)
+        if args.ref_mbp > 0 and args.scaling == "weak":
+            lp = args.ref_mbp * 1_000_000
+            hreads = host.HostArena(spec["read_len"] * n_local + 4096)
+            pac, rtasks, _ = host.synth_ref_tasks(n_local, lp, params, arena=hreads.u8, seed=3000 + rank, **spec)
+            with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.e2e_chunk) as c:
+                gref = c.ref_upload(pac, lp)
 
-    # ---- same shape of work, seeds against a DEVICE-RESIDENT reference: only the reads cross PCIe (SURVEY.md §8f F3) ----
-    ref_leg = None
-    if not args.no_e2e and args.ref_mbp > 0 and args.scaling == "weak":
-        lp = args.ref_mbp * 1_000_000
-        hreads = host.HostArena(spec["read_len"] * n_local + 4096)
-        pac, rtasks, _ = host.synth_ref_tasks(n_local, lp, params, arena=hreads.u8, seed=3000 + rank, **spec)
-        rctx = host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.e2e_chunk)
-        gref = rctx.ref_upload(pac, lp)
-        for _ in range(2):                                                      # warm up
-            rctx.submit_ref(params, gref, rtasks, out=out_buf); rctx.wait()
-        runs = []
-        for _ in range(args.e2e_reps):
-            barrier()
-            t1 = time.perf_counter()
-            rctx.submit_ref(params, gref, rtasks, out=out_buf); rctx.wait()
-            barrier()
-            runs.append(time.perf_counter() - t1)
-        rcells = cells_of(out_buf)
-        nchk = min(50_000, n_local)
-        same = bool(rctx.extend_ref(params, gref, rtasks[:nchk]).tobytes() == out_buf[:nchk].tobytes())
-        ref_first = out_buf.copy() if world == 1 else None
-        ref_leg = (float(np.median(runs)), rcells, same, int(rtasks["l_query"].astype(np.int64).sum()), lp, list(runs))
-        rctx.ref_free(gref)
-        rctx.close()
-        ref_stream = None
-        if world == 1:
-            refs = {}
-            def mk():
-                c = host.BswContext(device=local_rank, kernel=args.kernel, streams=STREAM_CFG["ref"][0], pack_threads=2, chunk_tasks=STREAM_CFG["ref"][1])
-                refs[id(c)] = c.ref_upload(pac, lp)
-                return c
-            d2, same2, (ca, cb) = stream_two_in_flight(mk, lambda c, o: (lambda: c.submit_ref(params, refs[id(c)], rtasks, out=o)))
-            ref_stream = (d2, same2 and bool(out_buf.tobytes() == ref_first.tobytes()))
-            for c in (ca, cb):
-                c.ref_free(refs[id(c)]); c.close()
-        hreads.free()
+                def ref_call():
+                    c.submit_ref(params, gref, rtasks, out=out_buf); c.wait()
+                runs, before = single_submits(c, ref_call, args.e2e_reps)
+                nchk = min(50_000, n_local)
+                ref_first = out_buf.copy()
+                legs["ref"] = {"runs": runs, "cells": cells_of(out_buf), "host": host_cost(c, n_local, before), "lp": lp,
+                               "bytes": int(rtasks["l_query"].astype(np.int64).sum()),
+                               "same": bool(c.extend_ref(params, gref, rtasks[:nchk]).tobytes() == out_buf[:nchk].tobytes())}
+                c.ref_free(gref)
+            with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=STREAM_CHUNK["ref"]) as c:
+                gref = c.ref_upload(pac, lp)
+                d2, before = stream_two_deep(c, lambda o: c.submit_ref(params, gref, rtasks, out=o), (out_buf, out_buf2), args.stream_reps)
+                legs["ref_stream"] = {"runs": [d2], "host": host_cost(c, n_local, before),
+                                      "same": bool(out_buf.tobytes() == ref_first.tobytes() and out_buf2.tobytes() == ref_first.tobytes())}
+                c.ref_free(gref)
+            del ref_first
+            hreads.free()
+        hout2.free()
 
+    # ---- reductions: times MAX over ranks, volumes SUM; the per-rank rows travel whole ----
+    LEG_NAMES = ["e2e", "e2e_stream", "packed", "packed_stream", "packed_pairs", "ref", "ref_stream"]
     place = ctx.placement()
-    rank_rows = [[float(rank), float(props.pci_domain_id), float(props.pci_bus_id), float(props.pci_device_id), float(my_node),
-                  float(repinned), float(place["pinned_cpus"]), dt / args.steps * 1e3, float(len(cpu_affinity or []))]]
+    leg_med = [float(np.median(legs[k]["runs"])) if k in legs else 0.0 for k in LEG_NAMES]
+    leg_cpu = [float(legs[k]["host"]["cpu_s_per_M_seeds"]) if k in legs else 0.0 for k in LEG_NAMES]
+    row = [float(rank), float(props.pci_domain_id), float(props.pci_bus_id), float(props.pci_device_id), float(my_node),
+           float(repinned), float(place["pinned_cpus"]), dt / args.steps * 1e3, float(len(cpu_affinity or [])),
+           (dt_k or 0.0) / max(args.kernels_only_steps, 1) * 1e3, float(n_local)] + leg_med + leg_cpu
+    rank_rows = [row]
     if dist is not None:
-        mine_t = torch.tensor(rank_rows[0], dtype=torch.float64, device=red_dev)
+        mine_t = torch.tensor(row, dtype=torch.float64, device=red_dev)
         allr = [torch.zeros_like(mine_t) for _ in range(world)]
         dist.all_gather(allr, mine_t)
         rank_rows = [t.tolist() for t in allr]
-    if dist is not None:
-        v = torch.tensor([dt, float(cells), float(ext_calls), float(n_tasks_local), float(nominal), e2e_dt or 0.0],
+        v = torch.tensor([float(cells), float(ext_calls), float(n_local), float(nominal), float(legs["ref"]["cells"]) if "ref" in legs else 0.0],
                          dtype=torch.float64, device=red_dev)
-        tmax = v[[0, 5]].clone()
+        tmax = torch.tensor([dt, dt_k or 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        dt_all, e2e_all = float(tmax[0].item()), float(tmax[1].item())
-        cells_all, ext_all, tasks_all, nominal_all = (float(x) for x in v[1:5].tolist())
+        dt_all, dtk_all = float(tmax[0].item()), float(tmax[1].item())
+        cells_all, ext_all, tasks_all, nominal_all, refcells_all = (float(x) for x in v.tolist())
     else:
-        dt_all, e2e_all = dt, e2e_dt or 0.0
-        cells_all, ext_all, tasks_all, nominal_all = float(cells), float(ext_calls), float(n_tasks_local), float(nominal)
+        dt_all, dtk_all = dt, dt_k or 0.0
+        cells_all, ext_all, tasks_all, nominal_all = float(cells), float(ext_calls), float(n_local), float(nominal)
+        refcells_all = float(legs["ref"]["cells"]) if "ref" in legs else 0.0
+    L0 = 11                                              # first leg column of a rank row
 
     out = None
     if rank == 0:
         gcups = cells_all * args.steps / dt_all / 1e9
-        kavg_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
-        alg_bytes = info["in_bytes"] + info["out_bytes"]          # per launch: packed seq + task records + order + results
-        pmc, pmc_src = pmc_summary(args.workload, n_local)
+        gcups_k = cells_all * args.kernels_only_steps / dtk_all / 1e9 if dtk_all else None
+        dp_avg = float(np.mean(dp_ms)) if dp_ms else float("nan")      # DP kernels of one step of THIS rank (HIP events)
+        st_avg = float(np.mean(stage_ms)) if stage_ms else 0.0
+        alg_bytes = info["in_bytes"] + info["out_bytes"]          # per step: packed seq + task records + order + results
+        pmc, pmc_src = pmc_summary(args.workload, n_local, key="%s@%d" % (args.workload, n_local))
         traffic = int((2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in pmc else None
-        tops = cells * VALU_OPS_PER_CELL / (kavg_ms * 1e-3) / 1e12
+        tops = cells * VALU_OPS_PER_CELL / (dp_avg * 1e-3) / 1e12
+        ipc = pmc.get("valu_lane_insts_per_cell")
+        waves = 1 if spec["read_len"] > 150 else 2
         out = {
-            "metric": "GCUPS (seed-extension DP cells/s, %d bp reads, w=%d)" % (spec["read_len"], spec["w"]), "value": round(gcups, 3), "unit": "GCUPS",
+            "metric": "GCUPS (seed-extension DP cells/s, %d bp %s, w=%d)" % (spec["read_len"], "PE seeds, left + right extension" if not spec["seed_at_start"] else "reads, right extension", spec["w"]),
+            "value": round(gcups, 3), "unit": "GCUPS",
             "n_gpus": world, "world_size": (dist.get_world_size() if dist is not None else 1),
             "collective_backend": (("rccl" if args.backend == "nccl" else args.backend) if dist is not None else None),
             "steps": args.steps, "warmup": args.warmup,
@@ -776,17 +798,26 @@ def main():
             "vs_baseline": None,
             "dtype": "u8 scores in packed u16 VALU ops (v_pk_*_u16: two seeds per lane), range-checked per seed; wider scores run 16-bit rows / int32",
             "data": "synthetic",
+            "step": "with_staging: pack (bytes -> 16 bases per uint64) + bin (counting sort into launch lists) + DP kernels of every resident batch (bsw_run_staged); inputs resident in HBM as byte-per-base sequences",
+            "with_staging": {"gcups": round(gcups, 3), "ms_per_step": round(dt_all / args.steps * 1e3, 4),
+                             "pack_bin_ms_per_step": round(st_avg, 4), "dp_kernels_ms_per_step": round(dp_avg, 4),
+                             "pack_bin_share": round(st_avg / (st_avg + dp_avg), 4) if dp_ms else None, "timing": "HIP events on the library's stream (rank 0), wall clock for the step"},
+            "kernels_only": ({"gcups": round(gcups_k, 3), "ms_per_step": round(dtk_all / args.kernels_only_steps * 1e3, 4), "steps": args.kernels_only_steps,
+                              "kernel_ms_avg": round(float(np.mean(kern_ms)), 4), "step": "bsw_run: the DP kernels of the same resident batches alone (the `value` of rounds 1-5)"}
+                             if gcups_k else None),
             "config": {"workload": args.workload, "seeds_per_gpu": n_local if args.scaling == "weak" else None,
                        "pool_seeds": args.pool if args.scaling == "strong" else None, "read_len": spec["read_len"],
                        "band_w": spec["w"], "zdrop": args.zdrop, "variant": "H" if args.variant == 0 else "M", "gaps": args.gaps or "6,1,6,1",
+                       "baseline_config": ("BASELINE.json configs[2] shape: 150 bp PE seeds (left + right extension each), mixed (qlen, tlen) bins via the batch manager"
+                                           if args.workload == "150bp_w100_mixed_bins" else None),
                        "sharding": "per-read task shard (chunk c -> rank c mod N), no collective" if world > 1 else "single GPU",
-                       "kernel_launches_per_step": info["launches"], "resident_batches_per_rank": len(batches), "preset": args.preset,
+                       "kernel_launches_per_step": info["launches"], "resident_batches_per_rank": nb, "preset": args.preset,
                        "cpu_affinity": cpu_list_str(cpu_affinity), "rank_cpus_pinned": bool(os.environ.get("BSW_RANK_CPUS")) or repinned,
                        "ranks": [{"rank": int(r[0]), "gpu_bdf": "%04x:%02x:%02x.0" % (int(r[1]), int(r[2]), int(r[3])), "numa_node": int(r[4]),
                                   "repinned_after_hip_check": bool(r[5]), "library_slot_threads_pinned_cpus": int(r[6]),
-                                  "ms_per_step": round(r[7], 4), "rank_cpus": int(r[8])} for r in rank_rows],
+                                  "ms_per_step": round(r[7], 4), "rank_cpus": int(r[8]), "ms_per_step_kernels_only": round(r[9], 4)} for r in rank_rows],
                        "ms_per_step_min_max_over_ranks": [round(min(r[7] for r in rank_rows), 4), round(max(r[7] for r in rank_rows), 4)],
-                       "setup_s": round(setup_s, 1) if args.scaling == "strong" else None,
+                       "setup_s": round(setup_s, 1), "gen_threads": gen_threads,
                        "rank0_chunk_cells_sample": ({"every": args.sample_stride, "chunk_seeds": chunk, "generator_seed": "5000 + chunk index", "cells": sample_cells}
                                                     if args.scaling == "strong" else None)},
             "extensions_per_s": round(ext_all * args.steps / dt_all, 1),
@@ -794,152 +825,122 @@ def main():
             "cells_per_step": cells_all,
             "nominal_gcups_qlen_x_tlen": round(nominal_all * args.steps / dt_all / 1e9, 3),
             "roofline": {
-                "bound": "valu", "ops_per_cell": VALU_OPS_PER_CELL,
+                "bound": "valu", "kernel": "bsw_lane2_kernel / bsw_lane2l_kernel (the DP launches of a step)", "ops_per_cell": VALU_OPS_PER_CELL,
                 "achieved": round(tops, 4), "peak": round(PEAK_VALU_TOPS, 2), "unit": "T lane-ops/s",
                 "frac": round(tops / PEAK_VALU_TOPS, 5),
-                "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"), "valu_issue_busy": pmc.get("valu_issue_busy"),
+                "frac_is": "the algorithmic model: 15 integer lane-ops per counted cell / the DP kernels' time / peak",
+                "frac_measured": (round(cells * ipc / (dp_avg * 1e-3) / 1e12 / PEAK_VALU_TOPS, 5) if ipc else None),
+                "frac_measured_is": "VALU lane-instructions the kernels actually issued per counted cell (rocprofv3 SQ_INSTS_VALU x 64 / cells) in place of the 15-op model",
+                "valu_insts_per_cell": ipc, "valu_issue_busy": pmc.get("valu_issue_busy"),
+                "waves_per_simd_avg": pmc.get("waves_per_simd_avg"),
                 "traffic": traffic, "traffic_kernels": pmc.get("traffic_kernels"),
                 "counters_source": pmc_src,
-                "issue_ceiling": issue_ceiling(pmc, cells, kavg_ms, 1 if spec["read_len"] > 150 else 2),
-                "kernel_ms_avg": round(kavg_ms, 4),
+                "issue_ceiling": issue_ceiling(pmc, cells, dp_avg, waves),
+                "kernel_ms_avg": round(dp_avg, 4), "kernel_ms_is": "DP part of one step on rank 0: all DP launches of its %d resident batches (HIP events)" % nb,
                 "note": "integer max/add DP at ~0.02 B/cell: VALU issue binds, not HBM and not MFMA; see roofline_hbm",
             },
             "roofline_hbm": {
-                "bound": "hbm", "achieved": round(alg_bytes / (kavg_ms * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,
-                "unit": "GB/s", "frac": round(alg_bytes / (kavg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
-                "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,
+                "bound": "hbm", "achieved": round(alg_bytes / (dp_avg * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": round(alg_bytes / (dp_avg * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
+                "algorithmic_bytes_per_step": alg_bytes, "traffic": traffic,
             },
         }
-        if e2e_dt is not None:
-            out["e2e"] = {
-                "seeds_per_s": round(tasks_all / e2e_all, 1), "gcups": round(cells_all / e2e_all / 1e9, 1),
-                "ratio_to_hbm_resident": round((cells_all / e2e_all / 1e9) / gcups, 3),
-                "pack_threads": 4, "host_threads": "4 slot threads (validate + count), no host packing", "reps_median_of": args.e2e_reps,
-                "pcie_h2d_GBps": round((harena_used(tasks) + len(tasks) * 60) * world / e2e_all / 1e9, 1),
-                "path": "bsw_submit: registered host arena DMA'd as is, pack + bin on the GPU, results DMA'd into registered host memory",
-                "bytes_per_seed_h2d": round((harena_used(tasks) + len(tasks) * 60) / max(len(tasks), 1), 1),
-                "bit_exact_vs_resident_run": e2e_same,
-                "spread": spread(e2e_runs, len(tasks)),
-            }
-            if e2e_stream is not None:
-                out["e2e"]["stream_two_in_flight"] = {
-                    "seeds_per_s": round(len(tasks) / e2e_stream[0], 1), "gcups": round(cells / e2e_stream[0] / 1e9, 1),
-                    "ratio_to_hbm_resident": round((cells / e2e_stream[0] / 1e9) / gcups, 3), "host_threads": stream_threads("bytes"),
-                    "batches_timed": 16, "bit_exact_vs_resident_run": e2e_stream[1]}
-        if packed_leg is not None:
-            pdt, psame, pbytes, pstream, qdt, qsame, pruns, qruns_ = packed_leg
-            out["e2e_packed_input"] = {
-                "seeds_per_s": round(len(tasks) / pdt, 1), "gcups": round(cells / pdt / 1e9, 1),
-                "ratio_to_hbm_resident": round((cells / pdt / 1e9) / gcups, 3), "host_threads": "4 slot threads", "reps_median_of": args.e2e_reps,
-                "path": "bsw_submit_packed: sequences 4-bit packed by the caller (16 bases per uint64, the device layout) in a registered arena, "
-                        "DMA'd straight into the sequence buffer, no pack kernel; packing itself is not timed (the caller keeps its reads packed)",
-                "bytes_per_seed_h2d": round((pbytes + len(tasks) * 44) / max(len(tasks), 1), 1),
-                "bit_exact_vs_resident_run": psame, "spread": spread(pruns, len(tasks)),
-                "stream_two_in_flight": {"seeds_per_s": round(len(tasks) / pstream[0], 1), "gcups": round(cells / pstream[0] / 1e9, 1),
-                                         "ratio_to_hbm_resident": round((cells / pstream[0] / 1e9) / gcups, 3),
-                                         "host_threads": stream_threads("packed"), "batches_timed": 16,
-                                         "bit_exact_vs_resident_run": pstream[1]},
-                "pair_records": {"seeds_per_s": round(len(tasks) / qdt, 1), "gcups": round(cells / qdt / 1e9, 1),
-                                 "ratio_to_hbm_resident": round((cells / qdt / 1e9) / gcups, 3), "bytes_per_seed_d2h": 32,
-                                 "path": "bsw_config.result_format = BSW_RESULT_PAIR: the RTL's 5-word record alone comes back (32 of 96 bytes per seed)",
-                                 "eight_fields_equal_full_records": qsame, "spread": spread(qruns_, len(tasks))}}
-        if ref_leg is not None and world == 1:
-            rdt, rcells, rsame, rbytes, rlp, rruns = ref_leg
-            out["e2e_device_reference"] = {
-                "seeds_per_s": round(n_local / rdt, 1), "gcups": round(rcells / rdt / 1e9, 1),
-                "ratio_to_hbm_resident": round((n_local / rdt) / (tasks_all * args.steps / dt_all), 3),
-                "host_threads": "4 slot threads", "reps_median_of": args.e2e_reps,
-                "path": "bsw_submit_ref: %d Mbp synthetic genome resident in HBM (2 bits/base), reads DMA'd from registered host memory, "
-                        "targets fetched and left flanks mirrored on the GPU" % (rlp // 1_000_000),
-                "bytes_per_seed_h2d": round((rbytes + n_local * (44 + 16 + 16)) / max(n_local, 1), 1),
-                "bit_exact_vs_resident_fetch_path": rsame, "spread": spread(rruns, n_local),
-            }
-            if ref_stream is not None:
-                out["e2e_device_reference"]["stream_two_in_flight"] = {
-                    "seeds_per_s": round(n_local / ref_stream[0], 1), "gcups": round(rcells / ref_stream[0] / 1e9, 1),
-                    "ratio_to_hbm_resident": round((n_local / ref_stream[0]) / (tasks_all * args.steps / dt_all), 3),
-                    "host_threads": stream_threads("ref"), "batches_timed": 16, "bit_exact_vs_single_submit": ref_stream[1]}
+        # ---- PCIe-inclusive legs: job rate = all ranks' seeds / the slowest rank's time; per-rank rates beside it ----
+        if legs:
+            n_job = tasks_all
+            cores_box = os.cpu_count()
+
+            def leg_obj(name, path, cells_job, extra=None):
+                k = LEG_NAMES.index(name)
+                ts = [r[L0 + k] for r in rank_rows]
+                cpu = [r[L0 + len(LEG_NAMES) + k] for r in rank_rows]
+                t = max(ts)
+                rate = n_job / t
+                o = {"seeds_per_s": round(rate, 1), "gcups": round(cells_job / t / 1e9, 1),
+                     "ratio_to_hbm_resident": round((cells_job / t / 1e9) / gcups, 3) if cells_job == cells_all else round(rate / (tasks_all * args.steps / dt_all), 3),
+                     "ratio_to_kernels_only": (round((cells_job / t / 1e9) / gcups_k, 3) if gcups_k and cells_job == cells_all else None),
+                     "path": path, "bit_exact": legs[name]["same"],
+                     "per_rank_seeds_per_s": [round(r[10] / x, 1) if x else None for r, x in zip(rank_rows, ts)],
+                     "host_cost": dict(legs[name]["host"], cpu_s_per_M_seeds_max_over_ranks=round(max(cpu), 4),
+                                       cores_to_feed_one_gpu_at_this_rate=round(max(cpu) * (rate / world) / 1e6, 2),
+                                       cores_to_feed_8_gpus_at_this_rate=round(max(cpu) * (rate / world) / 1e6 * 8, 1), cores_of_this_box=cores_box)}
+                if len(legs[name]["runs"]) > 1:
+                    o["reps_median_of"] = len(legs[name]["runs"])
+                    o["spread"] = spread(legs[name]["runs"], n_local)
+                else:
+                    o["batches_timed"] = 2 * args.stream_reps
+                    o["in_flight"] = "two submits in ONE context (tickets: bsw_submit_t / bsw_wait_ticket), %d slot threads" % args.e2e_slots
+                if extra:
+                    o.update(extra)
+                return o
+            bps = harena_used(tasks) / max(len(tasks), 1)
+            out["e2e"] = leg_obj("e2e", "bsw_submit: registered host arena DMA'd as is, pack + bin on the GPU, results DMA'd into registered host memory",
+                                 cells_all, {"bytes_per_seed_h2d": round(bps + 60, 1), "pcie_h2d_GBps": round((bps + 60) * n_job / max(r[L0] for r in rank_rows) / 1e9, 1)})
+            out["e2e"]["stream_two_in_flight"] = leg_obj("e2e_stream", "the same, a stream of submits kept two deep", cells_all)
+            out["e2e_packed_input"] = leg_obj("packed", "bsw_submit_packed: sequences 4-bit packed by the caller (16 bases per uint64, the device layout) in a registered arena, "
+                                              "DMA'd straight into the sequence buffer, no pack kernel; packing itself is not timed (the caller keeps its reads packed)",
+                                              cells_all, {"bytes_per_seed_h2d": round((legs["packed"]["bytes"] + len(tasks) * 44) / max(len(tasks), 1), 1)})
+            out["e2e_packed_input"]["stream_two_in_flight"] = leg_obj("packed_stream", "the same, a stream of submits kept two deep", cells_all)
+            out["e2e_packed_input"]["pair_records"] = leg_obj("packed_pairs", "bsw_config.result_format = BSW_RESULT_PAIR: the RTL's 5-word record alone comes back (32 of 96 bytes per seed)",
+                                                              cells_all, {"bytes_per_seed_d2h": 32})
+            if "ref" in legs:
+                out["e2e_device_reference"] = leg_obj("ref", "bsw_submit_ref: %d Mbp synthetic genome resident in HBM (2 bits/base), reads DMA'd from registered host memory, "
+                                                      "targets fetched and left flanks mirrored on the GPU" % (legs["ref"]["lp"] // 1_000_000), refcells_all,
+                                                      {"bytes_per_seed_h2d": round((legs["ref"]["bytes"] + n_local * (44 + 16 + 16)) / max(n_local, 1), 1)})
+                out["e2e_device_reference"]["stream_two_in_flight"] = leg_obj("ref_stream", "the same, a stream of submits kept two deep", refcells_all)
         if world == 1 and not args.no_cpu_baseline and tasks is not None:
-            orc = graft.load_oracle()
-            ncpu = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)
-            ns = min(args.cpu_sample, len(tasks))
-            runs = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                ref = orc.pair_batch(params, tasks[:ns], nthreads=ncpu)
-                runs.append(time.perf_counter() - t1)
-            dcpu = float(np.median(runs))
-            ccells = cells_of(ref)
-            n1 = min(ns, 30_000)
-            t1 = time.perf_counter()
-            orc.pair_batch(params, tasks[:n1], nthreads=1)
-            d1 = time.perf_counter() - t1
-            c1 = cells_of(ref[:n1])
-            # the strong CPU baseline: the same sample through the inter-task AVX2 kernel (16 seeds per __m256i), checked
-            # byte for byte against the scalar oracle's result batch
-            nsv = len(tasks)                                   # the whole batch: the vector kernel needs < 0.5 s for it
-            sruns = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                sref = orc.pair_batch_avx2(params, tasks[:nsv], nthreads=ncpu)
-                sruns.append(time.perf_counter() - t1)
-            dsimd = float(np.median(sruns))
-            out["cpu_baseline"] = {
-                "value": round(cells_of(sref) / dsimd / 1e9, 4), "unit": "GCUPS", "cores": ncpu, "kind": "port",
-                "impl": "ours-avx2: inter-task SIMD ksw_extend2, 16 seeds per __m256i (int16 lanes), oracle/ksw_extend_avx2.c",
-                "sample": "all %d seeds of the same batch, -O3 -march=x86-64-v3, %d pthreads, median of 3 runs (%s s)"
-                          % (nsv, ncpu, "/".join("%.2f" % r for r in sruns)),
-                "bit_exact_vs_scalar_oracle": bool(sref[:ns].tobytes() == ref.tobytes()),
-                "bit_exact_vs_gpu": bool(sref.tobytes() == res.tobytes()),
-                "scalar": {"value": round(ccells / dcpu / 1e9, 4), "cores": ncpu, "kind": "port",
-                           "impl": "scalar C oracle (bwa's ksw_extend is scalar code too)", "sample_seeds": ns,
-                           "runs_s": "/".join("%.2f" % r for r in runs), "single_thread_gcups": round(c1 / d1 / 1e9, 4)},
-            }
-            nchk = min(args.check, ns)
-            out["parity_spot_check"] = {"seeds": nchk, "bit_exact": bool(res[:nchk].tobytes() == ref[:nchk].tobytes()),
-                                        "cells_gpu_eq_cpu_on_sample": bool(cells_of(res[:ns]) == ccells), "sample_seeds": ns}
+            out.update(cpu_legs(host, params, tasks, res, args))
     if out is not None and world == 1 and not args.no_extra and not args.spec and args.scaling == "weak":
-        # BASELINE.json also asks for 250 bp batches; reported beside the headline, never part of `value`
+        # BASELINE.json configs[1] (single bin) and the 250 bp shape of configs[4]; reported beside the headline, never part of `value`
         extra = {}
-        for wl in ("250bp_w500", "150bp_w100_mixed_bins"):
+        for wl in ("150bp_w100_single_bin", "250bp_w500", "150bp_w100_mixed_bins"):
             if wl == args.workload:
                 continue
             sp2 = dict(WORKLOADS[wl])
             p2 = host.default_params(variant=args.variant, zdrop=args.zdrop, w=sp2["w"])
-            t2, a2 = host.synth_tasks(args.tasks, seed=2000, **sp2)
-            b2 = ctx.upload(p2, t2)
-            ctx.run(b2); ctx.sync(); ctx.run_history()
+            a2 = host.HostArena(host.synth_arena_bound(args.other_seeds, **sp2) + 4096)
+            t2, _ = host.synth_tasks(args.other_seeds, arena=a2.u8, seed=2000, **sp2)
+            b2 = ctx.upload_raw(p2, t2)
+            ctx.run(b2); ctx.run_staged(b2); ctx.sync(); ctx.run_history2()
             for _ in range(3):
                 ctx.run(b2)
-            ctx.sync()
-            ms = float(np.mean(ctx.run_history()))
+            for _ in range(3):
+                ctx.run_staged(b2)
+            h2 = ctx.run_history2()
+            ms, ms_st, ms_pb = float(np.mean([h[0] for h in h2[:3]])), float(np.mean([h[0] for h in h2[3:]])), float(np.mean([h[1] for h in h2[3:]]))
             r2 = ctx.download(b2)
-            g2 = cells_of(r2) / (ms * 1e-3) / 1e9
-            pm2, src2 = pmc_summary(wl, args.tasks)
-            extra[wl] = {"gcups": round(g2, 1), "ms_per_step": round(ms, 3), "seeds": args.tasks,
-                         "roofline_frac": round(g2 * 1e9 * VALU_OPS_PER_CELL / 1e12 / PEAK_VALU_TOPS, 4), "kernel_launches_per_step": b2.info()["launches"],
+            c2 = cells_of(r2)
+            g2 = c2 / (ms * 1e-3) / 1e9
+            pm2, src2 = pmc_summary(wl, args.other_seeds)
+            extra[wl] = {"gcups": round(c2 / (ms_st * 1e-3) / 1e9, 1), "ms_per_step": round(ms_st, 3), "pack_bin_ms": round(ms_pb, 3), "seeds": args.other_seeds,
+                         "gcups_kernels_only": round(g2, 1), "ms_per_step_kernels_only": round(ms, 3),
+                         "roofline_frac": round(c2 * VALU_OPS_PER_CELL / ((ms_st - ms_pb) * 1e-3) / 1e12 / PEAK_VALU_TOPS, 4), "kernel_launches_per_step": b2.info()["launches"],
                          "valu_insts_per_cell": pm2.get("valu_lane_insts_per_cell"), "valu_issue_busy": pm2.get("valu_issue_busy"),
                          "traffic": (int((2 * pm2["FETCH_SIZE_KiB"] + pm2["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in pm2 else None),
                          "counters": src2.get("status")}
             b2.free()
+            a2.free()
         out["other_workloads"] = extra
-        if args.pe_seeds > 0 and args.workload != "150bp_w100_mixed_bins":
-            out["pe_mixed_bins"] = pe_mixed_leg(host, ctx, args, cpu_affinity, args.pe_seeds)
         out["other_paths"] = side_paths(host, local_rank)
         if not args.no_e2e:
             # the same submit path when the caller's memory is NOT registered: host threads gather into pinned staging
-            t3, a3 = host.synth_tasks(args.tasks, seed=1000, **spec)
+            n3 = min(n_local, args.other_seeds)
+            t3, a3 = host.synth_tasks(n3, seed=1000, **spec)
             with host.BswContext(device=local_rank, kernel=args.kernel, streams=4, pack_threads=4, chunk_tasks=chunk) as c3:
                 o3 = np.ones(len(t3), dtype=host.RESULT)
                 c3.extend_pairs(params, t3, out=o3)
+                s0 = c3.host_stats()
                 t1 = time.perf_counter()
                 r3 = c3.extend_pairs(params, t3, out=o3)
                 d3 = time.perf_counter() - t1
-            out["e2e_unregistered_memory"] = {"seeds_per_s": round(len(t3) / d3, 1), "gcups": round(cells_of(r3) / d3 / 1e9, 1),
-                                              "pack_threads": 4, "path": "bsw_submit: pageable host memory, 4 threads gather into pinned staging"}
+                s1 = c3.host_stats()
+            out["e2e_unregistered_memory"] = {"seeds_per_s": round(len(t3) / d3, 1), "gcups": round(cells_of(r3) / d3 / 1e9, 1), "seeds": n3,
+                                              "pack_threads": 4, "path": "bsw_submit: pageable host memory, 4 threads gather into pinned staging",
+                                              "cpu_s_per_M_seeds": round((s1["slot_cpu_ns"] + s1["helper_cpu_ns"] - s0["slot_cpu_ns"] - s0["helper_cpu_ns"]) / 1e9 / n3 * 1e6, 4)}
     ctx.close()
     harena.free()
-    hout.free()
+    if not args.no_e2e:
+        hout.free()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -947,82 +948,62 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def pe_mixed_leg(host, ctx, args, cpu_affinity, n_seeds, steps=3):
-    """BASELINE.json's metric is quoted on 150 bp PE batches (configs[2]: 10 M PE reads, mixed (qlen, tlen) bins through the
-    batch manager).  The same measurement as the headline — inputs resident in HBM, HIP events around every bsw_run — on
-    n_seeds left + right seeds with seed length ~U[19, 60] at a uniform position, 5 % junk reads, Ns: resident batches of
-    32 x 128 Ki seeds (a batch holds < 4 GiB of bases), every chunk its own generator seed, generated side by side on this
-    rank's CPUs while the previous group uploads.  Never part of `value`."""
-    from concurrent.futures import ThreadPoolExecutor
-    wl = "150bp_w100_mixed_bins"
-    spec = dict(WORKLOADS[wl])
-    params = host.default_params(variant=args.variant, zdrop=args.zdrop, w=spec["w"])
-    chunk, per_batch = 131072, 32
-    nchunks = (n_seeds + chunk - 1) // chunk
-    groups = [list(range(i, min(i + per_batch, nchunks))) for i in range(0, nchunks, per_batch)]
-    gb = per_batch * host.synth_arena_bound(chunk, **spec) + 4096
-    arenas = [host.HostArena(gb) for _ in range(2 if len(groups) > 1 else 1)]
-    pool = ThreadPoolExecutor(max_workers=max(1, min(len(cpu_affinity or [0]), 32)))
-    t0 = time.perf_counter()
-
-    def generate(gi):
-        grp, ar = groups[gi], arenas[gi % len(arenas)]
-        sizes = [min(chunk, n_seeds - c * chunk) for c in grp]
-        tg = np.zeros(int(sum(sizes)), dtype=host.TASK)
-        offs = np.concatenate([[0], np.cumsum([host.synth_arena_bound(sz, **spec) for sz in sizes])]).astype(np.int64)
-        starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-
-        def one(k):
-            t, _ = host.synth_tasks(sizes[k], arena=ar.u8[int(offs[k]):], seed=7000 + grp[k], **spec)
-            tg[int(starts[k]):int(starts[k]) + sizes[k]] = t
-        return tg, [pool.submit(one, k) for k in range(len(grp))]
-
-    batches, sides = [], 0
-    nxt = generate(0)
-    for gi in range(len(groups)):
-        tg, futs = nxt
-        for f in futs:
-            f.result()
-        nxt = generate(gi + 1) if gi + 1 < len(groups) else None
-        batches.append(ctx.upload(params, tg))
-        sides += int((tg["lqlen"] > 0).sum() + (tg["rqlen"] > 0).sum())
-    pool.shutdown()
-    setup_s = time.perf_counter() - t0
-    for ar in arenas:
-        ar.free()
-    for b in batches:
-        ctx.run(b)
-    ctx.sync(); ctx.run_history()
+def cpu_legs(host, params, tasks, res, args):
+    """The CPU beside the GPU (rank 0, N = 1): the scalar oracle on a bounded sample, the inter-task AVX2 port on the whole batch
+    at the 1-GPU box's CPU share (16 threads) and, when the process may use more CPUs than that, on ALL of them."""
+    orc = graft.load_oracle()
+    avail = len(os.sched_getaffinity(0))
+    ncpu = args.cpu_threads or min(avail, 16)
+    ns = min(args.cpu_sample, len(tasks))
+    runs = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        ref = orc.pair_batch(params, tasks[:ns], nthreads=ncpu)
+        runs.append(time.perf_counter() - t1)
+    dcpu = float(np.median(runs))
+    ccells = cells_of(ref)
+    n1 = min(ns, 30_000)
     t1 = time.perf_counter()
-    for _ in range(steps):
-        for b in batches:
-            ctx.run(b)
-    ctx.sync()
-    wall = time.perf_counter() - t1
-    kms = ctx.run_history()
-    step_ms = [float(sum(kms[i:i + len(batches)])) for i in range(0, len(kms), len(batches))]
-    cells, launches = 0, 0
-    for b in batches:
-        r = ctx.download(b)
-        cells += cells_of(r)
-        launches += b.info()["launches"]
-        b.free()
-    ms = float(np.mean(step_ms))
-    gc = cells / (ms * 1e-3) / 1e9
-    pmc, pmc_src = pmc_summary(wl, None, key=wl + "@4194304")      # the pass on one 32 x 128 Ki-seed resident batch (tools/profile_r5.sh), else the 1 M-seed one
-    tops = cells * VALU_OPS_PER_CELL / (ms * 1e-3) / 1e12
-    return {"workload": wl, "config": "BASELINE.json configs[2] shape: %d PE seeds (left + right extension each), mixed bins via the batch manager" % n_seeds,
-            "seeds": n_seeds, "extensions": sides, "resident_batches": len(batches), "gcups": round(gc, 1), "ms_per_step": round(ms, 3),
-            "ms_per_step_wall": round(wall / steps * 1e3, 3), "steps": steps, "seeds_per_s": round(n_seeds / (ms * 1e-3), 1),
-            "cells_per_step": cells, "kernel_launches_per_step": launches, "setup_s": round(setup_s, 1),
-            "roofline": {"bound": "valu", "ops_per_cell": VALU_OPS_PER_CELL, "achieved": round(tops, 4), "peak": round(PEAK_VALU_TOPS, 2),
-                         "unit": "T lane-ops/s", "frac": round(tops / PEAK_VALU_TOPS, 5),
-                         "valu_insts_per_cell": pmc.get("valu_lane_insts_per_cell"), "valu_issue_busy": pmc.get("valu_issue_busy"),
-                         "waves_per_simd_avg": pmc.get("waves_per_simd_avg"),
-                         "traffic_per_counted_step": (int((2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024) if "FETCH_SIZE_KiB" in pmc else None),
-                         "counters_source": dict(pmc_src, note="collected on a %d-seed resident batch of this workload (bench.py --workload %s --tasks %d)%s"
-                                                 % (pmc.get("seeds_per_gpu", 0), wl, pmc.get("seeds_per_gpu", 0),
-                                                    ": the size of this leg's batches (32 x 128 Ki seeds)" if pmc.get("seeds_per_gpu") == 4194304 else ""))}}
+    orc.pair_batch(params, tasks[:n1], nthreads=1)
+    d1 = time.perf_counter() - t1
+    c1 = cells_of(ref[:n1])
+    # the strong CPU baseline: the whole batch through the inter-task AVX2 kernel (16 seeds per __m256i), checked byte for byte
+    # against the scalar oracle's result batch and against the GPU's
+    nsv = len(tasks)
+
+    def avx(nth):
+        sr = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            sref = orc.pair_batch_avx2(params, tasks[:nsv], nthreads=nth)
+            sr.append(time.perf_counter() - t1)
+        return sref, sr
+    sref, sruns = avx(ncpu)
+    dsimd = float(np.median(sruns))
+    out = {"cpu_baseline": {
+        "value": round(cells_of(sref) / dsimd / 1e9, 4), "unit": "GCUPS", "cores": ncpu, "kind": "port",
+        "impl": "ours-avx2: inter-task SIMD ksw_extend2, 16 seeds per __m256i (int16 lanes), oracle/ksw_extend_avx2.c",
+        "sample": "all %d seeds of the same batch, -O3 -march=x86-64-v3, %d pthreads, median of 3 runs (%s s)"
+                  % (nsv, ncpu, "/".join("%.2f" % r for r in sruns)),
+        "bit_exact_vs_scalar_oracle": bool(sref[:ns].tobytes() == ref.tobytes()),
+        "bit_exact_vs_gpu": bool(sref.tobytes() == res.tobytes()),
+        "cpus_this_process_may_use": avail, "cpus_of_the_box": os.cpu_count(),
+        "scalar": {"value": round(ccells / dcpu / 1e9, 4), "cores": ncpu, "kind": "port",
+                   "impl": "scalar C oracle (bwa's ksw_extend is scalar code too)", "sample_seeds": ns,
+                   "runs_s": "/".join("%.2f" % r for r in runs), "single_thread_gcups": round(c1 / d1 / 1e9, 4)},
+    }}
+    if avail > ncpu and not args.cpu_threads:
+        sall, aruns = avx(avail)
+        out["cpu_baseline"]["all_cores"] = {"value": round(cells_of(sall) / float(np.median(aruns)) / 1e9, 4), "unit": "GCUPS", "cores": avail, "kind": "port",
+                                            "impl": "the same AVX2 port on every CPU the process may use", "runs_s": "/".join("%.2f" % r for r in aruns),
+                                            "bit_exact_vs_gpu": bool(sall.tobytes() == res.tobytes())}
+    else:
+        out["cpu_baseline"]["all_cores"] = {"value": out["cpu_baseline"]["value"], "cores": ncpu, "note": "the process may use %d CPUs: the %d-thread figure IS the all-core figure of this box's share" % (avail, ncpu)}
+    nchk = min(args.check, ns)
+    out["parity_spot_check"] = {"seeds": nchk, "bit_exact": bool(res[:nchk].tobytes() == ref[:nchk].tobytes()),
+                                "cells_gpu_eq_cpu_on_sample": bool(cells_of(res[:ns]) == ccells), "sample_seeds": ns,
+                                "whole_batch_vs_avx2_port": bool(sref.tobytes() == res.tobytes())}
+    return out
 
 
 def harena_used(tasks):

@@ -320,7 +320,16 @@ static void gather_packed(const bsw_task *tasks, const bsw_dtask *dt, size_t n, 
 }
 
 /* copy the sequences of tasks[0..n) into the pinned staging arena laid out by prepare_chunk */
-static void gather_raw(const bsw_task *tasks, const bsw_rawoff *ro, size_t n, bool dev_targets, uint8_t *dst, int threads, bool rev_left = false)
+static inline uint64_t thread_cpu_ns()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+/* helper_ns: CPU time of the helper threads started here (the calling thread accounts for itself) */
+static void gather_raw(const bsw_task *tasks, const bsw_rawoff *ro, size_t n, bool dev_targets, uint8_t *dst, int threads, bool rev_left = false,
+                       std::atomic<uint64_t> *helper_ns = nullptr)
 {
     auto work = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
@@ -342,7 +351,7 @@ static void gather_raw(const bsw_task *tasks, const bsw_rawoff *ro, size_t n, bo
     const size_t per = (n + (size_t)threads - 1) / (size_t)threads;
     for (int k = 1; k < threads; ++k) {
         const size_t lo = per * (size_t)k, hi = std::min(n, lo + per);
-        if (lo < hi) th.emplace_back(work, lo, hi);
+        if (lo < hi) th.emplace_back([&work, lo, hi, helper_ns]() { const uint64_t c0 = thread_cpu_ns(); work(lo, hi); if (helper_ns) *helper_ns += thread_cpu_ns() - c0; });
     }
     work(0, std::min(n, per));
     for (auto &t : th) t.join();
@@ -581,15 +590,24 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
     if ((he = st.d_raw.reserve(rawb + RAW_FRONT + RAW_SLACK)) != hipSuccess || (he = st.d_seq.reserve(ci.words + 4)) != hipSuccess ||
         (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_roff.reserve(n + 1)) != hipSuccess ||
         (he = st.d_order.reserve(order_capacity(n))) != hipSuccess || (he = st.d_bins.reserve(BSW_BIN_WORDS)) != hipSuccess ||
+        (he = st.d_nflag.reserve(n + 4)) != hipSuccess || (he = st.d_keys.reserve(n + 1)) != hipSuccess ||
         (he = st.d_out.reserve(n + 1)) != hipSuccess || (n_desc && (he = st.d_desc.reserve(n_desc)) != hipSuccess))
         return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
     {
         std::unique_lock<std::mutex> lk;
         if (turn) {
             lk = std::unique_lock<std::mutex>(turn->gate->mu);
-            turn->gate->cv.wait(lk, [&]() { return turn->gate->next == turn->seq || *turn->abort_flag; });
-            if (*turn->abort_flag) return fail(e, BSW_E_HIP, "aborted: another chunk failed");
-            if (turn->gate->last) HIPCHK(e, hipStreamWaitEvent(s, turn->gate->last, 0));
+            /* the turns of a device are taken strictly in order, also by chunks that have nothing to do any more (their submit
+             * failed elsewhere): chunks of OTHER submits queue behind them */
+            turn->gate->cv.wait(lk, [&]() { return turn->gate->next == turn->seq; });
+            hipError_t we = hipSuccess;
+            if (!*turn->abort_flag && turn->gate->last) we = hipStreamWaitEvent(s, turn->gate->last, 0);
+            if (*turn->abort_flag || we != hipSuccess) {
+                if (turn->passed) *turn->passed = true;
+                turn->gate->next = turn->seq + 1;
+                turn->gate->cv.notify_all();
+                return we != hipSuccess ? fail(e, BSW_E_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(we)) : fail(e, BSW_E_HIP, "aborted: another chunk failed");
+            }
         }
         hipError_t ce = hipSuccess;
         if (ci.packed) {               /* the words are the device layout already: they land in `seq`, nothing is packed */
@@ -601,6 +619,7 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
         if (turn) {
             if (ce == hipSuccess) ce = hipEventRecord(turn->ev, s);
             if (ce == hipSuccess) turn->gate->last = turn->ev;
+            if (turn->passed) *turn->passed = true;
             turn->gate->next = turn->seq + 1;          /* pass the turn on even on failure: nobody may wait forever */
             turn->gate->cv.notify_all();
         }
@@ -609,8 +628,8 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
     (void)dev_targets;
     if (!ci.packed)
         HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, ci.raw_bias, (uint32_t)n, ci.rev_left ? 1 : 0,
-                                   ref ? ref->d_pac[dev_index] : nullptr, ref ? ref->l_pac : 0, ref ? st.d_desc.p : nullptr, st.d_seq.p, s));
-    HIPCHK(e, bsw::launch_bin(ci.bp, st.d_seq.p, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
+                                   ref ? ref->d_pac[dev_index] : nullptr, ref ? ref->l_pac : 0, ref ? st.d_desc.p : nullptr, st.d_seq.p, st.d_nflag.p, s));
+    HIPCHK(e, bsw::launch_bin(ci.bp, st.d_seq.p, ci.packed ? nullptr : st.d_nflag.p, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_keys.p, st.d_order.p, s));
     if (h2d_bytes) *h2d_bytes = (ci.packed ? ci.words * 8 : rawb + n * sizeof(bsw_rawoff)) + n * sizeof(bsw_dtask) + n_desc * sizeof(bsw_refx);
     return BSW_OK;
 }
@@ -924,10 +943,10 @@ static int run_common(bsw_ctx *ctx, bsw_dev_batch *b, bool staged, const char *w
         stage_t &st = b->st;
         if (!ci.packed) {
             HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, ci.raw_bias, (uint32_t)b->n, ci.rev_left ? 1 : 0,
-                                       nullptr, 0, nullptr, st.d_seq.p, s));
+                                       nullptr, 0, nullptr, st.d_seq.p, st.d_nflag.p, s));
             ++b->launches;
         }
-        HIPCHK(e, bsw::launch_bin(ci.bp, st.d_seq.p, st.d_tasks.p, (uint32_t)b->n, st.d_bins.p, st.d_order.p, s));
+        HIPCHK(e, bsw::launch_bin(ci.bp, st.d_seq.p, ci.packed ? nullptr : st.d_nflag.p, st.d_tasks.p, (uint32_t)b->n, st.d_bins.p, st.d_keys.p, st.d_order.p, s));
         b->launches += 3;
     }
     if (mid) HIPCHK(e, hipEventRecord(mid, s));
@@ -950,7 +969,7 @@ extern "C" int bsw_sync(bsw_ctx *ctx)
 {
     if (!ctx) return BSW_E_INVAL;
     errs &e = ctx->err;
-    if (ctx->worker_active) return fail(e, BSW_E_BUSY, "bsw_sync: a bsw_submit is in flight (call bsw_wait)");
+    if (pipeline_busy(ctx)) return fail(e, BSW_E_BUSY, "bsw_sync: a bsw_submit is in flight (call bsw_wait)");
     HIPCHK(e, hipSetDevice(ctx->device0()));
     return sync_stream(ctx, e, ctx->stream0(), ctx->devs[0].events[0]);
 }
@@ -1191,227 +1210,402 @@ static std::vector<std::vector<chunk_span>> plan_chunks(size_t n, size_t chunk, 
     return out;
 }
 
-/* One slot = one host thread + one stream + one set of staging buffers.  Per chunk: host pass (validate, lay out,
- * count) -> wait for the slot's previous chunk -> input DMAs in the device's chunk order -> pack, bin, DP kernels,
- * result DMA.  The host pass of chunk k+S runs while chunk k is still on the GPU: it only needs the pinned host
- * staging, which is free again as soon as chunk k's input DMAs are done. */
-static int slot_worker(bsw_ctx *ctx, const bsw_params &p, const bsw_dparams &dp, const bsw_task *tasks,
-                       const bsw_ref *ref, const bsw_ref_task *rtasks,   /* non-NULL: seeds against the device-resident reference */
-                       bsw_result *out, const std::vector<chunk_span> &chunks, size_t d, size_t s, int gather_threads,
-                       std::atomic<int> &abort_flag, h2d_gate &gate, errs &e, bool packed)
+
+/* ---- the pipeline behind bsw_submit / bsw_submit_packed / bsw_submit_ref -------------------------------------------------
+ * The reference keeps FOUR task batches in flight under one manager (batch_manager.v:343-348 request bits, :434-435 busy
+ * bitmap) and its host polls a status word for completion (DSM + 0x40 busy nibble, :844-854).  Here: up to BSW_MAX_INFLIGHT
+ * submits per context, each a TICKET; the chunks of all of them go through ONE queue per device in submit order, popped by
+ * the device's slot threads — persistent, started by the first submit, pinned next to the card — so that the last chunks of
+ * submit k and the first ones of submit k+1 overlap exactly as two neighbouring chunks of one submit do.
+ * One slot = one host thread + one stream + one set of staging buffers.  Per chunk: host pass (validate, lay out, count) ->
+ * wait for the slot's previous chunk -> input DMAs in the device's chunk order -> pack, bin, DP kernels -> result DMA.  The
+ * host pass of the slot's next chunk runs while its previous one is still on the GPU: it only needs the pinned host staging,
+ * which is free again as soon as that chunk's input DMAs are done. */
+struct ticket_t {
+    uint64_t id = 0;
+    bsw_params p{};
+    bsw_dparams dp{};
+    const bsw_task *tasks = nullptr;
+    const bsw_ref *ref = nullptr;
+    const bsw_ref_task *rtasks = nullptr;      /* non-NULL: seeds against the device-resident reference */
+    bsw_result *out = nullptr;
+    bool packed = false;
+    size_t n = 0;
+    std::atomic<size_t> remaining{0};           /* chunks whose results have not been handed over yet */
+    std::atomic<int> abort{0};                  /* a chunk failed: the others do nothing any more */
+    std::mutex emu;
+    int rc = 0;                                 /* the failure itself, not the chunks it made give up */
+    bool real = false;
+    errs err;
+    bool done = false;                          /* (pipeline::mu) */
+};
+
+struct chunk_job {
+    ticket_t *t = nullptr;
+    chunk_span span{0, 0};
+    size_t seq = 0;                             /* the chunk's place in its device's input-DMA order */
+};
+
+struct dev_pipe {
+    std::deque<chunk_job> q;
+    h2d_gate gate;
+    size_t next_seq = 0;
+};
+
+struct pipeline {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::unique_ptr<dev_pipe>> devs;
+    std::vector<std::thread> threads;
+    std::deque<std::unique_ptr<ticket_t>> live; /* submits not collected by a wait yet, oldest first */
+    uint64_t next_id = 1;
+    bool stop = false;
+    /* what the host side costs (bsw_host_stats): CPU time of the slot threads and of the gather helpers they start, volume */
+    std::atomic<uint64_t> slot_cpu_ns{0}, helper_cpu_ns{0}, seeds{0}, chunks{0}, h2d_bytes{0}, d2h_bytes{0}, submits{0};
+};
+
+static void slot_main(bsw_ctx *ctx, size_t d, size_t s)
 {
-    std::vector<bsw_task> rt_tasks;                 /* ref mode: this chunk's seeds as tasks (left queries by reference) */
-    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
-    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_host = 0, t_staging = 0, t_finish = 0, t_stage = 0;
+    pipeline &pp = *ctx->pipe;
+    dev_pipe &dq = *pp.devs[d];
     dev_state &dev = ctx->devs[d];
-    const size_t S = dev.slots.size();
     stage_t &st = dev.slots[s];
     hipStream_t stream = dev.streams[s];
-    struct { bool active = false; size_t n = 0; char *out = nullptr; bool direct = false, copied = false; } pend;
+    static const bool dbg = getenv("BSW_DEBUG_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    /* the slot's thread (and the gather threads it starts, which inherit the mask) next to its GPU: the host pass streams the
+     * caller's task array into write-combined pinned staging, and that staging is allocated — first touched — from here */
+    pin_this_thread(dev);
+    const hipError_t dev_err = hipSetDevice(dev.device);
     /* BSW_RESULT_PAIR: `out` addresses bsw_pair[n]; the dense 32-byte records come from their own device array */
     const bool pairs = ctx->cfg.result_format == BSW_RESULT_PAIR;
     const size_t rec = pairs ? sizeof(bsw_pair) : sizeof(bsw_result);
     auto d_res = [&]() -> const void * { return pairs ? (const void *)st.d_pair.p : (const void *)st.d_out.p; };
-    bool queued = false;                            /* some async op of the current chunk may be on the stream (set before the first one) */
-    auto bail = [&](int rc) {                       /* wake the slots waiting for their DMA turn; leave nothing in flight */
-        abort_flag = 1;
-        { std::lock_guard<std::mutex> lk(gate.mu); }
-        gate.cv.notify_all();
-        /* a failure after stage_device queued its first copy leaves DMAs out of the caller's registered arena and kernels
-         * in flight although pend.active is still false: drain the stream (with the watchdog) before the error is reported,
-         * so the caller may free or reuse that memory as soon as bsw_wait returns */
-        if (pend.active || queued) { errs quiet; (void)sync_stream(ctx, quiet, stream, dev.events[s]); pend.active = false; queued = false; }
-        return rc;
+    struct { bool active = false; ticket_t *t = nullptr; size_t n = 0; char *out = nullptr; bool direct = false, copied = false; } pend;
+    std::vector<bsw_task> rt_tasks;                 /* ref mode: this chunk's seeds as tasks (left queries by reference) */
+    uint64_t cpu_last = thread_cpu_ns();
+    auto account = [&]() { const uint64_t c = thread_cpu_ns(); pp.slot_cpu_ns += c - cpu_last; cpu_last = c; };
+
+    auto ticket_fail = [&](ticket_t *t, int rc, const errs &er) {
+        std::lock_guard<std::mutex> lk(t->emu);
+        const bool real = er.msg.compare(0, 7, "aborted") != 0;
+        if (!t->rc || (real && !t->real)) { t->rc = rc; t->err = er; t->real = real; }
+        t->abort = 1;
     };
-    /* the slot's thread (and the gather threads it starts, which inherit the mask) next to its GPU: the host pass streams the
-     * caller's task array into write-combined pinned staging, and that staging is allocated — first touched — below, from here */
-    pin_this_thread(dev);
-    hipError_t he = hipSetDevice(dev.device);
-    if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "hipSetDevice: %s", hipGetErrorString(he)));
-    auto finish = [&]() -> int {                    /* the slot's chunk in flight: wait (watchdog), hand the results over */
-        if (!pend.active) return BSW_OK;
+    auto chunk_done = [&](ticket_t *t) {
+        if (t->remaining.fetch_sub(1) == 1) {
+            std::lock_guard<std::mutex> lk(pp.mu);
+            t->done = true;
+            pp.cv_done.notify_all();
+        }
+    };
+    auto finish = [&]() {                           /* the slot's chunk in flight: wait (watchdog), hand the results over */
+        if (!pend.active) return;
         pend.active = false;
+        errs fe;
         int rc = BSW_OK;
         if (!pend.copied) {                         /* kernels done -> result DMA -> done */
-            rc = wait_event(ctx, e, dev.events[s]);
-            if (rc) return rc;
-            const hipError_t ce = hipMemcpyAsync(pend.direct ? (void *)pend.out : (void *)st.h_out.p, d_res(), pend.n * rec, hipMemcpyDeviceToHost, stream);
-            if (ce != hipSuccess) return fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(ce));
-        }
-        rc = sync_stream(ctx, e, stream, dev.events[s]);
-        if (rc) return rc;
-        if (!pend.direct) memcpy(pend.out, st.h_out.p, pend.n * rec);
-        return BSW_OK;
-    };
-    for (size_t k = s; k < chunks.size() && !abort_flag; k += S) {            /* k-th chunk of this device */
-        const bsw_task *ct = tasks ? tasks + chunks[k].base : nullptr;
-        const size_t n = chunks[k].cnt;
-        int rc = BSW_OK;
-        const double t0 = dbg ? tnow() : 0;
-        if (pend.active) rc = wait_event(ctx, e, dev.h2d_done[s]);           /* pinned host staging is free again */
-        if (rc) return bail(rc);
-        const double t1 = dbg ? tnow() : 0;
-        if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess ||
-            (rtasks && (he = st.h_desc.reserve(n + 1)) != hipSuccess))
-            return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
-        chunk_info ci;
-        if (rtasks) {                               /* mem_chain2aln's task extraction fused into the pass; the targets stay on the device */
-            const bsw_ref_task *crt = rtasks + chunks[k].base;
-            const size_t base = chunks[k].base;
-            bsw_refx *rx = st.h_desc.p;
-            size_t so = 0;
-            rc = prepare_chunk_t(e, &p, ctx->cfg.kernel, [&](size_t i, bsw_task &tmp, int &erc) -> const bsw_task * {
-                erc = ref_to_task(e, &p, ref->l_pac, crt[i], base + i, true, nullptr, so, tmp);
-                rx[i] = bsw_refx{crt[i].seed.rbeg - 1, crt[i].seed.rbeg + crt[i].seed.len};
-                return erc ? nullptr : &tmp;
-            }, n, true, st.h_tasks.p, st.h_roff.p, ci, true);
-            if (rc) return bail(rc);
-            if (!ci.direct) {                       /* reads in pageable memory: materialise the tasks for the gather */
-                rt_tasks.resize(n);
-                for (size_t i = 0; i < n && !rc; ++i) rc = ref_to_task(e, &p, ref->l_pac, crt[i], base + i, true, nullptr, so, rt_tasks[i]);
-                if (rc) return bail(rc);
-                ct = rt_tasks.data();
-                gather_offsets(ct, n, true, st.h_roff.p);
+            rc = wait_event(ctx, fe, dev.events[s]);
+            if (!rc) {
+                const hipError_t ce = hipMemcpyAsync(pend.direct ? (void *)pend.out : (void *)st.h_out.p, d_res(), pend.n * rec, hipMemcpyDeviceToHost, stream);
+                if (ce != hipSuccess) rc = fail(fe, BSW_E_HIP, "result DMA: %s", hipGetErrorString(ce));
             }
-        } else {
-            rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci, false, packed);
-            if (rc) return bail(rc);
         }
-        if (!ci.direct) {
-            if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
-            if (packed) gather_packed(ct, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
-            else gather_raw(ct, st.h_roff.p, n, rtasks != nullptr, st.h_raw.p, gather_threads, rtasks != nullptr);
-        }
-        const double t2 = dbg ? tnow() : 0;
-        rc = finish();
-        if (rc) return bail(rc);
+        if (!rc) rc = sync_stream(ctx, fe, stream, dev.events[s]);
+        else { errs quiet; (void)sync_stream(ctx, quiet, stream, dev.events[s]); }     /* leave nothing of the chunk in flight */
+        if (!rc && !pend.direct) memcpy(pend.out, st.h_out.p, pend.n * rec);
+        if (rc) ticket_fail(pend.t, rc, fe);
+        else { pp.d2h_bytes += pend.n * rec; pp.seeds += pend.n; }
+        chunk_done(pend.t);
+    };
+    auto process = [&](const chunk_job &job) {
+        ticket_t *t = job.t;
+        const size_t n = job.span.cnt, base = job.span.base;
+        const bsw_params &p = t->p;
+        const bsw_task *ct = t->tasks ? t->tasks + base : nullptr;
+        errs e;
+        int rc = BSW_OK;
+        hipError_t he;
+        chunk_info ci;
+        bool passed = false, queued = false;         /* the DMA turn has been passed on; some async op of this chunk may be on the stream */
+        const double t0 = dbg ? tnow() : 0;
+        double t1 = t0, t2 = t0;
+        do {
+            if (dev_err != hipSuccess) { rc = fail(e, BSW_E_HIP, "hipSetDevice: %s", hipGetErrorString(dev_err)); break; }
+            if (t->abort) { rc = fail(e, BSW_E_HIP, "aborted: another chunk failed"); break; }
+            if (pend.active && (rc = wait_event(ctx, e, dev.h2d_done[s]))) break;           /* pinned host staging is free again */
+            t1 = dbg ? tnow() : 0;
+            if ((he = st.h_tasks.reserve(n + 1)) != hipSuccess || (he = st.h_roff.reserve(n + 1)) != hipSuccess ||
+                (t->rtasks && (he = st.h_desc.reserve(n + 1)) != hipSuccess)) { rc = fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)); break; }
+            if (t->rtasks) {                        /* mem_chain2aln's task extraction fused into the pass; the targets stay on the device */
+                const bsw_ref_task *crt = t->rtasks + base;
+                bsw_refx *rx = st.h_desc.p;
+                size_t so = 0;
+                rc = prepare_chunk_t(e, &p, ctx->cfg.kernel, [&](size_t i, bsw_task &tmp, int &erc) -> const bsw_task * {
+                    erc = ref_to_task(e, &p, t->ref->l_pac, crt[i], base + i, true, nullptr, so, tmp);
+                    rx[i] = bsw_refx{crt[i].seed.rbeg - 1, crt[i].seed.rbeg + crt[i].seed.len};
+                    return erc ? nullptr : &tmp;
+                }, n, true, st.h_tasks.p, st.h_roff.p, ci, true);
+                if (rc) break;
+                if (!ci.direct) {                   /* reads in pageable memory: materialise the tasks for the gather */
+                    rt_tasks.resize(n);
+                    for (size_t i = 0; i < n && !rc; ++i) rc = ref_to_task(e, &p, t->ref->l_pac, crt[i], base + i, true, nullptr, so, rt_tasks[i]);
+                    if (rc) break;
+                    ct = rt_tasks.data();
+                    gather_offsets(ct, n, true, st.h_roff.p);
+                }
+            } else if ((rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci, false, t->packed))) break;
+            if (!ci.direct) {
+                if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) { rc = fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)); break; }
+                if (t->packed) gather_packed(ct, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
+                else gather_raw(ct, st.h_roff.p, n, t->rtasks != nullptr, st.h_raw.p, std::max(1, ctx->cfg.pack_threads / (int)dev.slots.size()), t->rtasks != nullptr, &pp.helper_cpu_ns);
+            }
+        } while (0);
+        t2 = dbg ? tnow() : 0;
+        if (rc) ticket_fail(t, rc, e);              /* (before the previous chunk reports what this failure did to the context) */
+        finish();                                   /* the slot's previous chunk, whatever became of this one */
         const double t3 = dbg ? tnow() : 0;
-        gate_turn turn;
-        turn.gate = &gate; turn.seq = k; turn.ev = dev.h2d_done[s]; turn.abort_flag = &abort_flag;
-        queued = true;
-        rc = stage_device(e, st, stream, ci, n, rtasks != nullptr, ref, nullptr, &turn, d);
-        if (!rc && pairs && (he = st.d_pair.reserve(n + 1)) != hipSuccess) rc = fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
-        if (!rc) rc = enqueue_batch(e, dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr, fork_for(ctx, stream, true), pairs ? st.d_pair.p : nullptr);
-        if (rc) return bail(rc);
-        char *co = (char *)out + chunks[k].base * rec;
-        pend.direct = is_registered(co, n * rec);
-        if (!pend.direct && (he = st.h_out.reserve(n)) != hipSuccess) return bail(fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)));
-        /* A result copy queued behind its kernels sits at the head of its DMA engine's ring until they finish and holds up
-         * the copies queued to that engine after it (profiles/r2/wire_submit_timeline.txt): the slot thread issues the result
-         * DMA itself once the chunk's kernels are done (it waits for them anyway before it reuses the staging).  Round 2 did
-         * that for the device-reference path only (+7 %) and queued the copy right away for byte and packed input (the host
-         * round trip cost 6 % then).  Re-measured with round 5's kernels (profiles/r5/e2e_late_result_dma.txt): the single
-         * submits are unchanged in the median, the byte path loses its outliers — one pass in five took 16 - 18 ms instead of
-         * 10.4 when an input DMA landed behind a waiting result copy: max / min 1.05 - 1.07 instead of 1.2 - 1.8 — and a stream of
-         * packed submits kept two deep goes from 110 - 113 to 128 - 134 M seeds/s.  BSW_LATE_RESULT=0: the old behaviour. */
-        static const int late_env = getenv("BSW_LATE_RESULT") ? atoi(getenv("BSW_LATE_RESULT")) : -1;     /* (measurements) */
-        const bool late = late_env >= 0 ? late_env != 0 : true;
-        if (!late) he = hipMemcpyAsync(pend.direct ? (void *)co : (void *)st.h_out.p, d_res(), n * rec, hipMemcpyDeviceToHost, stream);
-        else he = hipEventRecord(dev.events[s], stream);
-        if (he != hipSuccess) return bail(fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(he)));
-        pend.copied = !late;
-        pend.active = true; pend.n = n; pend.out = co;
-        queued = false;                             /* from here on finish() / bail() drain through pend */
-        if (dbg) { const double t4 = tnow(); t_staging += t1 - t0; t_host += t2 - t1; t_finish += t3 - t2; t_stage += t4 - t3; }
+        char *co = (char *)t->out + base * rec;
+        uint64_t h2d = 0;
+        if (!rc) {
+            gate_turn turn;
+            turn.gate = &dq.gate; turn.seq = job.seq; turn.ev = dev.h2d_done[s]; turn.abort_flag = &t->abort; turn.passed = &passed;
+            queued = true;
+            rc = stage_device(e, st, stream, ci, n, t->rtasks != nullptr, t->ref, &h2d, &turn, d);
+            if (!rc && pairs && (he = st.d_pair.reserve(n + 1)) != hipSuccess) rc = fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
+            if (!rc) rc = enqueue_batch(e, t->dp, p.variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, ci.plan, st.d_out.p, stream, nullptr, fork_for(ctx, stream, true), pairs ? st.d_pair.p : nullptr);
+        }
+        if (!rc) {
+            pend.direct = is_registered(co, n * rec);
+            if (!pend.direct && (he = st.h_out.reserve(n)) != hipSuccess) rc = fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
+        }
+        if (!rc) {
+            /* A result copy queued behind its kernels sits at the head of its DMA engine's ring until they finish and holds up
+             * the copies queued to that engine after it (profiles/r2/wire_submit_timeline.txt): the slot thread issues the result
+             * DMA itself once the chunk's kernels are done (it waits for them anyway before it reuses the staging).
+             * profiles/r5/e2e_late_result_dma.txt: the byte path loses its outliers (max / min 1.05 - 1.07 instead of 1.2 - 1.8), a
+             * stream of packed submits goes from 110 - 113 to 128 - 134 M seeds/s.  BSW_LATE_RESULT=0: the copy is queued right away. */
+            static const int late_env = getenv("BSW_LATE_RESULT") ? atoi(getenv("BSW_LATE_RESULT")) : -1;     /* (measurements) */
+            const bool late = late_env != 0;
+            if (!late) he = hipMemcpyAsync(pend.direct ? (void *)co : (void *)st.h_out.p, d_res(), n * rec, hipMemcpyDeviceToHost, stream);
+            else he = hipEventRecord(dev.events[s], stream);
+            if (he != hipSuccess) rc = fail(e, BSW_E_HIP, "result DMA: %s", hipGetErrorString(he));
+            else {
+                pend.copied = !late;
+                pend.active = true; pend.t = t; pend.n = n; pend.out = co;
+                pp.h2d_bytes += h2d;
+                pp.chunks += 1;
+            }
+        }
+        if (rc) {
+            /* the turn is passed on whatever happened (chunks of other submits queue behind this one); a failure after the
+             * first input DMA was queued leaves copies out of the caller's registered arena and kernels in flight: drain the
+             * stream (with the watchdog) before the failure is reported, so the caller may free or reuse that memory as soon
+             * as the wait returns */
+            if (!passed) {
+                std::unique_lock<std::mutex> lk(dq.gate.mu);
+                dq.gate.cv.wait(lk, [&]() { return dq.gate.next == job.seq; });
+                dq.gate.next = job.seq + 1;
+                dq.gate.cv.notify_all();
+            }
+            if (queued) { errs quiet; (void)sync_stream(ctx, quiet, stream, dev.events[s]); }
+            ticket_fail(t, rc, e);
+            chunk_done(t);
+        }
+        if (dbg) fprintf(stderr, "[bsw] slot %zu.%zu ticket %llu chunk @%zu n=%zu: wait staging %.3f ms, host pass %.3f, wait prev results %.3f, DMA turn + enqueue %.3f (t0=%.3f)%s\n",
+                         d, s, (unsigned long long)t->id, base, n, t1 - t0, t2 - t1, t3 - t2, tnow() - t3, t0, rc ? " FAILED" : "");
+    };
+
+    std::unique_lock<std::mutex> lk(pp.mu);
+    for (;;) {
+        if (!dq.q.empty()) {
+            const chunk_job job = dq.q.front();
+            dq.q.pop_front();
+            lk.unlock();
+            process(job);
+            account();
+            lk.lock();
+            continue;
+        }
+        if (pend.active) {                          /* nothing queued behind it: hand the chunk in flight over now */
+            lk.unlock();
+            finish();
+            account();
+            lk.lock();
+            continue;
+        }
+        if (pp.stop) break;
+        pp.cv_work.wait(lk);
+        cpu_last = thread_cpu_ns();
     }
-    const double t5 = dbg ? tnow() : 0;
-    const int rc = finish();
-    if (dbg) fprintf(stderr, "[bsw] slot %zu.%zu: wait staging %.2f ms, host pass %.2f, wait results %.2f, DMA turn + enqueue %.2f, drain %.2f\n",
-                     d, s, t_staging, t_host, t_finish, t_stage, tnow() - t5);
-    return rc ? bail(rc) : BSW_OK;
 }
 
-static int submit_pipeline(bsw_ctx *ctx, bsw_params p, const bsw_task *tasks, const bsw_ref *ref, const bsw_ref_task *rtasks,
-                           size_t n, bsw_result *out, bool packed = false)
+static int pipeline_start(bsw_ctx *ctx)
 {
-    bsw_dparams dp;
-    int rc = check_params(ctx->err, &p, &dp);
-    if (rc) return rc;
+    if (ctx->pipe) return BSW_OK;
+    pipeline *pp = new pipeline();
     const size_t G = ctx->devs.size(), S = (size_t)ctx->cfg.streams;
-    const std::vector<std::vector<chunk_span>> chunks = plan_chunks(n, ctx->cfg.chunk_tasks, G);
-    struct wk { size_t d, s; int rc = 0; errs e; };
-    std::vector<wk> ws;
+    for (size_t d = 0; d < G; ++d) pp->devs.emplace_back(new dev_pipe());
+    ctx->pipe = pp;
     for (size_t s = 0; s < S; ++s)
-        for (size_t d = 0; d < G; ++d)
-            if (s < chunks[d].size()) { wk w; w.d = d; w.s = s; ws.push_back(w); }
-    if (ws.empty()) return BSW_OK;
-    const int gather_threads = std::max(1, ctx->cfg.pack_threads / (int)ws.size());
-    std::atomic<int> abort_flag{0};
-    std::vector<h2d_gate> gates(G);
-    std::vector<std::thread> th;
-    for (size_t k = 1; k < ws.size(); ++k)
-        th.emplace_back([&, k]() { ws[k].rc = slot_worker(ctx, p, dp, tasks, ref, rtasks, out, chunks[ws[k].d], ws[k].d, ws[k].s, gather_threads, abort_flag, gates[ws[k].d], ws[k].e, packed); });
-    ws[0].rc = slot_worker(ctx, p, dp, tasks, ref, rtasks, out, chunks[ws[0].d], ws[0].d, ws[0].s, gather_threads, abort_flag, gates[ws[0].d], ws[0].e, packed);
-    for (auto &t : th) t.join();
-    for (int pass = 0; pass < 2; ++pass)             /* report the failure itself, not the slots it made give up */
-        for (auto &w : ws)
-            if (w.rc && (pass || w.e.msg.compare(0, 7, "aborted") != 0)) { ctx->err = w.e; return w.rc; }
+        for (size_t d = 0; d < G; ++d) pp->threads.emplace_back(slot_main, ctx, d, s);
     return BSW_OK;
 }
 
-extern "C" int bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out)
+BSW_LOCAL bool pipeline_busy(bsw_ctx *ctx)
 {
-    if (!ctx) return BSW_E_INVAL;
-    if (!p || (!tasks && n) || (!out && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_submit: NULL argument");
-    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "bsw_submit: context is dead (an earlier wait for the GPU timed out)");
-    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "previous bsw_submit not waited for");
+    if (!ctx->pipe) return false;
+    std::lock_guard<std::mutex> lk(ctx->pipe->mu);
+    return !ctx->pipe->live.empty();
+}
+
+BSW_LOCAL void pipeline_shutdown(bsw_ctx *ctx)
+{
+    pipeline *pp = ctx->pipe;
+    if (!pp) return;
+    {
+        std::unique_lock<std::mutex> lk(pp->mu);
+        pp->cv_done.wait(lk, [&]() { for (auto &t : pp->live) if (!t->done) return false; return true; });
+        pp->live.clear();
+        pp->stop = true;
+    }
+    pp->cv_work.notify_all();
+    for (auto &t : pp->threads) t.join();
+    ctx->pipe = nullptr;
+    delete pp;
+}
+
+static int submit_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, const bsw_ref *ref, const bsw_ref_task *rtasks,
+                         size_t n, bsw_result *out, bool packed, bsw_ticket *ticket, const char *what)
+{
+    if (ticket) *ticket = 0;
+    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "%s: context is dead (an earlier wait for the GPU timed out)", what);
     bsw_dparams dp;
     int rc = check_params(ctx->err, p, &dp);
     if (rc) return rc;
-    ctx->worker_active = true;
-    ctx->worker_rc = 0;
-    bsw_params pc = *p;
-    ctx->worker = std::thread([ctx, pc, tasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, tasks, nullptr, nullptr, n, out); });
+    if ((rc = pipeline_start(ctx))) return rc;
+    pipeline &pp = *ctx->pipe;
+    const size_t G = ctx->devs.size();
+    std::unique_ptr<ticket_t> t(new ticket_t());
+    t->p = *p; t->dp = dp; t->tasks = tasks; t->ref = ref; t->rtasks = rtasks; t->out = out; t->packed = packed; t->n = n;
+    const std::vector<std::vector<chunk_span>> chunks = plan_chunks(n, ctx->cfg.chunk_tasks, G);
+    size_t total = 0;
+    for (const auto &v : chunks) total += v.size();
+    t->remaining = total;
+    t->done = total == 0;
+    {
+        std::lock_guard<std::mutex> lk(pp.mu);
+        if (pp.live.size() >= BSW_MAX_INFLIGHT)
+            return fail(ctx->err, BSW_E_BUSY, "%s: %d submits in flight already (BSW_MAX_INFLIGHT); wait for one first", what, BSW_MAX_INFLIGHT);
+        t->id = pp.next_id++;
+        if (ticket) *ticket = t->id;
+        /* chunk c of the submit -> device c mod G; the devices' queues are filled in the submit's own chunk order */
+        size_t left = total;
+        for (size_t k = 0; left; ++k)
+            for (size_t d = 0; d < G; ++d)
+                if (k < chunks[d].size()) { pp.devs[d]->q.push_back(chunk_job{t.get(), chunks[d][k], pp.devs[d]->next_seq++}); --left; }
+        pp.live.push_back(std::move(t));
+        pp.submits += 1;
+    }
+    pp.cv_work.notify_all();
     return BSW_OK;
 }
+
+extern "C" int bsw_submit_t(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out, bsw_ticket *ticket)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!p || (!tasks && n) || (!out && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_submit: NULL argument");
+    return submit_common(ctx, p, tasks, nullptr, nullptr, n, out, false, ticket, "bsw_submit");
+}
+extern "C" int bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out) { return bsw_submit_t(ctx, p, tasks, n, out, nullptr); }
 
 /* bsw_submit for callers that keep their sequences 4-bit packed — 16 bases per uint64, base k in bits [4k, 4k+3], codes
  * 0-3 = ACGT, 4-7 = N, every sequence on an 8-byte boundary, lengths still in bases: the device's own layout and the
  * encoding the reference ships over its link (8 bases per 32-bit word, sw_pe_array_proc_element.v:1638,1677-1683).  The
  * words of a registered arena are DMA'd straight into the sequence buffer: no pack kernel, less than half the PCIe bytes
- * of byte-per-base input.  bsw_pack_bases() converts one sequence.  Wait with bsw_wait. */
-extern "C" int bsw_submit_packed(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out)
+ * of byte-per-base input.  bsw_pack_bases() converts one sequence. */
+extern "C" int bsw_submit_packed_t(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out, bsw_ticket *ticket)
 {
     if (!ctx) return BSW_E_INVAL;
     if (!p || (!tasks && n) || (!out && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_submit_packed: NULL argument");
-    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "bsw_submit_packed: context is dead (an earlier wait for the GPU timed out)");
-    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "previous bsw_submit not waited for");
-    bsw_dparams dp;
-    int rc = check_params(ctx->err, p, &dp);
-    if (rc) return rc;
-    ctx->worker_active = true;
-    ctx->worker_rc = 0;
-    bsw_params pc = *p;
-    ctx->worker = std::thread([ctx, pc, tasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, tasks, nullptr, nullptr, n, out, true); });
-    return BSW_OK;
+    return submit_common(ctx, p, tasks, nullptr, nullptr, n, out, true, ticket, "bsw_submit_packed");
 }
+extern "C" int bsw_submit_packed(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out) { return bsw_submit_packed_t(ctx, p, tasks, n, out, nullptr); }
 
 /* bsw_submit for seeds against a DEVICE-RESIDENT reference (F3): only the reads cross PCIe; the targets are fetched
- * from the 2-bit pac on the GPU, the left flank of every read is mirrored by the pack kernel.  Wait with bsw_wait. */
-extern "C" int bsw_submit_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rtasks, size_t n, bsw_result *out)
+ * from the 2-bit pac on the GPU, the left flank of every read is mirrored by the pack kernel. */
+extern "C" int bsw_submit_ref_t(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rtasks, size_t n, bsw_result *out, bsw_ticket *ticket)
 {
     if (!ctx) return BSW_E_INVAL;
     if (!p || !ref || (!rtasks && n) || (!out && n)) return fail(ctx->err, BSW_E_INVAL, "bsw_submit_ref: NULL argument");
     if (ref->d_pac.size() != ctx->devs.size()) return fail(ctx->err, BSW_E_INVAL, "bsw_submit_ref: the reference was uploaded through another context");
-    if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "bsw_submit_ref: context is dead (an earlier wait for the GPU timed out)");
-    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "previous bsw_submit not waited for");
-    bsw_dparams dp;
-    int rc = check_params(ctx->err, p, &dp);
-    if (rc) return rc;
-    ctx->worker_active = true;
-    ctx->worker_rc = 0;
-    bsw_params pc = *p;
-    ctx->worker = std::thread([ctx, pc, ref, rtasks, n, out]() { ctx->worker_rc = submit_pipeline(ctx, pc, nullptr, ref, rtasks, n, out); });
-    return BSW_OK;
+    return submit_common(ctx, p, nullptr, ref, rtasks, n, out, false, ticket, "bsw_submit_ref");
 }
+extern "C" int bsw_submit_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *rtasks, size_t n, bsw_result *out) { return bsw_submit_ref_t(ctx, p, ref, rtasks, n, out, nullptr); }
 
+/* every submit in flight; the first failure in submit order is returned (and is what bsw_last_error describes) */
 extern "C" int bsw_wait(bsw_ctx *ctx)
 {
     if (!ctx) return BSW_E_INVAL;
-    if (!ctx->worker_active) return BSW_OK;
-    if (ctx->worker.joinable()) ctx->worker.join();
-    ctx->worker_active = false;
-    return ctx->worker_rc;
+    pipeline *pp = ctx->pipe;
+    if (!pp) return BSW_OK;
+    std::unique_lock<std::mutex> lk(pp->mu);
+    pp->cv_done.wait(lk, [&]() { for (auto &t : pp->live) if (!t->done) return false; return true; });
+    int rc = BSW_OK;
+    for (auto &t : pp->live)
+        if (t->rc && !rc) { rc = t->rc; ctx->err = t->err; }
+    pp->live.clear();
+    return rc;
 }
 
+extern "C" int bsw_wait_ticket(bsw_ctx *ctx, bsw_ticket ticket)
+{
+    if (!ctx) return BSW_E_INVAL;
+    pipeline *pp = ctx->pipe;
+    if (!pp) return fail(ctx->err, BSW_E_INVAL, "bsw_wait_ticket: no such ticket");
+    std::unique_lock<std::mutex> lk(pp->mu);
+    auto find = [&]() { for (size_t i = 0; i < pp->live.size(); ++i) if (pp->live[i]->id == ticket) return (long)i; return -1L; };
+    long i = find();
+    if (i < 0) return fail(ctx->err, BSW_E_INVAL, "bsw_wait_ticket: no such ticket (%llu)", (unsigned long long)ticket);
+    ticket_t *t = pp->live[(size_t)i].get();
+    pp->cv_done.wait(lk, [&]() { return t->done; });
+    const int rc = t->rc;
+    if (rc) ctx->err = t->err;
+    pp->live.erase(pp->live.begin() + find());
+    return rc;
+}
+
+/* the host's status poll (batch_manager.v:844-854): 1 = the submit is complete (results are in out[]; collect it — and its
+ * error code, if any — with bsw_wait_ticket / bsw_wait), 0 = still in flight.  Never blocks. */
+extern "C" int bsw_test(bsw_ctx *ctx, bsw_ticket ticket)
+{
+    if (!ctx) return BSW_E_INVAL;
+    pipeline *pp = ctx->pipe;
+    if (pp) {
+        std::lock_guard<std::mutex> lk(pp->mu);
+        for (auto &t : pp->live)
+            if (t->id == ticket) return t->done ? 1 : 0;
+    }
+    return fail(ctx->err, BSW_E_INVAL, "bsw_test: no such ticket (%llu)", (unsigned long long)ticket);
+}
+
+extern "C" int bsw_inflight(bsw_ctx *ctx)
+{
+    if (!ctx) return BSW_E_INVAL;
+    if (!ctx->pipe) return 0;
+    std::lock_guard<std::mutex> lk(ctx->pipe->mu);
+    return (int)ctx->pipe->live.size();
+}
+
+extern "C" int bsw_host_stats(bsw_ctx *ctx, bsw_stats *out, size_t out_size)
+{
+    if (!ctx || !out || out_size < sizeof(uint64_t)) return BSW_E_INVAL;
+    bsw_stats s;
+    memset(&s, 0, sizeof(s));
+    if (pipeline *pp = ctx->pipe) {
+        s.slot_cpu_ns = pp->slot_cpu_ns; s.helper_cpu_ns = pp->helper_cpu_ns; s.seeds = pp->seeds; s.chunks = pp->chunks;
+        s.h2d_bytes = pp->h2d_bytes; s.d2h_bytes = pp->d2h_bytes; s.submits = pp->submits; s.slot_threads = pp->threads.size();
+    }
+    memcpy(out, &s, std::min(out_size, sizeof(s)));
+    return BSW_OK;
+}

@@ -377,7 +377,7 @@ extern "C" int bsw_create_sized(const bsw_config *cfg, size_t cfg_size, bsw_ctx 
 extern "C" void bsw_destroy(bsw_ctx *ctx)
 {
     if (!ctx) return;
-    if (ctx->worker_active && ctx->worker.joinable()) ctx->worker.join();
+    pipeline_shutdown(ctx);
     ctx_release(ctx);
 }
 
@@ -502,7 +502,7 @@ extern "C" int64_t bsw_pack_tasks(const bsw_task *tasks, size_t n, uint64_t *are
 BSW_LOCAL int busy_check(bsw_ctx *ctx, const char *what)
 {
     if (ctx->dead) return fail(ctx->err, BSW_E_HIP, "%s: context is dead (an earlier wait for the GPU timed out)", what);
-    if (ctx->worker_active) return fail(ctx->err, BSW_E_BUSY, "%s: a bsw_submit is in flight (call bsw_wait first)", what);
+    if (pipeline_busy(ctx)) return fail(ctx->err, BSW_E_BUSY, "%s: a bsw_submit is in flight (call bsw_wait first)", what);
     return BSW_OK;
 }
 

@@ -75,7 +75,7 @@ static int global_chunk(bsw_ctx *ctx, errs &e, const bsw_dparams &dp, const bsw_
     HIPCHK(e, hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(ctx->g_tasks.p, gt.data(), n * sizeof(bsw_gdtask), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(ctx->g_order.p, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(e, bsw::launch_pack(st.d_raw.p, st.d_tasks.p, st.d_roff.p, 0u, (uint32_t)n, 0, nullptr, 0, nullptr, st.d_seq.p, s));
+    HIPCHK(e, bsw::launch_pack(st.d_raw.p, st.d_tasks.p, st.d_roff.p, 0u, (uint32_t)n, 0, nullptr, 0, nullptr, st.d_seq.p, nullptr, s));
     for (int c = 0; c < ncls; ++c) {
         const uint32_t k = cnt[(size_t)c + 1] - cnt[(size_t)c];
         if (!k) continue;
@@ -235,7 +235,7 @@ static int align_chunk(bsw_ctx *ctx, errs &e, const bsw_dparams &dp, const bsw_a
     HIPCHK(e, hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(ctx->a_tasks.p, at.data(), n * sizeof(bsw_adtask), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(ctx->g_order.p, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, 0u, (uint32_t)n, 0, nullptr, 0, nullptr, st.d_seq.p, s));
+    HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, 0u, (uint32_t)n, 0, nullptr, 0, nullptr, st.d_seq.p, nullptr, s));
     for (int c = 0; c < ncls; ++c) {
         const uint32_t k = cnt[(size_t)c + 1] - cnt[(size_t)c];
         if (!k) continue;

@@ -22,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -154,6 +156,8 @@ struct stage_t {
     dbuf<bsw_dtask> d_tasks;
     dbuf<bsw_rawoff> d_roff;
     dbuf<uint32_t> d_order, d_bins;
+    dbuf<uint8_t> d_nflag;            /* per seed: bit 0 / 1 = the left / right query holds an N (bsw_pack_kernel -> bsw_bin_count) */
+    dbuf<uint64_t> d_keys;            /* per seed: its three list indices (bsw_bin_count -> bsw_bin_scatter) */
     dbuf<bsw_result> d_out;
     dbuf<bsw_pair> d_pair;            /* BSW_RESULT_PAIR: the dense 32-byte records that cross PCIe */
     hbuf<uint64_t> h_blob;            /* small batches: packed sequences | task records | order lists + counters, one DMA */
@@ -164,7 +168,7 @@ struct stage_t {
     dbuf<uint32_t> d_wout;
     void set_pinned(bool on) { h_raw.pinned = h_tasks.pinned = h_roff.pinned = h_out.pinned = h_desc.pinned = h_woff.pinned = h_blob.pinned = h_wout.pinned = on; }
     void release_host() { h_raw.release(); h_tasks.release(); h_roff.release(); h_out.release(); h_desc.release(); h_woff.release(); h_blob.release(); h_wout.release(); }
-    void release_transient_dev() { d_raw.release(); d_roff.release(); d_bins.release(); d_desc.release(); d_woff.release(); d_blob.release(); d_wout.release(); }
+    void release_transient_dev() { d_raw.release(); d_roff.release(); d_bins.release(); d_nflag.release(); d_keys.release(); d_desc.release(); d_woff.release(); d_blob.release(); d_wout.release(); }
     void release()
     {
         release_host();
@@ -223,6 +227,7 @@ struct refbatch_req {
     uint32_t *out;
 };
 
+struct pipeline;
 struct bsw_ctx {
     bsw_config cfg{};
     std::vector<dev_state> devs;
@@ -235,10 +240,8 @@ struct bsw_ctx {
     size_t hist_used = 0;
     hipEvent_t ev_last0 = nullptr, ev_last1 = nullptr;
     errs err;
-    /* async submit */
-    std::thread worker;
-    bool worker_active = false;
-    int worker_rc = 0;
+    /* async submits: persistent slot threads behind a chunk queue (bsw_batch.hip), started by the first submit */
+    struct pipeline *pipe = nullptr;
     /* small synchronous batches (bsw_extend_batch, scalar ABI, wire format) */
     stage_t small;
     /* banded global alignment (F4) */
@@ -282,6 +285,9 @@ BSW_LOCAL int mat_max(const int8_t *mat);
 BSW_LOCAL int gap_limit(const bsw_params *p, int mx, int qlen, int end_bonus);
 BSW_LOCAL size_t nwords(int len);
 BSW_LOCAL int busy_check(bsw_ctx *ctx, const char *what);
+/* ---- bsw_batch.hip: the streaming pipeline ---- */
+BSW_LOCAL bool pipeline_busy(bsw_ctx *ctx);               /* some submit has not been waited for */
+BSW_LOCAL void pipeline_shutdown(bsw_ctx *ctx);           /* waits for what is in flight, joins the slot threads */
 
 /* ---- bsw_batch.hip ---- */
 /* How one batch is cut into kernel launches lives in batch_plan (above); a chunk's host pass leaves this: */
@@ -302,7 +308,8 @@ struct gate_turn {                    /* this chunk's place in its device's inpu
     h2d_gate *gate = nullptr;
     size_t seq = 0;
     hipEvent_t ev = nullptr;
-    std::atomic<int> *abort_flag = nullptr;
+    std::atomic<int> *abort_flag = nullptr;   /* the chunk's submit has failed elsewhere: pass the turn on, do nothing */
+    bool *passed = nullptr;           /* set once the turn has been passed on */
 };
 BSW_LOCAL size_t order_capacity(size_t n);
 BSW_LOCAL int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams &bp);

@@ -48,8 +48,9 @@ hipError_t launch_finalize(const bsw_dparams &P, const bsw_dtask *tasks, const u
 hipError_t launch_pairs_from_results(const uint32_t *order, uint32_t n, const uint32_t *n_dev, const bsw_result *out, bsw_pair *pairs, hipStream_t s);
 /* raw byte of a sequence = raw[roff - bias] (uint32 arithmetic).  pac != NULL: the targets are not in raw, they are
  * fetched from the resident reference at refx[] */
+/* nflag (may be NULL): one byte per seed, bit 0 / 1 = the left / right query holds an N (what launch_bin wants to know) */
 hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t bias, uint32_t n, int rev_left,
-                       const uint8_t *pac, int64_t l_pac, const bsw_refx *refx, uint64_t *seq, hipStream_t s);
+                       const uint8_t *pac, int64_t l_pac, const bsw_refx *refx, uint64_t *seq, uint8_t *nflag, hipStream_t s);
 hipError_t launch_wire_pack(const uint32_t *wire, const bsw_dtask *tasks, const bsw_wireoff *woffs, uint32_t n, uint64_t *seq, hipStream_t s);
 /* the group's 16 KiB result batches, written on the device: wout[woffs[t].out_word .. + 4] = R0..R4 of task t, the rest zero */
 hipError_t launch_wire_results(const bsw_result *out, const bsw_wireoff *woffs, uint32_t n, uint32_t *wout, size_t wout_words, hipStream_t s);
@@ -61,7 +62,9 @@ int align_class_count();
 int align_class_of(int qlen, int byte_mode);                 /* -1: query too long for the mode */
 hipError_t launch_align(int cls, const bsw_dparams &P, const uint64_t *seq, const bsw_adtask *tasks, const uint32_t *order, uint32_t n,
                         unsigned long long *blist, bsw_kswr *out, hipStream_t s);
-hipError_t launch_bin(const bsw_binparams &bp, const uint64_t *seq, const bsw_dtask *tasks, uint32_t n, uint32_t *bins, uint32_t *order, hipStream_t s);
+/* nflag == NULL: the queries' words are read from seq instead (input that arrived packed); keys: n words of scratch */
+hipError_t launch_bin(const bsw_binparams &bp, const uint64_t *seq, const uint8_t *nflag, const bsw_dtask *tasks, uint32_t n, uint32_t *bins,
+                      uint64_t *keys, uint32_t *order, hipStream_t s);
 }  // namespace bsw
 
 #endif

@@ -104,64 +104,105 @@ __device__ __forceinline__ uint64_t fetch_word(const uint8_t *__restrict__ pac, 
     return v;
 }
 
-/* 16 lanes per sequence, 4 sequences per seed (leftQ, leftT, rightQ, rightT); lane k packs words k, k+16, ...
+/* One workgroup = 64 seeds = 256 sequences (leftQ, leftT, rightQ, rightT per seed); one thread per OUTPUT WORD.
+ * Round 5's mapping — 16 lanes per sequence, lane k packing words k, k + 16, ... — left most lanes idle (a PE query is 3 - 9
+ * words, a target 5 - 14): 1.58 ms per 4 Mi PE seeds, 1.7 TB/s.  Here thread t of the group first describes sequence t (length,
+ * word offset, byte offset), the group prefix-sums the word counts, and then the threads walk the group's words 256 at a
+ * time, each finding its sequence by a binary search over the prefix sums in LDS (8 probes): every lane packs a word, a
+ * wavefront's stores are consecutive words of `seq`, its loads consecutive 16-byte pieces of `raw`.
  * rev_left: the left query is read BACKWARDS from its offset (base k = raw[off - k]): a read DMA'd as it is holds
  * query[0..qbeg) forwards, mem_chain2aln extends it reversed (the host's reversal loop, done here for free).
- * pac != NULL: the two target groups fetch from the resident reference instead of packing raw bytes. */
+ * pac != NULL: the two target sequences are fetched from the resident reference instead of packed from raw bytes.
+ * nflag != NULL: nflag[seed] = (left query holds an N) | (right query holds an N) << 1 — what the binning needs to know about
+ * the bases, so that bsw_bin_count does not have to read `seq` again. */
+#define BSW_PACK_SEEDS 64
 __global__ __launch_bounds__(256) void bsw_pack_kernel(const uint8_t *__restrict__ raw, const bsw_dtask *__restrict__ tasks,
                                                        const bsw_rawoff *__restrict__ roff, const uint32_t bias, const uint32_t n,
                                                        const int rev_left, const uint8_t *__restrict__ pac, const int64_t l_pac,
-                                                       const bsw_refx *__restrict__ refx, uint64_t *__restrict__ seq)
+                                                       const bsw_refx *__restrict__ refx, uint64_t *__restrict__ seq, uint8_t *__restrict__ nflag)
 {
-    const uint32_t g = blockIdx.x * 16u + (threadIdx.x >> 4);
-    const int l16 = threadIdx.x & 15;
-    const uint32_t ti = g >> 2;
-    const int which = (int)(g & 3u);
-    if (ti >= n) return;
-    const bsw_dtask T = tasks[ti];
-    if (pac && (which & 1)) {
-        const bsw_refx X = refx[ti];
-        const bool left = which == 1;
-        const int tlen = left ? (T.lqlen ? T.ltlen : 0) : (T.rqlen ? T.rtlen : 0);
-        const uint32_t woff = left ? T.lt_off : T.rt_off;
-        const int nw = (tlen + 15) >> 4;
-        for (int k = l16; k < nw; k += 16) seq[woff + (uint32_t)k] = fetch_word(pac, l_pac, left ? X.xl : X.xr, left ? -1 : 1, tlen, k);
-        return;
-    }
-    const bsw_rawoff R = roff[ti];
-    int len;
-    uint32_t woff, boff;
-    switch (which) {
-    case 0: len = T.lqlen; woff = T.lq_off; boff = R.lq; break;
-    case 1: len = T.lqlen ? T.ltlen : 0; woff = T.lt_off; boff = R.lt; break;
-    case 2: len = T.rqlen; woff = T.rq_off; boff = R.rq; break;
-    default: len = T.rqlen ? T.rtlen : 0; woff = T.rt_off; boff = R.rt; break;
-    }
-    boff -= bias;
-    const int nw = (len + 15) >> 4;
-    const bool rev = rev_left && which == 0;
-    for (int k = l16; k < nw; k += 16) {
-        /* forwards: bytes [off + 16k, +16); backwards: bytes (off - 16k - 16, off - 16k], then mirrored */
-        const uintptr_t a = rev ? (uintptr_t)(raw + boff) - 16u * (uint32_t)k - 15u : (uintptr_t)(raw + boff) + 16u * (uint32_t)k;
-        const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
-        const uint32_t sh = (uint32_t)(a & 3u);
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];   /* the raw buffer has >= 32 bytes of slack on both sides */
-        const uint32_t x0 = __builtin_amdgcn_alignbyte(d1, d0, sh), x1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        const uint32_t x2 = __builtin_amdgcn_alignbyte(d3, d2, sh), x3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-        uint64_t lo = (uint64_t)x0 | ((uint64_t)x1 << 32), hi = (uint64_t)x2 | ((uint64_t)x3 << 32);
-        if (rev) {
-            const uint64_t t = __builtin_bswap64(hi);
-            hi = __builtin_bswap64(lo);
-            lo = t;
+    __shared__ uint32_t start[257];               /* start[s] = words of the group's sequences before s */
+    __shared__ uint32_t s_woff[256], s_boff[256], s_hasn[256];
+    __shared__ int s_len[256];
+    __shared__ uint32_t wsum[4];
+    const int sq = threadIdx.x, which = sq & 3;
+    const uint32_t ti = blockIdx.x * (uint32_t)BSW_PACK_SEEDS + (uint32_t)(sq >> 2);
+    int len = 0;
+    uint32_t woff = 0, boff = 0;
+    if (ti < n) {
+        const bsw_dtask T = tasks[ti];
+        const bool from_pac = pac && (which & 1);
+        bsw_rawoff R = {0, 0, 0, 0};
+        if (!from_pac) R = roff[ti];
+        switch (which) {
+        case 0: len = T.lqlen; woff = T.lq_off; boff = R.lq; break;
+        case 1: len = T.lqlen ? T.ltlen : 0; woff = T.lt_off; boff = R.lt; break;
+        case 2: len = T.rqlen; woff = T.rq_off; boff = R.rq; break;
+        default: len = T.rqlen ? T.rtlen : 0; woff = T.rt_off; boff = R.rt; break;
         }
-        const int valid = len - 16 * k;                     /* bases of this word */
-        if (valid < 16) {
-            if (valid <= 8) { hi = 0; lo = valid == 8 ? lo : lo & ((1ull << (8 * valid)) - 1ull); }
-            else hi &= (1ull << (8 * (valid - 8))) - 1ull;
+        boff -= bias;
+    }
+    const uint32_t nw = (uint32_t)(len + 15) >> 4;
+    /* inclusive scan of nw inside the wavefront, then across the four wavefronts */
+    uint32_t inc = nw;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64);
+        if ((sq & 63) >= d) inc += up;
+    }
+    if ((sq & 63) == 63) wsum[sq >> 6] = inc;
+    s_woff[sq] = woff; s_boff[sq] = boff; s_len[sq] = len; s_hasn[sq] = 0;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int k = 0; k < (sq >> 6); ++k) before += wsum[k];
+    start[sq] = before + inc - nw;
+    if (sq == 255) start[256] = before + inc;
+    __syncthreads();
+    const uint32_t total = start[256];
+    for (uint32_t w = (uint32_t)sq; w < total; w += 256u) {
+        int lo = 0;                                            /* the last sequence that starts at or before word w */
+#pragma unroll
+        for (int step = 128; step >= 1; step >>= 1)
+            if (start[lo + step] <= w) lo += step;
+        const int k = (int)(w - start[lo]);
+        const int wh = lo & 3, L = s_len[lo];
+        const uint32_t tsk = blockIdx.x * (uint32_t)BSW_PACK_SEEDS + (uint32_t)(lo >> 2);
+        uint64_t v;
+        if (pac && (wh & 1)) {
+            const bsw_refx X = refx[tsk];
+            const bool left = wh == 1;
+            v = fetch_word(pac, l_pac, left ? X.xl : X.xr, left ? -1 : 1, L, k);
+        } else {
+            const bool rev = rev_left && wh == 0;
+            const uint8_t *base = raw + s_boff[lo];
+            /* forwards: bytes [off + 16k, +16); backwards: bytes (off - 16k - 16, off - 16k], then mirrored */
+            const uintptr_t a = rev ? (uintptr_t)base - 16u * (uint32_t)k - 15u : (uintptr_t)base + 16u * (uint32_t)k;
+            const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
+            const uint32_t sh = (uint32_t)(a & 3u);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];   /* the raw buffer has >= 32 bytes of slack on both sides */
+            const uint32_t x0 = __builtin_amdgcn_alignbyte(d1, d0, sh), x1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            const uint32_t x2 = __builtin_amdgcn_alignbyte(d3, d2, sh), x3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+            uint64_t lo64 = (uint64_t)x0 | ((uint64_t)x1 << 32), hi64 = (uint64_t)x2 | ((uint64_t)x3 << 32);
+            if (rev) {
+                const uint64_t t = __builtin_bswap64(hi64);
+                hi64 = __builtin_bswap64(lo64);
+                lo64 = t;
+            }
+            const int valid = L - 16 * k;                     /* bases of this word */
+            if (valid < 16) {
+                if (valid <= 8) { hi64 = 0; lo64 = valid == 8 ? lo64 : lo64 & ((1ull << (8 * valid)) - 1ull); }
+                else hi64 &= (1ull << (8 * (valid - 8))) - 1ull;
+            }
+            lo64 = clamp_codes(lo64);
+            hi64 = clamp_codes(hi64);
+            v = squeeze8(lo64) | (squeeze8(hi64) << 32);
         }
-        lo = clamp_codes(lo);
-        hi = clamp_codes(hi);
-        seq[woff + (uint32_t)k] = squeeze8(lo) | (squeeze8(hi) << 32);
+        seq[s_woff[lo] + (uint32_t)k] = v;
+        if (!(wh & 1) && (v & 0x4444444444444444ull)) s_hasn[lo] = 1u;      /* (a query word with an N: rare; any writer writes the same 1) */
+    }
+    if (nflag) {
+        __syncthreads();
+        if (which == 0 && ti < n) nflag[ti] = (uint8_t)((s_hasn[sq] ? 1u : 0u) | (s_hasn[sq + 2] ? 2u : 0u));
     }
 }
 
@@ -181,7 +222,9 @@ __device__ __forceinline__ int packed_has_n(const uint64_t *__restrict__ seq, co
 
 struct seed_bins { int k0, k1, k2; };      /* class list, left-side bin, right-side bin (-1: none) */
 
-__device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const uint64_t *__restrict__ seq, const bsw_dtask &T)
+/* nflag: the pack kernel's per-seed N bits (NULL: input that came packed already — the queries' words are read here) */
+__device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const uint64_t *__restrict__ seq, const uint8_t *__restrict__ nflag,
+                                               const uint32_t ti, const bsw_dtask &T)
 {
     seed_bins s;
     s.k1 = s.k2 = -1;
@@ -191,20 +234,31 @@ __device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const ui
         s.k0 = BSW_BIN_WAVE0 + (c < 0 ? 0 : c);     /* c < 0 cannot happen: the host rejects such seeds */
     } else {
         s.k0 = BSW_BIN_LANEALL;
-        if (T.lqlen) s.k1 = BSW_BIN_L(bits == 16, packed_has_n(seq, T.lq_off, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
-        if (T.rqlen) s.k2 = BSW_BIN_R(bits == 16, packed_has_n(seq, T.rq_off, T.rqlen), T.rqlen);
+        const int nf = nflag ? (int)nflag[ti] : -1;
+        if (T.lqlen) s.k1 = BSW_BIN_L(bits == 16, nf >= 0 ? (nf & 1) : packed_has_n(seq, T.lq_off, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
+        if (T.rqlen) s.k2 = BSW_BIN_R(bits == 16, nf >= 0 ? ((nf >> 1) & 1) : packed_has_n(seq, T.rq_off, T.rqlen), T.rqlen);
     }
     return s;
 }
 
-__global__ __launch_bounds__(256) void bsw_bin_count(const bsw_binparams bp, const uint64_t *__restrict__ seq,
-                                                     const bsw_dtask *__restrict__ tasks, const uint32_t n, uint32_t *__restrict__ bins)
+/* the three list indices of a seed in one word (0xffff: none): bsw_bin_count works them out once, bsw_bin_scatter reads 8 bytes
+ * per seed instead of the task record and the query words again */
+__device__ __forceinline__ uint64_t keys_pack(const seed_bins &s)
+{
+    return (uint64_t)(uint32_t)s.k0 | ((uint64_t)(uint16_t)s.k1 << 16) | ((uint64_t)(uint16_t)s.k2 << 32);
+}
+static_assert(BSW_BIN_WORDS < 0xffff, "bin indices are kept in 16 bits");
+
+__global__ __launch_bounds__(256) void bsw_bin_count(const bsw_binparams bp, const uint64_t *__restrict__ seq, const uint8_t *__restrict__ nflag,
+                                                     const bsw_dtask *__restrict__ tasks, const uint32_t n, uint32_t *__restrict__ bins,
+                                                     uint64_t *__restrict__ keys)
 {
     __shared__ uint32_t h[BSW_BIN_WAVE0];
     for (int b = threadIdx.x; b < BSW_BIN_WAVE0; b += 256) h[b] = 0;
     __syncthreads();
     for (uint32_t ti = blockIdx.x * 256u + threadIdx.x; ti < n; ti += gridDim.x * 256u) {
-        const seed_bins s = seed_keys(bp, seq, tasks[ti]);
+        const seed_bins s = seed_keys(bp, seq, nflag, ti, tasks[ti]);
+        keys[ti] = keys_pack(s);
         if (s.k1 >= 0) atomicAdd(&h[s.k1], 1u);
         if (s.k2 >= 0) atomicAdd(&h[s.k2], 1u);
     }
@@ -257,28 +311,45 @@ __global__ __launch_bounds__(256) void bsw_bin_scan(const bsw_binparams bp, uint
     if (t == 0) bins[BSW_BIN_LANEALL] = bp.lane_all_off;
 }
 
-/* BSW_SCATTER_TPT tasks per thread: the two passes over the cursor table (9 232 words) are shared by 1 024 tasks */
+/* BSW_SCATTER_TPT tasks per thread: the two passes over the cursor table (9 232 words) are shared by 1 024 tasks.  The class
+ * list of a seed (k0) is one of a handful of values — nearly always the list of all lane seeds — so its rank inside the
+ * workgroup is taken per WAVEFRONT (one LDS atomic per distinct value and wavefront, ranks from the lane mask) instead of
+ * 1 024 atomics on one LDS word. */
 #define BSW_SCATTER_TPT 4
-__global__ __launch_bounds__(256) void bsw_bin_scatter(const bsw_binparams bp, const uint64_t *__restrict__ seq,
-                                                       const bsw_dtask *__restrict__ tasks, const uint32_t n,
+__global__ __launch_bounds__(256) void bsw_bin_scatter(const uint64_t *__restrict__ keys, const uint32_t n,
                                                        uint32_t *__restrict__ bins, uint32_t *__restrict__ order)
 {
     __shared__ uint32_t cnt[BSW_BIN_WORDS];               /* first the block's count per list, then — in place — its base in the list */
     for (int b = threadIdx.x; b < BSW_BIN_WORDS; b += 256) cnt[b] = 0;
     __syncthreads();
-    seed_bins s[BSW_SCATTER_TPT];
+    int k0[BSW_SCATTER_TPT], k1[BSW_SCATTER_TPT], k2[BSW_SCATTER_TPT];
     uint32_t r0[BSW_SCATTER_TPT], r1[BSW_SCATTER_TPT], r2[BSW_SCATTER_TPT];
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < BSW_SCATTER_TPT; ++k) {
         const uint32_t ti = (blockIdx.x * BSW_SCATTER_TPT + k) * 256u + threadIdx.x;
-        s[k].k0 = s[k].k1 = s[k].k2 = -1;
+        k0[k] = k1[k] = k2[k] = -1;
         r0[k] = r1[k] = r2[k] = 0;
         if (ti < n) {
-            s[k] = seed_keys(bp, seq, tasks[ti]);
-            r0[k] = atomicAdd(&cnt[s[k].k0], 1u);
-            if (s[k].k1 >= 0) r1[k] = atomicAdd(&cnt[s[k].k1], 1u);
-            if (s[k].k2 >= 0) r2[k] = atomicAdd(&cnt[s[k].k2], 1u);
+            const uint64_t K = keys[ti];
+            k0[k] = (int)(K & 0xffffu);
+            k1[k] = (int)((K >> 16) & 0xffffu); if (k1[k] == 0xffff) k1[k] = -1;
+            k2[k] = (int)((K >> 32) & 0xffffu); if (k2[k] == 0xffff) k2[k] = -1;
         }
+        /* rank in the class list: the lanes of the wavefront that share a value take consecutive places */
+        uint64_t todo = __ballot(k0[k] >= 0);
+        while (todo) {
+            const int lead = __builtin_ctzll(todo);
+            const int val = __shfl(k0[k], lead, 64);
+            const uint64_t same = __ballot(k0[k] == val) & todo;
+            uint32_t basev = 0;
+            if (lane == lead) basev = atomicAdd(&cnt[val], (uint32_t)__builtin_popcountll(same));
+            basev = (uint32_t)__shfl((int)basev, lead, 64);
+            if (k0[k] == val) r0[k] = basev + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
+        }
+        if (k1[k] >= 0) r1[k] = atomicAdd(&cnt[k1[k]], 1u);
+        if (k2[k] >= 0) r2[k] = atomicAdd(&cnt[k2[k]], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < BSW_BIN_WORDS; b += 256)
@@ -288,9 +359,9 @@ __global__ __launch_bounds__(256) void bsw_bin_scatter(const bsw_binparams bp, c
     for (int k = 0; k < BSW_SCATTER_TPT; ++k) {
         const uint32_t ti = (blockIdx.x * BSW_SCATTER_TPT + k) * 256u + threadIdx.x;
         if (ti < n) {
-            order[cnt[s[k].k0] + r0[k]] = ti;
-            if (s[k].k1 >= 0) order[cnt[s[k].k1] + r1[k]] = ti;
-            if (s[k].k2 >= 0) order[cnt[s[k].k2] + r2[k]] = ti;
+            order[cnt[k0[k]] + r0[k]] = ti;
+            if (k1[k] >= 0) order[cnt[k1[k]] + r1[k]] = ti;
+            if (k2[k] >= 0) order[cnt[k2[k]] + r2[k]] = ti;
         }
     }
 }
@@ -360,10 +431,10 @@ __global__ __launch_bounds__(256) void bsw_wire_results_kernel(const bsw_result 
 
 /* ---- launchers ---- */
 hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t bias, uint32_t n, int rev_left,
-                       const uint8_t *pac, int64_t l_pac, const bsw_refx *refx, uint64_t *seq, hipStream_t s)
+                       const uint8_t *pac, int64_t l_pac, const bsw_refx *refx, uint64_t *seq, uint8_t *nflag, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(bsw_pack_kernel, dim3(n / 4u + (n % 4u ? 1u : 0u)), dim3(256), 0, s, raw, tasks, roff, bias, n, rev_left, pac, l_pac, refx, seq);
+    hipLaunchKernelGGL(bsw_pack_kernel, dim3((n + BSW_PACK_SEEDS - 1u) / BSW_PACK_SEEDS), dim3(256), 0, s, raw, tasks, roff, bias, n, rev_left, pac, l_pac, refx, seq, nflag);
     return hipGetLastError();
 }
 
@@ -383,15 +454,16 @@ hipError_t launch_wire_results(const bsw_result *out, const bsw_wireoff *woffs, 
     return hipGetLastError();
 }
 
-hipError_t launch_bin(const bsw_binparams &bp, const uint64_t *seq, const bsw_dtask *tasks, uint32_t n, uint32_t *bins, uint32_t *order, hipStream_t s)
+hipError_t launch_bin(const bsw_binparams &bp, const uint64_t *seq, const uint8_t *nflag, const bsw_dtask *tasks, uint32_t n, uint32_t *bins,
+                      uint64_t *keys, uint32_t *order, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(bins, 0, BSW_BIN_WORDS * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     const uint32_t blocks = (n + 255u) / 256u, sblocks = (n + 256u * BSW_SCATTER_TPT - 1u) / (256u * BSW_SCATTER_TPT);
-    hipLaunchKernelGGL(bsw_bin_count, dim3(blocks > 1024u ? 1024u : blocks), dim3(256), 0, s, bp, seq, tasks, n, bins);
+    hipLaunchKernelGGL(bsw_bin_count, dim3(blocks > 2048u ? 2048u : blocks), dim3(256), 0, s, bp, seq, nflag, tasks, n, bins, keys);
     hipLaunchKernelGGL(bsw_bin_scan, dim3(1), dim3(256), 0, s, bp, bins);
-    hipLaunchKernelGGL(bsw_bin_scatter, dim3(sblocks), dim3(256), 0, s, bp, seq, tasks, n, bins, order);
+    hipLaunchKernelGGL(bsw_bin_scatter, dim3(sblocks), dim3(256), 0, s, keys, n, bins, order);
     return hipGetLastError();
 }
 

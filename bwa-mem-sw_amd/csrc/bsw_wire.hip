@@ -215,6 +215,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     if ((he = st.d_seq.reserve((size_t)acc + 4)) != hipSuccess ||
         (he = st.d_tasks.reserve(n + 1)) != hipSuccess || (he = st.d_woff.reserve(n + 1)) != hipSuccess ||
         (he = st.d_order.reserve(order_capacity(n))) != hipSuccess || (he = st.d_bins.reserve(BSW_BIN_WORDS)) != hipSuccess ||
+        (he = st.d_keys.reserve(n + 1)) != hipSuccess ||
         (he = st.d_out.reserve(n + 1)) != hipSuccess || (he = st.d_wout.reserve(wout_words)) != hipSuccess)
         return fail(e, BSW_E_NOMEM, "device staging: %s", hipGetErrorString(he));
     if ((he = st.h_wout.reserve(wout_words)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
@@ -222,7 +223,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     HIPCHK(e, hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(st.d_woff.p, st.h_woff.p, n * sizeof(bsw_wireoff), hipMemcpyHostToDevice, s));
     HIPCHK(e, bsw::launch_wire_pack((const uint32_t *)st.d_raw.p, st.d_tasks.p, st.d_woff.p, (uint32_t)n, st.d_seq.p, s));
-    HIPCHK(e, bsw::launch_bin(bp, st.d_seq.p, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_order.p, s));
+    HIPCHK(e, bsw::launch_bin(bp, st.d_seq.p, nullptr, st.d_tasks.p, (uint32_t)n, st.d_bins.p, st.d_keys.p, st.d_order.p, s));
     rc = enqueue_batch(e, dp, variant, st.d_seq.p, st.d_tasks.p, st.d_order.p, pl, st.d_out.p, s, nullptr);
     if (rc) return rc;
     /* the 16 KiB result batches are written on the device (five words of a 96-byte record per task: a fifth of the bytes over

@@ -44,6 +44,9 @@ MAX_DEVICES = 16
 CONFIG = np.dtype([("device", "<i4"), ("kernel", "<i4"), ("streams", "<i4"), ("pack_threads", "<i4"),
                    ("chunk_tasks", "<u8"), ("n_devices", "<i4"), ("devices", "<i4", (MAX_DEVICES,)),
                    ("timeout_ms", "<i4"), ("result_format", "<i4"), ("pin_threads", "<i4")])
+STATS = np.dtype([("slot_cpu_ns", "<u8"), ("helper_cpu_ns", "<u8"), ("seeds", "<u8"), ("chunks", "<u8"), ("submits", "<u8"),
+                  ("h2d_bytes", "<u8"), ("d2h_bytes", "<u8"), ("slot_threads", "<u8")])
+MAX_INFLIGHT = 4
 PAIR = np.dtype([("tag", "<u4"), ("qb", "<i4"), ("qe", "<i4"), ("rb", "<i4"), ("re", "<i4"),
                  ("score", "<i4"), ("truesc", "<i4"), ("w", "<i4")])       # the RTL's 5-word record: the first 32 bytes of RESULT
 RESULT_FULL, RESULT_PAIR = 0, 1
@@ -99,6 +102,11 @@ def lib():
             "bsw_last_error": (C.c_char_p, [vp]),
             "bsw_submit": (C.c_int, [vp, vp, vp, sz, vp]), "bsw_wait": (C.c_int, [vp]),
             "bsw_submit_packed": (C.c_int, [vp, vp, vp, sz, vp]),
+            "bsw_submit_t": (C.c_int, [vp, vp, vp, sz, vp, C.POINTER(C.c_uint64)]),
+            "bsw_submit_packed_t": (C.c_int, [vp, vp, vp, sz, vp, C.POINTER(C.c_uint64)]),
+            "bsw_submit_ref_t": (C.c_int, [vp, vp, vp, vp, sz, vp, C.POINTER(C.c_uint64)]),
+            "bsw_wait_ticket": (C.c_int, [vp, C.c_uint64]), "bsw_test": (C.c_int, [vp, C.c_uint64]),
+            "bsw_inflight": (C.c_int, [vp]), "bsw_host_stats": (C.c_int, [vp, vp, sz]),
             "bsw_upload_packed": (C.c_int, [vp, vp, vp, sz, C.POINTER(vp)]),
             "bsw_pack_tasks": (C.c_int64, [vp, sz, vp, sz, vp]), "bsw_pack_tasks_bound": (sz, [vp, sz]),
             "bsw_extend_batch": (C.c_int, [vp, vp, vp, sz, vp]),
@@ -158,6 +166,7 @@ EXPORTS = ["ksw_global2", "ksw_global", "bsw_global_batch", "bsw_align_batch", "
            "bsw_host_register", "bsw_host_unregister", "bsw_batch_order", "bsw_refbatch_submit", "bsw_refbatch_wait", "bsw_default_params", "bsw_default_config",
            "bsw_device_count", "bsw_create", "bsw_create_sized", "bsw_abi_version", "bsw_chain_timeouts", "bsw_device_placement", "bsw_destroy", "bsw_last_error", "bsw_submit", "bsw_wait",
            "bsw_submit_packed", "bsw_upload_packed", "bsw_pack_tasks", "bsw_pack_tasks_bound",
+           "bsw_submit_t", "bsw_submit_packed_t", "bsw_submit_ref_t", "bsw_wait_ticket", "bsw_test", "bsw_inflight", "bsw_host_stats",
            "bsw_upload_raw", "bsw_run_staged", "bsw_run_history2", "bsw_effective_timeout_ms",
            "bsw_extend_batch", "bsw_upload", "bsw_run", "bsw_sync", "bsw_download", "bsw_batch_info",
            "bsw_last_run_ms", "bsw_run_history", "bsw_free_batch", "bsw_refbatch_encode", "bsw_refbatch_decode",
@@ -313,6 +322,7 @@ class BswContext:
             raise BswError(rc, "bsw_create")
         self.handle = h
         self._keep = None
+        self.last_ticket = 0
 
     def _chk(self, rc, what):
         if rc:
@@ -342,27 +352,55 @@ class BswContext:
     def __exit__(self, *a):
         self.close()
 
-    # streaming path: host buffers in, host buffers out
-    def submit(self, params, tasks, out=None):
+    # streaming path: host buffers in, host buffers out.  Up to MAX_INFLIGHT submits per context; every submit has a ticket.
+    def _submit(self, fn, what, params, tasks, out, *front):
         if out is None:
             out = np.zeros(len(tasks), dtype=self.out_dtype)
         assert out.dtype == self.out_dtype and len(out) >= len(tasks)
-        self._keep = (params, tasks, out)
-        self._chk(lib().bsw_submit(self.handle, params.ctypes.data, tasks.ctypes.data, len(tasks), out.ctypes.data), "bsw_submit")
+        t = C.c_uint64(0)
+        self._chk(fn(self.handle, params.ctypes.data, *front, tasks.ctypes.data, len(tasks), out.ctypes.data, C.byref(t)), what)
+        if self._keep is None:
+            self._keep = {}
+        self._keep[t.value] = (params, tasks, out)          # the arrays must outlive the submit
+        self.last_ticket = t.value
         return out
 
+    def submit(self, params, tasks, out=None):
+        return self._submit(lib().bsw_submit_t, "bsw_submit", params, tasks, out)
+
     def wait(self):
-        self._chk(lib().bsw_wait(self.handle), "bsw_wait")
-        self._keep = None
+        """every submit in flight; raises the first failure in submit order"""
+        try:
+            self._chk(lib().bsw_wait(self.handle), "bsw_wait")
+        finally:
+            self._keep = None
+
+    def wait_ticket(self, ticket):
+        try:
+            self._chk(lib().bsw_wait_ticket(self.handle, ticket), "bsw_wait_ticket")
+        finally:
+            if self._keep:
+                self._keep.pop(ticket, None)
+
+    def test(self, ticket):
+        """non-blocking: True once the submit is complete (collect it with wait_ticket / wait)"""
+        rc = lib().bsw_test(self.handle, ticket)
+        if rc < 0:
+            self._chk(rc, "bsw_test")
+        return bool(rc)
+
+    def inflight(self):
+        return int(lib().bsw_inflight(self.handle))
+
+    def host_stats(self):
+        """bsw_host_stats as a dict: CPU ns of the slot / gather threads, seeds, chunks, submits, bytes moved"""
+        s = np.zeros(1, dtype=STATS)
+        self._chk(lib().bsw_host_stats(self.handle, s.ctypes.data, STATS.itemsize), "bsw_host_stats")
+        return {k: int(s[k][0]) for k in STATS.names}
 
     def submit_packed(self, params, ptasks, out=None):
         """bsw_submit_packed: `ptasks` from pack_tasks() (sequence pointers address 4-bit packed words)."""
-        if out is None:
-            out = np.zeros(len(ptasks), dtype=self.out_dtype)
-        assert out.dtype == self.out_dtype and len(out) >= len(ptasks)
-        self._keep = (params, ptasks, out)
-        self._chk(lib().bsw_submit_packed(self.handle, params.ctypes.data, ptasks.ctypes.data, len(ptasks), out.ctypes.data), "bsw_submit_packed")
-        return out
+        return self._submit(lib().bsw_submit_packed_t, "bsw_submit_packed", params, ptasks, out)
 
     def extend_pairs_packed(self, params, ptasks, out=None):
         out = self.submit_packed(params, ptasks, out)
@@ -482,12 +520,7 @@ class BswContext:
 
     def submit_ref(self, params, ref, rtasks, out=None):
         """Streaming form of extend_ref (finish with wait()): only the reads cross PCIe."""
-        if out is None:
-            out = np.zeros(len(rtasks), dtype=self.out_dtype)
-        assert out.dtype == self.out_dtype and len(out) >= len(rtasks)
-        self._keep = (params, rtasks, out)
-        self._chk(lib().bsw_submit_ref(self.handle, params.ctypes.data, ref, rtasks.ctypes.data, len(rtasks), out.ctypes.data), "bsw_submit_ref")
-        return out
+        return self._submit(lib().bsw_submit_ref_t, "bsw_submit_ref", params, rtasks, out, ref)
 
     def refbatch_run(self, in_words, variant=VARIANT_H, zdrop=0):
         in_words = np.ascontiguousarray(in_words, dtype=np.uint32)

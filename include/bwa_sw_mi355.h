@@ -48,7 +48,7 @@ extern "C" {
 #define BSW_E_LIMIT      (-3)  /* task outside device limits (see BSW_MAX_*)      */
 #define BSW_E_HIP        (-4)  /* a HIP runtime call failed                       */
 #define BSW_E_NOMEM      (-5)
-#define BSW_E_BUSY       (-6)  /* submit while a previous submit is in flight     */
+#define BSW_E_BUSY       (-6)  /* BSW_MAX_INFLIGHT submits in flight already, or a synchronous call while one is */
 
 /* ---- device limits ------------------------------------------------------- */
 #define BSW_MAX_QLEN   1023    /* query side length per extension                 */
@@ -152,8 +152,10 @@ typedef struct bsw_config {
 /* ABI of this header.  bsw_config has no size field of its own: bsw_create() reads sizeof(bsw_config) of THIS header, so a
  * caller built against an older, shorter struct must use bsw_create_sized() with ITS sizeof (fields beyond it take their
  * defaults) — or check bsw_abi_version() == BSW_ABI_VERSION at start-up.  History: 3 = 96-byte config; 4 = result_format
- * (104 bytes); 5 = pin_threads in the former padding, bsw_create_sized, bsw_chain_timeouts. */
-#define BSW_ABI_VERSION 5
+ * (104 bytes); 5 = pin_threads in the former padding, bsw_create_sized, bsw_chain_timeouts; 6 = tickets (bsw_submit*_t,
+ * bsw_wait_ticket, bsw_test: BSW_MAX_INFLIGHT submits per context where 5 answered BSW_E_BUSY to the second), bsw_host_stats,
+ * bsw_upload_raw / bsw_run_staged, bsw_default_config writes timeout_ms = 0 (bsw_effective_timeout_ms). */
+#define BSW_ABI_VERSION 6
 
 #define BSW_RESULT_FULL  0
 #define BSW_RESULT_PAIR  1
@@ -214,9 +216,33 @@ int      bsw_host_unregister(void *p);
 
 /* Asynchronous: validates lengths, DMAs the raw sequences to the device in chunks (chunk k ->
  * device k mod n_devices), packs + bins them there, launches, copies results back into out[] in
- * TASK ORDER.  out[] and the task sequences must stay valid until bsw_wait returns.        */
+ * TASK ORDER.  out[], tasks[] and the task sequences must stay valid until the submit has been waited for.
+ * Up to BSW_MAX_INFLIGHT submits may be in flight per context (the reference's manager keeps four task batches
+ * going: batch_manager.v:343-348 request bits, :434-435 busy bitmap); their chunks run through the context's slots in
+ * submit order, so the tail of one overlaps the head of the next.  One more than that answers BSW_E_BUSY.
+ * bsw_wait waits for ALL of them and returns the first failure in submit order. */
+#define BSW_MAX_INFLIGHT 4
+typedef uint64_t bsw_ticket;            /* names one submit; never 0 */
 int      bsw_submit(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out);
 int      bsw_wait(bsw_ctx *ctx);
+/* the same submit, handing back its ticket (ticket may be NULL) */
+int      bsw_submit_t(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out, bsw_ticket *ticket);
+/* wait for ONE submit and collect it: its error code, BSW_E_INVAL for a ticket that is not in flight */
+int      bsw_wait_ticket(bsw_ctx *ctx, bsw_ticket ticket);
+/* the host's status poll (the busy nibble at DSM + 0x40, batch_manager.v:844-854): 1 = complete (out[] is filled; collect the
+ * submit and its error code with bsw_wait_ticket / bsw_wait), 0 = in flight, < 0 = no such ticket.  Never blocks. */
+int      bsw_test(bsw_ctx *ctx, bsw_ticket ticket);
+int      bsw_inflight(bsw_ctx *ctx);    /* submits not collected by a wait yet */
+/* What the host side of the streaming path has cost so far: CPU time of the context's slot threads (validate, lay out,
+ * count, start DMAs, poll) and of the gather helpers (sequences outside registered memory), and the volume moved.  out_size
+ * = the caller's sizeof(bsw_stats). */
+typedef struct bsw_stats {
+    uint64_t slot_cpu_ns, helper_cpu_ns;    /* CLOCK_THREAD_CPUTIME_ID, summed over threads */
+    uint64_t seeds, chunks, submits;
+    uint64_t h2d_bytes, d2h_bytes;
+    uint64_t slot_threads;
+} bsw_stats;
+int      bsw_host_stats(bsw_ctx *ctx, bsw_stats *out, size_t out_size);
 /* The same for callers that keep sequences 4-BIT PACKED: the bsw_task pointers then address uint64 words, 16 bases
  * each (base k in bits [4k, 4k+3]; codes 0-3 = ACGT, 4-7 = N), every sequence starting on an 8-byte boundary; the
  * lengths stay in bases; the unused nibbles behind a sequence's last base may hold anything.  This is the device's own layout and the encoding the reference ships over its link (8 bases
@@ -224,6 +250,7 @@ int      bsw_wait(bsw_ctx *ctx);
  * memory are DMA'd straight into the sequence buffer — no pack kernel, ~0.6x the PCIe bytes per seed of bsw_submit.
  * bsw_pack_bases() packs one byte-per-base sequence; bsw_pack_tasks() a whole task array. */
 int      bsw_submit_packed(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out);
+int      bsw_submit_packed_t(bsw_ctx *ctx, const bsw_params *p, const bsw_task *tasks, size_t n, bsw_result *out, bsw_ticket *ticket);
 /* tasks[0..n) (byte per base) -> out[0..n) with the sequences packed into `arena` (8-byte aligned, `cap` bytes);
  * returns the bytes used or <0 (BSW_E_NOMEM: arena too small).  bsw_pack_tasks_bound() = a sufficient `cap`. */
 int64_t  bsw_pack_tasks(const bsw_task *tasks, size_t n, uint64_t *arena, size_t cap, bsw_task *out);
@@ -400,6 +427,7 @@ int      bsw_upload_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, c
  * its own copy of the reference (bsw_ref_upload puts one on each GPU of the context).  Only the reads cross PCIe
  * (~1/2.5 of the bytes of bsw_submit at 150 bp); reads in bsw_host_alloc / registered memory are DMA'd as they are. */
 int      bsw_submit_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *tasks, size_t n, bsw_result *out);
+int      bsw_submit_ref_t(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *tasks, size_t n, bsw_result *out, bsw_ticket *ticket);
 /* convenience: upload_ref + run + download + free (synchronous) */
 int      bsw_extend_ref(bsw_ctx *ctx, const bsw_params *p, const bsw_ref *ref, const bsw_ref_task *tasks, size_t n, bsw_result *out);
 

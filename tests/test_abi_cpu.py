@@ -264,10 +264,10 @@ def test_abi_version_and_sized_create(host):
     import re
     L = host.lib()
     hdr = open(os.path.join(ROOT, "include", "bwa_sw_mi355.h")).read()
-    assert L.bsw_abi_version() == int(re.search(r"#define BSW_ABI_VERSION (\d+)", hdr).group(1)) == 5
+    assert L.bsw_abi_version() == int(re.search(r"#define BSW_ABI_VERSION (\d+)", hdr).group(1)) == 6
     cfg = np.zeros(1, dtype=host.CONFIG)
     L.bsw_default_config(cfg.ctypes.data)
-    assert cfg["pin_threads"][0] == 1 and cfg["timeout_ms"][0] == 120000 and cfg["result_format"][0] == host.RESULT_FULL
+    assert cfg["pin_threads"][0] == 1 and cfg["timeout_ms"][0] == 0 and cfg["result_format"][0] == host.RESULT_FULL
     h = C.c_void_p()
     for bad in (0, 8, host.CONFIG.itemsize + 8, 4096):
         assert L.bsw_create_sized(cfg.ctypes.data, bad, C.byref(h)) == -2 and not h.value          # BSW_E_INVAL
@@ -275,3 +275,22 @@ def test_abi_version_and_sized_create(host):
     if not torch.cuda.is_available():       # the accepted sizes get as far as the device check (ABI 3: 96 bytes, ABI 4/5: 104)
         for ok in (96, host.CONFIG.itemsize):
             assert L.bsw_create_sized(cfg.ctypes.data, ok, C.byref(h)) == -1 and not h.value        # BSW_E_NODEVICE
+
+
+def test_default_config_leaves_the_watchdog_to_the_environment(host, monkeypatch):
+    """bsw_default_config wrote timeout_ms = 120000, so BSW_TIMEOUT_MS was dead for every host that starts from
+    the defaults.  Now 0 = the library default, resolved by bsw_effective_timeout_ms (what bsw_create_sized stores)."""
+    cfg = np.zeros(1, dtype=host.CONFIG)
+    host.lib().bsw_default_config(cfg.ctypes.data)
+    assert int(cfg["timeout_ms"][0]) == 0
+    monkeypatch.delenv("BSW_TIMEOUT_MS", raising=False)
+    assert host.lib().bsw_effective_timeout_ms(cfg.ctypes.data) == 120000
+    assert host.lib().bsw_effective_timeout_ms(None) == 120000
+    monkeypatch.setenv("BSW_TIMEOUT_MS", "5000")
+    assert host.lib().bsw_effective_timeout_ms(cfg.ctypes.data) == 5000
+    monkeypatch.setenv("BSW_TIMEOUT_MS", "junk")
+    assert host.lib().bsw_effective_timeout_ms(cfg.ctypes.data) == 120000
+    cfg["timeout_ms"] = 250
+    monkeypatch.setenv("BSW_TIMEOUT_MS", "5000")
+    assert host.lib().bsw_effective_timeout_ms(cfg.ctypes.data) == 250          # explicit wins
+    assert host.lib().bsw_abi_version() == 6

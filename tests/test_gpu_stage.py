@@ -381,11 +381,14 @@ def test_busy_context_refuses_other_entry_points(host):
         with pytest.raises(host.BswError) as ei:
             c.upload(p, tasks[:10])
         assert ei.value.code == -6
+        more = [c.submit(p, tasks[:10]) for _ in range(host.MAX_INFLIGHT - 1)]        # ABI 6: a context keeps MAX_INFLIGHT submits going
         with pytest.raises(host.BswError) as ei:
             c.submit(p, tasks[:10])
-        assert ei.value.code == -6
+        assert ei.value.code == -6 and c.inflight() == host.MAX_INFLIGHT
         c.wait()
+        assert c.inflight() == 0
         assert (out["tag"] == np.arange(len(tasks), dtype=np.uint32)).all()
+        assert all((m["tag"] == np.arange(10, dtype=np.uint32)).all() for m in more)
 
 
 def test_watchdog_marks_the_context_dead(host):
