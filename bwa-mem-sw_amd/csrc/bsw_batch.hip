@@ -82,7 +82,7 @@ BSW_LOCAL void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_
  * out by direct DMA the pack kernel subtracts raw_bias, otherwise gather_offsets() replaces them. */
 template <class Src>
 static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, size_t n, bool dev_targets,
-                           bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left, bool packed = false)
+                           bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left, bool packed = false, size_t idx0 = 0 /* index of the chunk's first seed in the caller's array: error texts name the caller's index */)
 {
     ci.packed = packed;
     const int mx = mat_max(p->mat);
@@ -133,16 +133,16 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         if (!tp) return rc;
         const bsw_task &t = *tp;
         if (t.lqlen < 0 || t.rqlen < 0 || t.ltlen < 0 || t.rtlen < 0)
-            return fail(e, BSW_E_INVAL, "task %zu: negative length", i);
+            return fail(e, BSW_E_INVAL, "task %zu: negative length", i + idx0);
         if (t.lqlen > BSW_MAX_QLEN || t.rqlen > BSW_MAX_QLEN || t.ltlen > BSW_MAX_TLEN || t.rtlen > BSW_MAX_TLEN)
-            return fail(e, BSW_E_LIMIT, "task %zu: length beyond BSW_MAX_QLEN/BSW_MAX_TLEN", i);
-        if (t.h0 <= 0) return fail(e, BSW_E_INVAL, "task %zu: h0 must be > 0", i);
+            return fail(e, BSW_E_LIMIT, "task %zu: length beyond BSW_MAX_QLEN/BSW_MAX_TLEN", i + idx0);
+        if (t.h0 <= 0) return fail(e, BSW_E_INVAL, "task %zu: h0 must be > 0", i + idx0);
         if ((int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * mx >= BSW_MAX_SCORE)
-            return fail(e, BSW_E_LIMIT, "task %zu: score range beyond BSW_MAX_SCORE", i);
+            return fail(e, BSW_E_LIMIT, "task %zu: score range beyond BSW_MAX_SCORE", i + idx0);
         if ((t.lqlen && (!t.lquery || (t.ltlen && !t.ltarget && !dev_targets))) ||
             (t.rqlen && (!t.rquery || (t.rtlen && !t.rtarget && !dev_targets))))
-            return fail(e, BSW_E_INVAL, "task %zu: NULL sequence pointer", i);
-        if (t.wlim_l < 0 || t.wlim_r < 0) return fail(e, BSW_E_INVAL, "task %zu: negative wlim", i);
+            return fail(e, BSW_E_INVAL, "task %zu: NULL sequence pointer", i + idx0);
+        if (t.wlim_l < 0 || t.wlim_r < 0) return fail(e, BSW_E_INVAL, "task %zu: negative wlim", i + idx0);
         bsw_dtask d;                                /* built here, stored once: dt[] is write-combined staging */
         bsw_rawoff r;
         memset(&d, 0, sizeof(d));
@@ -152,7 +152,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
              * 8-byte boundary: the spans are whole words, rawoff keeps the pointers' low bits until the arena base is known */
             if ((t.lqlen && (((uintptr_t)t.lquery | (t.ltlen ? (uintptr_t)t.ltarget : 0)) & 7)) ||
                 (t.rqlen && (((uintptr_t)t.rquery | (t.rtlen ? (uintptr_t)t.rtarget : 0)) & 7)))
-                return fail(e, BSW_E_INVAL, "task %zu: packed sequences must start on 8-byte boundaries", i);
+                return fail(e, BSW_E_INVAL, "task %zu: packed sequences must start on 8-byte boundaries", i + idx0);
             /* direct: the registered arena IS the device's seq buffer, word offsets relative to its lowest word (an empty
              * target takes its query's offset: word 0 of a target may be read even when no row is) */
             if (t.lqlen) {
@@ -198,7 +198,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         /* class counts (the device sorts with the same functions) */
         const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
         const int wc = bsw_wave_class_of(&bp, qm);
-        if (wc < 0) return fail(e, BSW_E_LIMIT, "task %zu: no kernel class", i);
+        if (wc < 0) return fail(e, BSW_E_LIMIT, "task %zu: no kernel class", i + idx0);
         ++cw_all[wc];
         const int bits = bsw_seed_lane_bits(&bp, t.lqlen, t.rqlen, t.h0);
         if (!bits) ++cw[wc];
@@ -207,14 +207,14 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
             int lc = -1;
             if (t.lqlen) {
                 const int c = lc = bsw_side_lane_class(&bp, bits, t.lqlen);
-                if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i);
+                if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i + idx0);
                 ++cl[c];
                 lane_work[c] += (uint64_t)t.lqlen;
                 h0_lo = std::min(h0_lo, t.h0); h0_hi = std::max(h0_hi, t.h0);
             }
             if (t.rqlen) {
                 const int c = bsw_side_lane_class(&bp, bits, t.rqlen);
-                if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i);
+                if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i + idx0);
                 ++cr[c];
                 lane_work[c] += (uint64_t)t.rqlen;
                 if (lc >= 0) dep[lc] |= (uint8_t)(1u << c);
@@ -295,9 +295,9 @@ static void gather_offsets(const bsw_task *tasks, size_t n, bool dev_targets, bs
 }
 
 static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task *tasks, size_t n, bool dev_targets,
-                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left = false, bool packed = false)
+                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left = false, bool packed = false, size_t idx0 = 0)
 {
-    int rc = prepare_chunk_t(e, p, kern, [tasks](size_t i, bsw_task &, int &) { return tasks + i; }, n, dev_targets, dt, ro, ci, rev_left, packed);
+    int rc = prepare_chunk_t(e, p, kern, [tasks](size_t i, bsw_task &, int &) { return tasks + i; }, n, dev_targets, dt, ro, ci, rev_left, packed, idx0);
     if (!rc && !ci.direct && !packed) gather_offsets(tasks, n, dev_targets, ro);
     return rc;
 }
@@ -1345,7 +1345,7 @@ static void slot_main(bsw_ctx *ctx, size_t d, size_t s)
                     erc = ref_to_task(e, &p, t->ref->l_pac, crt[i], base + i, true, nullptr, so, tmp);
                     rx[i] = bsw_refx{crt[i].seed.rbeg - 1, crt[i].seed.rbeg + crt[i].seed.len};
                     return erc ? nullptr : &tmp;
-                }, n, true, st.h_tasks.p, st.h_roff.p, ci, true);
+                }, n, true, st.h_tasks.p, st.h_roff.p, ci, true, false, base);
                 if (rc) break;
                 if (!ci.direct) {                   /* reads in pageable memory: materialise the tasks for the gather */
                     rt_tasks.resize(n);
@@ -1354,7 +1354,7 @@ static void slot_main(bsw_ctx *ctx, size_t d, size_t s)
                     ct = rt_tasks.data();
                     gather_offsets(ct, n, true, st.h_roff.p);
                 }
-            } else if ((rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci, false, t->packed))) break;
+            } else if ((rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci, false, t->packed, base))) break;
             if (!ci.direct) {
                 if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) { rc = fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)); break; }
                 if (t->packed) gather_packed(ct, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
