@@ -430,8 +430,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the single-bin / 250 bp / side-path measurements (N=1 only, outside the timed region)")
     ap.add_argument("--other-seeds", type=int, default=1_000_000, help="seeds of the other_workloads legs")
-    ap.add_argument("--packed-chunk", type=int, default=114688, help="seeds per chunk of the packed-input single-submit legs (112 Ki; profiles/r5/e2e_packed_chunk_sweep.txt)")
-    ap.add_argument("--e2e-chunk", type=int, default=131072, help="seeds per chunk of the byte-input and device-reference single-submit legs")
+    ap.add_argument("--packed-chunk", type=int, default=0, help="seeds per chunk of the packed-input legs (0 = the library's choice: sized by the seeds' work, bsw_config.chunk_tasks = 0)")
+    ap.add_argument("--e2e-chunk", type=int, default=0, help="seeds per chunk of the byte-input and device-reference legs (0 = the library's choice)")
     ap.add_argument("--e2e-slots", type=int, default=4, help="slot threads (= streams) of the PCIe-inclusive legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bsw_submit (PCIe-inclusive) measurements")
     ap.add_argument("--e2e-reps", type=int, default=5, help="bsw_submit passes timed (median reported)")
@@ -687,7 +687,7 @@ def main():
         barrier()
         return d, before
 
-    STREAM_CHUNK = {"bytes": 2 * chunk, "packed": 131072, "ref": chunk}
+    STREAM_CHUNK = {"bytes": args.e2e_chunk, "packed": args.packed_chunk, "ref": args.e2e_chunk}
     for kind in list(STREAM_CHUNK):                       # (measurements) BENCH_STREAM_PACKED=chunk etc.
         ov = os.environ.get("BENCH_STREAM_" + kind.upper())
         if ov:

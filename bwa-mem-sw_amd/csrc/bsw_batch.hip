@@ -75,6 +75,34 @@ BSW_LOCAL void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_
     bp.lane_cols[0] = 0;
 }
 
+BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint32_t &n_lane, uint32_t n16, uint32_t *cl, uint32_t *cr,
+                                uint32_t *cw, const uint32_t *cw16, uint8_t *dep)
+{
+    /* BSW_GROUP=0: never the group kernel; 1: the group kernel for every chunk with lane seeds (tests, measurements);
+     * BSW_GROUP_MIN=n: the threshold */
+    static const int genv = getenv("BSW_GROUP") ? atoi(getenv("BSW_GROUP")) : -1;
+    static const uint32_t gmin = getenv("BSW_GROUP_MIN") ? (uint32_t)atoi(getenv("BSW_GROUP_MIN")) : (uint32_t)GROUP_AUTO_MIN;
+    if (!bp.lane_on) return false;
+    uint32_t l8 = 0, r8 = 0;
+    for (int c = 0; c < bp.n_lane; ++c)
+        if (bp.lane_bits[c] == 8) { l8 += cl[c]; r8 += cr[c]; }
+    const uint32_t sides8 = (l8 ? 1u : 0u) + (r8 ? 1u : 0u), n8 = n_lane - n16;
+    bool group = false;
+    if (genv == 1) group = group_ok && n8 > 0 && kern != BSW_KERNEL_WAVE;
+    else if (kern == BSW_KERNEL_AUTO && !lane_bins_pay(n_lane, cl, cr)) {
+        group = genv != 0 && group_ok && n8 >= gmin * (sides8 ? sides8 : 1u);
+        if (!group) { bp.lane_on = 0; return false; }
+    }
+    if (!group) return false;
+    /* the group kernel serves the 8-bit classes; the chunk's 16-bit seeds (scores beyond 255) go to the general kernel */
+    bp.cols16 = 0;
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c)
+        if (c < bp.n_lane && bp.lane_bits[c] == 16) { cl[c] = cr[c] = 0; if (dep) dep[c] = 0; }
+    for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) cw[c] += cw16[c];
+    n_lane -= n16;
+    return true;
+}
+
 /* tasks[0..n) -> dt[0..n) (device task records), ro[0..n) (gather layout of the raw bytes), class counts -> plan */
 /* One pass over the seeds of a chunk: validate, lay the 4-bit arena out, count the kernel classes.  `src(i, tmp, rc)`
  * hands out seed i as a bsw_task (a pointer into the caller's array, or `tmp` filled on the fly — bsw_submit_ref never
@@ -91,8 +119,8 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     bsw_binparams &bp = ci.bp;
     uint64_t acc = 0, accb = 0;
     const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
-    uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0};
-    uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0;
+    uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cw16[BSW_MAX_WAVE_CLASSES] = {0};
+    uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0, n16 = 0;
     uint8_t dep[BSW_MAX_LANE_CLASSES] = {0};
     uint64_t lane_work[BSW_MAX_LANE_CLASSES] = {0};          /* sum of query lengths per lane class (narrow_fold) */
     int h0_lo = INT_MAX, h0_hi = 0;                          /* h0 range of the left sides that go to lane classes (bsw_h0_bucket) */
@@ -204,6 +232,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         if (!bits) ++cw[wc];
         else {
             ++n_lane;
+            if (bits == 16) { ++n16; ++cw16[wc]; }
             int lc = -1;
             if (t.lqlen) {
                 const int c = lc = bsw_side_lane_class(&bp, bits, t.lqlen);
@@ -223,11 +252,18 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     }
     if (acc >= (1ull << 32)) return fail(e, BSW_E_LIMIT, "batch sequence arena beyond 2^32 words; split the batch");
     if (accb >= (1ull << 32) - RAW_SLACK) return fail(e, BSW_E_LIMIT, "batch holds more than 4 GiB of bases; split the batch");
-    if (kern == BSW_KERNEL_AUTO && !lane_bins_pay(n_lane, cl, cr)) bp.lane_on = 0;
+    bool group = false;
+    {
+        bsw_dparams dpx;
+        errs quiet;
+        const bool group_ok = check_params(quiet, p, &dpx) == BSW_OK && bsw::lane_class_finishes(0, dpx, p->variant);
+        group = decide_lane_mode(kern, group_ok, bp, n_lane, n16, cl, cr, cw, cw16, dep);
+    }
     if (bp.lane_on && narrow_foldable(bp)) {
         uint64_t all8 = 0;
         for (int c = 0; c < bp.n_lane; ++c) if (bp.lane_bits[c] == bp.lane_bits[0]) all8 += lane_work[c];
-        if ((double)lane_work[0] < narrow_min_share() * (double)all8) narrow_fold(bp, cl, cr, dep);
+        /* (the group kernel runs one instantiation for both 8-bit classes up to 136 columns: one launch per side) */
+        if (group || (double)lane_work[0] < narrow_min_share() * (double)all8) narrow_fold(bp, cl, cr, dep);
     }
     if (!bp.lane_on) {
         memcpy(cw, cw_all, sizeof(cw));
@@ -250,6 +286,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     pl.redo_off = cur;
     pl.order_len = cur + n_lane;
     pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
+    pl.lane_group = group ? 1 : 0;
     memcpy(pl.dep, dep, sizeof(pl.dep));
     memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
     bp.lane_all_off = pl.lane_all_off;
@@ -451,6 +488,7 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
         for (int c = 0; c < nlc && all; ++c)
             if ((pl.laneL_off[c + 1] - pl.laneL_off[c] || pl.laneR_off[c + 1] - pl.laneR_off[c]) && !bsw::lane_class_finishes(c, *J.P, J.variant)) all = false;
         fins[j].redo = J.d_order + pl.redo_off; fins[j].redo_cnt = J.d_order + pl.order_len; fins[j].pairs = J.d_pair; fins[j].on = all ? 1 : 0;
+        fins[j].group = pl.lane_group;
     }
     auto fin_of = [&](int j) -> const bsw_fin * { return j < MAXJ ? &fins[j] : nullptr; };
     struct link { int job, side, cls; uint32_t off, cnt; };
@@ -458,7 +496,9 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
     link chain[MAXL];
     int nchain = 0;
     bool chain_pays = false;
-    if (fk && fk->mode == 2) {
+    bool any_group = false;
+    for (int j = 0; j < nj; ++j) any_group = any_group || jobs[j].pl->lane_group;
+    if (fk && fk->mode == 2 && !any_group) {        /* (the group kernel's launches are short: nothing for a chain to fill) */
         bool fits = true;
         for (int side = 0; side < 2; ++side)
             for (int j = 0; j < nj; ++j) {
@@ -1488,7 +1528,30 @@ static int submit_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *task
     const size_t G = ctx->devs.size();
     std::unique_ptr<ticket_t> t(new ticket_t());
     t->p = *p; t->dp = dp; t->tasks = tasks; t->ref = ref; t->rtasks = rtasks; t->out = out; t->packed = packed; t->n = n;
-    const std::vector<std::vector<chunk_span>> chunks = plan_chunks(n, ctx->cfg.chunk_tasks, G);
+    /* chunk_tasks = 0 (the default): sized by WORK, not by seeds.  A chunk's launches must fill the machine — 128 Ki seeds of
+     * the 150 bp single bin (131-base sides) do; PE seeds with their two shorter sides hold half the cells per seed and want
+     * twice the seeds (sweep on 4 M PE seeds, profiles/r6/e2e_pe_chunk_sweep.txt: packed input 67 / 91 / 104 / 86 M seeds/s
+     * for 128 / 192 / 256 / 384 Ki).  Work of a seed ~ lqlen^2 + rqlen^2 (rows x live columns both grow with the side), taken
+     * over a strided sample of the submit. */
+    size_t chunk = ctx->cfg.chunk_tasks;
+    if (chunk == 0) {
+        chunk = 131072;
+        if (n > 0) {
+            const size_t step = std::max<size_t>(1, n / 2048);
+            double acc = 0;
+            size_t cnt = 0;
+            for (size_t i = 0; i < n; i += step, ++cnt) {
+                double l, r;
+                if (rtasks) { l = rtasks[i].seed.qbeg; r = rtasks[i].l_query - rtasks[i].seed.qbeg - rtasks[i].seed.len; }
+                else { l = tasks[i].lqlen; r = tasks[i].rqlen; }
+                acc += l * l + r * r;
+            }
+            const double mean = cnt ? acc / (double)cnt : 0.0;
+            if (mean > 1.0) chunk = (size_t)std::min(524288.0, std::max(65536.0, 131072.0 * (131.0 * 131.0) / mean));
+            chunk = (chunk + 8191) & ~(size_t)8191;
+        }
+    }
+    const std::vector<std::vector<chunk_span>> chunks = plan_chunks(n, chunk, G);
     size_t total = 0;
     for (const auto &v : chunks) total += v.size();
     t->remaining = total;

@@ -129,7 +129,7 @@ extern "C" void bsw_default_config(bsw_config *c)
     c->kernel = BSW_KERNEL_AUTO;
     c->streams = 4;
     c->pack_threads = 4;
-    c->chunk_tasks = 131072;
+    c->chunk_tasks = 0;               /* 0 = sized per submit by the seeds' work (bsw_batch.hip: submit_common) */
     c->n_devices = 0;
     c->timeout_ms = 0;                /* 0 = the library default: BSW_TIMEOUT_MS if set, else 120 s (bsw_effective_timeout_ms) */
     c->result_format = BSW_RESULT_FULL;
@@ -281,7 +281,6 @@ extern "C" int bsw_create_sized(const bsw_config *cfg, size_t cfg_size, bsw_ctx 
     if (c.streams < 1) c.streams = 2;
     if (c.streams > 8) c.streams = 8;
     if (c.pack_threads < 1) c.pack_threads = 1;
-    if (c.chunk_tasks == 0) c.chunk_tasks = 131072;
     /* BSW_TIMEOUT_MS is the DEFAULT for hosts that pass no timeout of their own; an explicit bsw_config.timeout_ms wins */
     c.timeout_ms = bsw_effective_timeout_ms(&c);
     if (c.n_devices < 0 || c.n_devices > BSW_MAX_DEVICES) return BSW_E_INVAL;

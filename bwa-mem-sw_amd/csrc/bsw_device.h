@@ -152,6 +152,8 @@ typedef struct bsw_fin {
     uint32_t *redo, *redo_cnt;                 /* the chunk's redo list and its length (device words) */
     bsw_pair *pairs;                           /* BSW_RESULT_PAIR: the dense 32-byte records; else NULL */
     int on;                                    /* 0: the lane kernels only store their side (bsw_pair_finalize follows) */
+    int group;                                 /* 1: the chunk is mid-sized — its 8-bit lane launches run bsw_lane2g_kernel (a seed pair
+                                                  per group of eight lanes, 16 seeds per wavefront) instead of the 128-seed kernels */
 } bsw_fin;
 
 #if defined(__HIPCC__) || defined(__HIP__)

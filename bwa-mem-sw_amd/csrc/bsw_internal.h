@@ -55,6 +55,10 @@ inline bool lane_bins_pay(uint32_t n_lane, const uint32_t *cl, const uint32_t *c
     const uint32_t sides = (l ? 1u : 0u) + (r ? 1u : 0u);
     return n_lane >= (uint32_t)LANE_AUTO_MIN * (sides ? sides : 1u);
 }
+/* Below that, a chunk with at least GROUP_AUTO_MIN 8-bit lane seeds per launched side runs its lane launches on
+ * bsw_lane2g_kernel (a seed pair per group of eight lanes: 16 seeds per wavefront, a tenth of the lane kernels' wave
+ * lifetime); smaller ones still take the general kernels (one wavefront per seed: every seed starts at once). */
+#define GROUP_AUTO_MIN 3000
 #define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
 #define RAW_FRONT 32                 /* ... and in front of the first one (reversed left queries) */
 
@@ -67,6 +71,7 @@ struct batch_plan {
     uint32_t redo_off = 0;
     uint32_t order_len = 0;          /* entries before the redo counter */
     int redo_cls = 0;
+    int lane_group = 0;              /* 1: the lane launches of this chunk run the eight-lanes-per-seed-pair kernel (bsw_fin.group) */
     /* dep[lc] bit rc: some seed has its left side in lane class lc and its right side in lane class rc — the right-side
      * launch of class rc then has to wait for the left-side launch of class lc (h0 of the right extension is the score
      * after the left one, sw_pe_array_proc_element.v:1671).  All ones = not known. */
@@ -312,6 +317,11 @@ struct gate_turn {                    /* this chunk's place in its device's inpu
     bool *passed = nullptr;           /* set once the turn has been passed on */
 };
 BSW_LOCAL size_t order_capacity(size_t n);
+/* AUTO policy of a chunk once its seeds are counted: lane bins (128 seeds per wavefront), the group kernel (16 per wavefront;
+ * returns true — the 16-bit seeds then leave the lane lists for the general kernel: cw16 = their count per wave class, n16
+ * their number) or no lane launches at all (bp.lane_on = 0).  group_ok: the scoring parameters allow the packed kernels. */
+BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint32_t &n_lane, uint32_t n16, uint32_t *cl, uint32_t *cr,
+                                uint32_t *cw, const uint32_t *cw16, uint8_t *dep);
 BSW_LOCAL int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams &bp);
 BSW_LOCAL bool narrow_foldable(const bsw_binparams &bp);
 BSW_LOCAL void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_t *dep);

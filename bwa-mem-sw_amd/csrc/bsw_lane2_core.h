@@ -83,6 +83,10 @@ L2_FN uint32_t pk_neg(uint32_t a) { uint32_t d; asm("v_pk_sub_u16 %0, 0, %1" : "
 L2_FN uint32_t byte_pair_dyn(uint32_t a, uint32_t b, uint32_t k) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(0x0c000c00u + k * 0x00010001u + 0x00040000u)); return d; }
 L2_FN int popc(uint32_t x) { return __builtin_popcount(x); }
 L2_FN int clz32(uint32_t x) { return __builtin_clz(x); }
+/* (lane2g) the same byte pair with the selector in a VGPR: sel = 0x0c000c00 | kA | (4 + kB) << 16 picks byte kA of a and byte kB of b */
+L2_FN uint32_t byte_pair_sel(uint32_t a, uint32_t b, uint32_t sel) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "v"(sel)); return d; }
+/* per half: a << (sh & 15), the shift amounts in the halves of sh */
+L2_FN uint32_t pk_shlv(uint32_t sh, uint32_t a) { uint32_t d; asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(d) : "v"(sh), "v"(a)); return d; }
 /* the looped kernel's per-block folds (row maximum, K8 trackers: see lane2l::row_body) as one aligned statement, ordered so
  * that no packed result is read by the instruction behind it */
 template <bool GRID = true>
@@ -160,6 +164,8 @@ L2_FN uint32_t pk_neg(uint32_t a) { return pk_sub(0u, a); }
 L2_FN uint32_t byte_pair_dyn(uint32_t a, uint32_t b, uint32_t k) { return ((a >> (8 * k)) & 0xffu) | (((b >> (8 * k)) & 0xffu) << 16); }
 L2_FN int popc(uint32_t x) { return __builtin_popcount(x); }
 L2_FN int clz32(uint32_t x) { return __builtin_clz(x); }
+L2_FN uint32_t byte_pair_sel(uint32_t a, uint32_t b, uint32_t sel) { return ((a >> (8 * (sel & 3u))) & 0xffu) | (((b >> (8 * ((sel >> 16) & 3u))) & 0xffu) << 16); }
+L2_FN uint32_t pk_shlv(uint32_t sh, uint32_t a) { return mk2((uint32_t)(uint16_t)(lo16(a) << (lo16(sh) & 15)), (uint32_t)(uint16_t)(hi16(a) << (hi16(sh) & 15))); }
 L2_FN uint32_t pk_subs_sv(uint32_t sa, uint32_t b) { return pk_subs(sa, b); }
 L2_FN uint32_t pk_sub_sv(uint32_t sa, uint32_t b) { return pk_sub(sa, b); }
 L2_FN uint32_t pk_adds(uint32_t a, uint32_t b) { return pk_adds_vs(a, b); }
@@ -825,6 +831,167 @@ struct lane2l {
         }
         L2_STAMP(3);
         row_tail2<SYM>(p, k, i, r.ACT, h1, mk2, Fnz, Lnz);        /* K7, K8 for both seeds at once */
+    }
+};
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * lane2g: the same packed arithmetic with a seed PAIR spread over a GROUP of eight lanes — the kernel between the general
+ * ones (one / four seeds per wavefront, int32) and the lane kernels (128 seeds per wavefront, one lane walks a whole row:
+ * a launch lasts one wave's lifetime, ~1 ms per 131-column side, however few seeds it holds).  Here a wavefront holds 16
+ * seeds and lives a tenth as long (bsw_lane2g_kernel.hip: batches of a few thousand to ~100 k seeds, wire-format groups).
+ *   Columns are STRIPED: lane g of the group owns the 8-column block j0 = 64 s + 8 g of stripe s = 0 .. NS-1, in registers
+ *   for the whole extension (T[s][c] = eh[j0 + c], both seeds packed as in lane2).  A row costs the stripes between the
+ *   smallest beg and the largest end of the wavefront's seeds.
+ *   The columns of a row depend on each other through f (the horizontal gap) and through H(i, j-1) in the stored pair:
+ *   - f: a lane first works out what its block OFFERS the columns right of it with nothing coming in (phase_a: the f
+ *     recurrence over max(M, e) — what f itself adds to h never matters to the next f, because o_ins >= 0), the offers
+ *     are combined across the group by a max-plus prefix scan with a decay of 8 e_ins per lane (three DPP steps), and
+ *     the block body then runs ONCE with the true f entering it (phase_b = lane2::block8, the very cell of the lane kernels);
+ *   - H(i, j0 - 1), needed only for the stored eh[j0] of the NEXT row, is the left neighbour's last h of THIS row: the body
+ *     runs with 0 in its place and phase_c puts the true byte (and the column's non-zero bit) in afterwards.
+ *   Everything per seed (pairv, K3 / K7 / K8) is computed redundantly by the eight lanes of the group; the row maximum, the
+ *   first / last non-zero trackers and eh[end].h are reduced over the group by three-step DPP butterflies.
+ * The phases are per-lane functions so that the CPU model of the tests (tests/lane2_model.cpp) runs THIS code with the
+ * exchanges between them restated as array shifts. */
+template <int NS, bool VM = false, bool SYM = true>
+struct lane2g {
+    using B = lane2<8 * NS, VM, SYM>;
+    static constexpr int G = 8, COLS = 64 * NS;
+
+    struct state {
+        uint32_t T[NS][8];              /* T[s][c] = eh[64 s + 8 g + c], half = {e:8 | h:8} */
+        pairv p;
+    };
+    struct rowk {                       /* per-lane values of the current row (equal in the lanes of a group) */
+        uint32_t Bv2, D2;               /* mismatch / N penalties of this row's target bases, scaled (lane2::row_body) */
+        uint32_t tnm8;                  /* 0x00ff in a half whose target base is not an N (an N row has no match bits) */
+        uint32_t sel;                   /* byte selector of the two seeds' match bytes for this row's target bases */
+        uint32_t h1init;                /* K4: H(i, -1) scaled, 0 unless beg == 0 */
+        uint32_t BEG2, END2;
+    };
+    struct stripe_in { uint32_t Wc, WN, ENDr, mi_in, J0d; };
+
+    L2_MFN uint32_t j0_of(int s, int g) { return (uint32_t)(64 * s + 8 * g); }
+
+    /* K2 first row, closed form (sw_pe_array_sw_extend.v:1979,1957,1974) */
+    L2_MFN void init_row(state &S, const consts &k, const int g)
+    {
+        const int h00 = half_of(S.p.H0, 0), h01 = half_of(S.p.H0, 1);
+        sfor<NS>([&](auto si) {
+            constexpr int s = decltype(si)::value;
+            sfor<8>([&](auto ci) {
+                constexpr int c = decltype(ci)::value;
+                const int j = 64 * s + 8 * g + c;
+                const int v0 = j == 0 ? h00 : imax(h00 - k.oe_ins - (j - 1) * k.e_ins, 0);
+                const int v1 = j == 0 ? h01 : imax(h01 - k.oe_ins - (j - 1) * k.e_ins, 0);
+                S.T[s][c] = pack2(v0, v1);
+            });
+        });
+    }
+
+    /* the columns [zlo, zhi) a band clamp dropped are zeroed (rare), keeping "eh[j] == 0 below beg" */
+    L2_MFN void zero_dropped(state &S, const rowp &r, const int g)
+    {
+        sfor<NS>([&](auto si) {
+            constexpr int s = decltype(si)::value;
+            sfor<8>([&](auto ci) {
+                constexpr int c = decltype(ci)::value;
+                const uint32_t Jd = dup16(64 * s + 8 * g + c);
+                const uint32_t below_hi = pk_nzmask(pk_subs(r.ZHI, Jd));          /* J < zhi */
+                const uint32_t below_lo = pk_nzmask(pk_subs(r.ZLO, Jd));          /* J < zlo */
+                S.T[s][c] &= ~(r.BITE & below_hi & ~below_lo);
+            });
+        });
+    }
+
+    L2_MFN rowk row_consts(const pairv &p, const consts &k, const int i, const int (&tb)[2])
+    {
+        rowk rk;
+        const int pbA = tb[0] < 4 ? k.pb : k.pn, pbB = tb[1] < 4 ? k.pb : k.pn;
+        rk.Bv2 = pack2(pbA, pbB) << 8;
+        rk.D2 = pack2(pbA - k.pn, pbB - k.pn) << 8;
+        rk.tnm8 = (tb[0] < 4 ? 0x000000ffu : 0u) | (tb[1] < 4 ? 0x00ff0000u : 0u);
+        rk.sel = 0x0c000c00u | (uint32_t)(tb[0] & 3) | ((uint32_t)(4 + (tb[1] & 3)) << 16);
+        const uint32_t h1c = pk_subs_vs(p.H0, dup16(imin(k.o_del + k.e_del * (i + 1), 0xffff)));     /* K4, both seeds at once */
+        rk.h1init = pk_shl8(h1c & ~pk_nzmask(p.BEG));
+        rk.BEG2 = p.BEG; rk.END2 = p.END;
+        return rk;
+    }
+
+    /* does some seed of this lane need stripe s this row?  (columns [beg, end] — the column `end` takes a store) */
+    L2_MFN uint32_t needs_stripe(const rowk &rk, const uint32_t act, const int s)
+    {
+        const uint32_t left = pk_nzmask(pk_subs_sv(dup16(64 * s + 64), rk.BEG2));             /* beg < 64 (s + 1) */
+        const uint32_t right = pk_nzmask(pk_subs_vs(rk.END2 + 0x00010001u, dup16(64 * s)));   /* end + 1 > 64 s */
+        return act & left & right;
+    }
+
+    /* Phase A: the block's operands and its OFFER — f at the lane's exit when nothing enters it.  mA / mB: the four per-base
+     * match bytes of the block's columns (seed A / B), WNs: their query-N bits (A in [7:0], B in [23:16]). */
+    template <bool NQ>
+    L2_MFN uint32_t phase_a(const uint32_t (&T)[8], const rowk &rk, const consts &k, const uint32_t mA, const uint32_t mB,
+                            const uint32_t WNs, const uint32_t J0d, stripe_in &si)
+    {
+        /* the columns below beg lose their match bits: keep = bits [clamp(beg - j0, 0, 8), 8) */
+        const uint32_t sh = pk_min_vs(pk_subs(rk.BEG2, J0d), 0x00080008u);
+        const uint32_t keep = pk_shlv(sh, 0x00ff00ffu) & 0x00ff00ffu;
+        si.Wc = byte_pair_sel(mA, mB, rk.sel) & keep & rk.tnm8;
+        si.WN = WNs;
+        si.J0d = J0d;
+        si.ENDr = pk_subs(rk.END2, J0d);                                   /* max(end - j0, 0): the bodies' masks are block-relative */
+        si.mi_in = pk_nzmask(pk_subs(rk.END2 + 0x00010001u, J0d));         /* 0xffff where j0 <= end: the mask of column j0 - 1 */
+        uint32_t f = 0;
+        sfor<8>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            constexpr uint32_t BIT = (uint32_t)(1u << c) * 0x00010001u;
+            const uint32_t hd = pk_shl8(T[c]);
+            uint32_t X = pk_mad_vsv(si.Wc & BIT, k.MC[c], hd);
+            if (NQ) X = pk_mad((c ? (WNs >> c) : WNs) & 0x00010001u, rk.D2, X);
+            uint32_t M = pk_subs(X, rk.Bv2);
+            if (VM) M &= pk_nzmask(hd);
+            const uint32_t gsrc = VM ? M : pk_max(M, T[c]);                 /* what a gap opens from, without f (see above) */
+            const uint32_t tI = pk_subs_vs(gsrc, SYM ? k.OED2s : k.OEI2s);
+            f = pk_max(pk_subs_vs(f, SYM ? k.ED2s : k.EI2s), tI);
+        });
+        return f;
+    }
+
+    /* Phase B: the block with the true f entering it (lane2's body, masks relative to `end`); hl = H of the lane's last
+     * column below `end` (0: it has none), f = what leaves the lane */
+    template <bool NQ>
+    L2_MFN void phase_b(uint32_t (&T)[8], const stripe_in &si, const rowk &rk, const consts &k, uint32_t &hl, uint32_t &f, uint32_t &mkb, uint32_t &nz8)
+    {
+        hl = 0;
+        B::template block8<true, NQ>(T, si.Wc, si.WN, rk.Bv2, rk.D2, k, si.ENDr, si.mi_in, hl, f, mkb, nz8);
+    }
+
+    /* Phase C: eh[j0].h = H(i, j0 - 1) from the left neighbour (column j0 takes a store iff j0 <= end), and the column's
+     * non-zero bit with it */
+    L2_MFN void phase_c(uint32_t &T0, uint32_t &nz8, const stripe_in &si, const consts &k, const uint32_t Hin)
+    {
+        T0 = bfi(si.mi_in & 0x00ff00ffu, pk_shr8(Hin), T0);
+        nz8 = (nz8 & 0xfffefffeu) | pk_min_vs(T0 & si.mi_in, k.ONE2);
+    }
+
+    /* the block's row-max key and non-zero bits into the lane's running values (lane2l's fold8 with the column in a VGPR) */
+    L2_MFN void foldv(uint32_t &mk2, uint32_t &Fnz, uint32_t &Lnz, const uint32_t mkb, const uint32_t nz8, const uint32_t J0d, const consts &k)
+    {
+        const uint32_t key = pk_mad(pk_min_vs(nz8, k.ONE2), pk_shl8(J0d), nz8);
+        mk2 = pk_max(mk2, mkb + J0d);
+        Lnz = pk_max(Lnz, key);
+        Fnz = pk_min(Fnz, pk_sub_vs(key, k.ONE2));
+    }
+
+    /* eh[end].h comes from the lane that holds column end - 1: 1 <= end - j0 <= 8 */
+    L2_MFN uint32_t hfin_cand(const stripe_in &si, const uint32_t hl)
+    {
+        return hl & pk_nzmask(si.ENDr) & ~pk_nzmask(pk_subs_vs(si.ENDr, 0x00080008u));
+    }
+    /* ... and with an empty range at column 0 it is K4's value (lane2: h1 keeps its initial value) */
+    L2_MFN uint32_t hfin_of(const rowk &rk, const uint32_t reduced)
+    {
+        return bfi(pk_nzmask(rk.END2), reduced, rk.h1init);
     }
 };
 

@@ -308,7 +308,7 @@ hipError_t launch_lane2(int qb, const bsw_dparams &P, int variant, int side, con
                         uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target, const bsw_fin *finp)
 {
     bsw_fin fin;
-    if (finp) fin = *finp; else { fin.redo = fin.redo_cnt = nullptr; fin.pairs = nullptr; fin.on = 0; }
+    if (finp) fin = *finp; else { fin.redo = fin.redo_cnt = nullptr; fin.pairs = nullptr; fin.on = 0; fin.group = 0; }
     if (n == 0) return tail_flag ? hipMemsetD32Async((hipDeviceptr_t)tail_flag, 1, 1, s) : hipSuccess;
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins, vm = variant == BSW_VARIANT_M;
     const dim3 grid((n + 511u) / 512u), block(256);

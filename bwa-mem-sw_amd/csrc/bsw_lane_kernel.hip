@@ -430,6 +430,9 @@ hipError_t launch_lane2(int qb, const bsw_dparams &P, int variant, int side, con
                         uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target, const bsw_fin *fin);
 hipError_t launch_lane2l(int qb, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks,
                          const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *tail_flag, uint32_t *tail_target, const bsw_fin *fin);
+/* bsw_lane2g_kernel.hip: the same arithmetic with a seed pair spread over a group of eight lanes — mid-sized chunks (bsw_fin.group) */
+hipError_t launch_lane2g(int cols, const bsw_dparams &P, int variant, int side, const uint64_t *seq, const bsw_dtask *tasks, const uint32_t *order,
+                         uint32_t n, bsw_result *out, hipStream_t s, const bsw_fin *fin);
 
 static hipError_t launch_lane_k(int cls, int variant, const bsw_dparams &P, int side, const uint64_t *seq, const bsw_dtask *tasks,
                                 const uint32_t *order, uint32_t n, bsw_result *out, hipStream_t s, uint32_t *&tail_flag, uint32_t *tail_target, const bsw_fin *fin);
@@ -475,6 +478,8 @@ static hipError_t launch_lane_k(int cls, int variant, const bsw_dparams &P, int 
     int ncls;
     const lane_class_t &C = lane_classes(&ncls)[cls];
     const int kern = lane_kernel_of(cls, P, variant);
+    if (kern != 1 && fin && fin->group)                               /* (does not signal its tail: launch_lane raises the flag behind it) */
+        return launch_lane2g(C.qb * 8, P, variant, side, seq, tasks, order, n, out, s, fin);
     if (kern != 1) {
         uint32_t *tf = tail_flag;
         tail_flag = nullptr;                                           /* (these kernels raise the flag themselves) */

@@ -50,7 +50,7 @@ static int ext_batch_on(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEv
     }
     if (wmax > (1 << 20)) return fail(e, BSW_E_INVAL, "band out of range");
     int rc = BSW_OK;
-    const size_t chunk = std::max<size_t>(ctx->cfg.chunk_tasks, 1);
+    const size_t chunk = ctx->cfg.chunk_tasks ? ctx->cfg.chunk_tasks : 131072;
     for (size_t b0 = 0; b0 < pos.size() && !rc; b0 += chunk)
         rc = ext_group(ctx, e, st, s, ev, p, tasks, pos.data() + b0, std::min(chunk, pos.size() - b0), wmax, out);
     /* w <= 0 (never passed by bwa): one launch per distinct value */

@@ -132,7 +132,8 @@ typedef struct bsw_config {
     int32_t streams;        /* staging slots per device = streams = pipeline threads of bsw_submit (1..8, def 4) */
     int32_t pack_threads;   /* extra host threads that gather sequences which are NOT in registered memory
                                into pinned staging, shared by the slots (def 4; registered arenas need none) */
-    size_t  chunk_tasks;    /* tasks per H2D/launch chunk in bsw_submit (def 128Ki: two chunks fill the GPU) */
+    size_t  chunk_tasks;    /* tasks per H2D/launch chunk in bsw_submit; 0 (def) = sized per submit by the seeds' work:
+                               128 Ki seeds of 131-base sides, more of shorter ones (two chunks in flight fill the GPU) */
     /* One context can drive several GPUs, as the reference's batch manager drives its 4 PE arrays
      * round-robin (batch_manager.v:343-348,418; bwa_mem_sw.v:162): chunk k of a bsw_submit goes to
      * devices[k mod n_devices].  n_devices == 0 means the single `device` above.  The same ordinal

@@ -196,3 +196,164 @@ extern "C" int lane2l_model_run(const bsw_params *p, const bsw_task *tasks, int 
     }
     return 0;
 }
+
+// ---- bsw_lane2g_kernel: a seed pair per GROUP of eight lanes (lane2g in bsw_lane2_core.h).  The per-lane phases are the
+// product header's; the exchanges between them (the max-plus scan of the f offers, the H(i, j0 - 1) shift, the group
+// reductions) are restated on arrays.  One wavefront = 8 groups = 16 seeds: slot 16 w + k (low halves) and 16 w + 8 + k.
+template <int NS, bool VM, bool SYM>
+struct group_model {
+    using L = lane2g<NS, VM, SYM>;
+    struct lane_t {
+        typename L::state S;
+        uint32_t mA[NS], mB[NS], WNs[NS];
+    };
+    static uint32_t sat8(int v) { return dup16((v > 255 ? 255 : v) << 8); }
+
+    static void run(const bsw_params *p, const bsw_task *tasks, int side, const uint32_t *order, size_t n, size_t w0,
+                    const int32_t *h0s, bsw_ext *out)
+    {
+        consts k;
+        k.a = p->mat[0]; k.pb = -p->mat[1]; k.pn = -p->mat[24];
+        k.o_del = p->o_del; k.e_del = p->e_del; k.oe_ins = p->o_ins + p->e_ins; k.e_ins = p->e_ins; k.zdrop = p->zdrop;
+        fill_packed_consts(k);
+        int mx = 0;
+        for (int i = 0; i < 25; ++i) mx = mx > p->mat[i] ? mx : p->mat[i];
+        const uint32_t E8 = sat8(8 * k.e_ins), E16 = sat8(16 * k.e_ins), E32 = sat8(32 * k.e_ins);
+        std::vector<lane_t> ln(64);
+        const uint8_t *tq[8][2];
+        bool valid[8][2];
+        uint32_t ti[8][2];
+        bool nqs[NS] = {false};
+        for (int grp = 0; grp < 8; ++grp)
+            for (int x = 0; x < 2; ++x) {
+                const size_t slot = w0 + (size_t)grp + 8 * (size_t)x;
+                valid[grp][x] = slot < n;
+                ti[grp][x] = valid[grp][x] ? order[slot] : order[0];
+                const bsw_task &T = tasks[ti[grp][x]];
+                int qlen = side ? T.rqlen : T.lqlen, tlen = side ? T.rtlen : T.ltlen;
+                const uint8_t *q = side ? T.rquery : T.lquery;
+                tq[grp][x] = side ? T.rtarget : T.ltarget;
+                const int eb = side ? p->pen_clip3 : p->pen_clip5;
+                int wl = side ? T.wlim_r : T.wlim_l;
+                if (wl <= 0) {
+                    int mi = (qlen * mx + eb - p->o_ins + p->e_ins) / p->e_ins, md = (qlen * mx + eb - p->o_del + p->e_del) / p->e_del;
+                    if (mi < 1) mi = 1;
+                    if (md < 1) md = 1;
+                    wl = mi < md ? mi : md;
+                }
+                if (!valid[grp][x]) tlen = 0;
+                for (int g = 0; g < 8; ++g) {
+                    lane_t &a = ln[8 * grp + g];
+                    init_pair(a.S.p, x, qlen, tlen, h0s ? h0s[ti[grp][x]] : T.h0, p->w < wl ? p->w : wl);
+                    for (int s = 0; s < NS; ++s) {
+                        uint32_t m[4] = {0, 0, 0, 0}, nb = 0;
+                        for (int c = 0; c < 8; ++c) {
+                            const int j = 64 * s + 8 * g + c;
+                            // (nibbles past the query read as base 0: the packed words are zero there, words past it are not fetched)
+                            const int code = (valid[grp][x] && j < qlen) ? (q[j] > 4 ? 4 : q[j]) : 0;
+                            if (code >= 4) nb |= 1u << c; else m[code] |= 1u << c;
+                        }
+                        const uint32_t packed = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
+                        if (x == 0) { a.mA[s] = packed; a.WNs[s] = nb; } else { a.mB[s] = packed; a.WNs[s] |= nb << 16; }
+                        if (nb && valid[grp][x]) nqs[s] = true;
+                    }
+                }
+            }
+        for (int l = 0; l < 64; ++l) L::init_row(ln[l].S, k, l & 7);
+        std::vector<rowp> rv(64);
+        for (int i = 0;; ++i) {
+            bool any = false, anybite = false;
+            for (int l = 0; l < 64; ++l) {
+                row_begin2(ln[l].S.p, i, rv[l]);
+                any = any || rv[l].ACT != 0;
+                anybite = anybite || rv[l].BITE != 0;
+            }
+            if (!any) break;
+            if (anybite) for (int l = 0; l < 64; ++l) L::zero_dropped(ln[l].S, rv[l], l & 7);
+            typename L::rowk rk[64];
+            for (int l = 0; l < 64; ++l) {
+                int tb[2];
+                for (int x = 0; x < 2; ++x) {
+                    int b = half_of(rv[l].ACT, x) ? tq[l >> 3][x][i] : 0;
+                    tb[x] = b > 4 ? 4 : b;
+                }
+                rk[l] = L::row_consts(ln[l].S.p, k, i, tb);
+            }
+            uint32_t Hc[64], Fc[64], mk2[64], Fnz[64], Lnz[64], hfin[64];
+            for (int l = 0; l < 64; ++l) { Hc[l] = rk[l].h1init; Fc[l] = 0; mk2[l] = 0; Fnz[l] = 0xffffffffu; Lnz[l] = 0; hfin[l] = 0; }
+            for (int s = 0; s < NS; ++s) {
+                bool need = false;
+                for (int l = 0; l < 64; ++l) need = need || L::needs_stripe(rk[l], rv[l].ACT, s) != 0;
+                if (!need) continue;
+                typename L::stripe_in si[64];
+                uint32_t D[64], x[64], Fin[64], hl[64], fo[64], mkb[64], nz8[64];
+                for (int l = 0; l < 64; ++l) {
+                    const uint32_t J0d = dup16((int)L::j0_of(s, l & 7));
+                    D[l] = nqs[s] ? L::template phase_a<true>(ln[l].S.T[s], rk[l], k, ln[l].mA[s], ln[l].mB[s], ln[l].WNs[s], J0d, si[l])
+                                  : L::template phase_a<false>(ln[l].S.T[s], rk[l], k, ln[l].mA[s], ln[l].mB[s], ln[l].WNs[s], J0d, si[l]);
+                }
+                // the carry of the stripe before enters lane 0's offer; inclusive max-plus scan, decay 8 e_ins per lane
+                for (int l = 0; l < 64; ++l) x[l] = (l & 7) == 0 ? pk_max(D[l], pk_subs_vs(Fc[l], E8)) : D[l];
+                const uint32_t dec[3] = {E8, E16, E32};
+                for (int st = 0; st < 3; ++st) {
+                    uint32_t y[64];
+                    const int d = 1 << st;
+                    for (int l = 0; l < 64; ++l) y[l] = (l & 7) >= d ? x[l - d] : 0u;
+                    for (int l = 0; l < 64; ++l) x[l] = pk_max(x[l], pk_subs_vs(y[l], dec[st]));
+                }
+                for (int l = 0; l < 64; ++l) Fin[l] = (l & 7) == 0 ? Fc[l] : x[l - 1];
+                for (int l = 0; l < 64; ++l) {
+                    fo[l] = Fin[l];
+                    if (nqs[s]) L::template phase_b<true>(ln[l].S.T[s], si[l], rk[l], k, hl[l], fo[l], mkb[l], nz8[l]);
+                    else L::template phase_b<false>(ln[l].S.T[s], si[l], rk[l], k, hl[l], fo[l], mkb[l], nz8[l]);
+                }
+                for (int l = 0; l < 64; ++l) {
+                    const uint32_t Hin = (l & 7) == 0 ? Hc[l] : hl[l - 1];
+                    L::phase_c(ln[l].S.T[s][0], nz8[l], si[l], k, Hin);
+                    L::foldv(mk2[l], Fnz[l], Lnz[l], mkb[l], nz8[l], si[l].J0d, k);
+                    hfin[l] = pk_max(hfin[l], L::hfin_cand(si[l], hl[l]));
+                }
+                for (int l = 0; l < 64; l += 8) { Hc[l] = hl[l + 7]; Fc[l] = fo[l + 7]; }      // (only lane 0 of a group reads them)
+            }
+            for (int grp = 0; grp < 8; ++grp) {
+                uint32_t m = 0, L2v = 0, F = 0xffffffffu, h = 0;
+                for (int g = 0; g < 8; ++g) {
+                    const int l = 8 * grp + g;
+                    m = pk_max(m, mk2[l]); L2v = pk_max(L2v, Lnz[l]); F = pk_min(F, Fnz[l]); h = pk_max(h, hfin[l]);
+                }
+                for (int g = 0; g < 8; ++g) {
+                    const int l = 8 * grp + g;
+                    row_tail2<SYM>(ln[l].S.p, k, i, rv[l].ACT, L::hfin_of(rk[l], h), m, F, L2v);
+                }
+            }
+        }
+        for (int grp = 0; grp < 8; ++grp)
+            for (int x = 0; x < 2; ++x) {
+                if (!valid[grp][x]) continue;
+                const ext_out s = pair_result(ln[8 * grp].S.p, x);
+                bsw_ext &e = out[ti[grp][x]];
+                e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
+                e.gscore = s.gscore; e.max_off = s.max_off; e.aw = p->w; e.cells = s.cells;
+            }
+    }
+};
+
+// ns = stripes of 64 columns (3: the 8-bit classes up to 136 columns, 4: the 232-column class)
+extern "C" int lane2g_model_run(const bsw_params *p, const bsw_task *tasks, int side, const uint32_t *order, size_t n,
+                                const int32_t *h0s, bsw_ext *out, int ns)
+{
+    if (!p || !tasks || !order || !out) return -1;
+    if (p->mat[1] > 0 || p->mat[24] > 0 || -p->mat[1] < -p->mat[24]) return -2;
+    if (p->o_del + p->e_del > 255 || p->o_ins + p->e_ins > 255 || p->mat[0] - p->mat[1] > 255) return -2;
+    const bool sym = p->o_del == p->o_ins && p->e_del == p->e_ins, vm = p->variant == BSW_VARIANT_M;
+    for (size_t w0 = 0; w0 < n; w0 += 16) {
+#define RUNG(NS) do { \
+        if (!vm && sym) group_model<NS, false, true>::run(p, tasks, side, order, n, w0, h0s, out); \
+        else if (!vm) group_model<NS, false, false>::run(p, tasks, side, order, n, w0, h0s, out); \
+        else if (sym) group_model<NS, true, true>::run(p, tasks, side, order, n, w0, h0s, out); \
+        else group_model<NS, true, false>::run(p, tasks, side, order, n, w0, h0s, out); } while (0)
+        if (ns == 3) RUNG(3); else if (ns == 4) RUNG(4); else return -3;
+#undef RUNG
+    }
+    return 0;
+}

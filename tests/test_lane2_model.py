@@ -26,6 +26,8 @@ def model_lib(tmp_path_factory):
     L.lane2_model_run_qb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     L.lane2l_model_run.restype = C.c_int
     L.lane2l_model_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    L.lane2g_model_run.restype = C.c_int
+    L.lane2g_model_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     return L
 
 
@@ -35,17 +37,19 @@ class Model:
     run-time loop, row behind an accessor) for the 136- and the 232-column class"""
     def __init__(self, lib, kind):
         self.lib, self.kind = lib, kind
-        self.qcap = {"loop29": 231, "unrolled9": 71}.get(kind, 135)
+        self.qcap = {"loop29": 231, "unrolled9": 71, "group4": 231}.get(kind, 135)
 
     def lane2_model_run(self, *a):
         if self.kind == "unrolled":
             return self.lib.lane2_model_run(*a)
         if self.kind == "unrolled9":
             return self.lib.lane2_model_run_qb(*a, 9)
+        if self.kind in ("group3", "group4"):        # bsw_lane2g_kernel: a seed pair per group of eight lanes, 3 / 4 stripes of 64 columns
+            return self.lib.lane2g_model_run(*a, 3 if self.kind == "group3" else 4)
         return self.lib.lane2l_model_run(*a, 29 if self.kind == "loop29" else 17)
 
 
-@pytest.fixture(scope="module", params=["unrolled", "unrolled9", "loop17", "loop29"])
+@pytest.fixture(scope="module", params=["unrolled", "unrolled9", "loop17", "loop29", "group3", "group4"])
 def model(model_lib, request):
     return Model(model_lib, request.param)
 
