@@ -75,23 +75,24 @@ BSW_LOCAL void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_
     bp.lane_cols[0] = 0;
 }
 
+/* work8_l / work8_r: the summed query lengths of the chunk's 8-bit left / right lane sides */
 BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint32_t &n_lane, uint32_t n16, uint32_t *cl, uint32_t *cr,
-                                uint32_t *cw, const uint32_t *cw16, uint8_t *dep)
+                                uint32_t *cw, const uint32_t *cw16, uint8_t *dep, uint64_t work8_l, uint64_t work8_r)
 {
-    /* BSW_GROUP=0: never the group kernel; 1: the group kernel for every chunk with lane seeds (tests, measurements);
-     * BSW_GROUP_MIN=n: the threshold */
+    /* BSW_GROUP=0: never the group kernel (the lane kernels then start at round 5's seed count); 1: the group kernel for every
+     * chunk with 8-bit lane seeds (tests, measurements) */
     static const int genv = getenv("BSW_GROUP") ? atoi(getenv("BSW_GROUP")) : -1;
-    static const uint32_t gmin = getenv("BSW_GROUP_MIN") ? (uint32_t)atoi(getenv("BSW_GROUP_MIN")) : (uint32_t)GROUP_AUTO_MIN;
     if (!bp.lane_on) return false;
-    uint32_t l8 = 0, r8 = 0;
-    for (int c = 0; c < bp.n_lane; ++c)
-        if (bp.lane_bits[c] == 8) { l8 += cl[c]; r8 += cr[c]; }
-    const uint32_t sides8 = (l8 ? 1u : 0u) + (r8 ? 1u : 0u), n8 = n_lane - n16;
+    const uint32_t n8 = n_lane - n16;
+    const uint64_t work = std::max(work8_l, work8_r);
     bool group = false;
     if (genv == 1) group = group_ok && n8 > 0 && kern != BSW_KERNEL_WAVE;
-    else if (kern == BSW_KERNEL_AUTO && !lane_bins_pay(n_lane, cl, cr)) {
-        group = genv != 0 && group_ok && n8 >= gmin * (sides8 ? sides8 : 1u);
-        if (!group) { bp.lane_on = 0; return false; }
+    else if (kern == BSW_KERNEL_AUTO) {
+        const bool lane = genv == 0 || !group_ok ? lane_bins_pay(n_lane, cl, cr) : (work >= LANE_WORK_MIN || lane_bins_pay(n16, cl, cr));
+        if (!lane) {
+            group = genv != 0 && group_ok && work >= GROUP_WORK_MIN;
+            if (!group) { bp.lane_on = 0; return false; }
+        }
     }
     if (!group) return false;
     /* the group kernel serves the 8-bit classes; the chunk's 16-bit seeds (scores beyond 255) go to the general kernel */
@@ -123,6 +124,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0, n16 = 0;
     uint8_t dep[BSW_MAX_LANE_CLASSES] = {0};
     uint64_t lane_work[BSW_MAX_LANE_CLASSES] = {0};          /* sum of query lengths per lane class (narrow_fold) */
+    uint64_t work8_l = 0, work8_r = 0;                       /* ... of the 8-bit left / right sides (decide_lane_mode) */
     int h0_lo = INT_MAX, h0_hi = 0;                          /* h0 range of the left sides that go to lane classes (bsw_h0_bucket) */
     auto span = [&](const uint8_t *s, int len) {
         if (len > 0) { if (s < lo) lo = s; if (s + len > hi) hi = s + len; }
@@ -239,6 +241,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
                 if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i + idx0);
                 ++cl[c];
                 lane_work[c] += (uint64_t)t.lqlen;
+                if (bits == 8) work8_l += (uint64_t)t.lqlen;
                 h0_lo = std::min(h0_lo, t.h0); h0_hi = std::max(h0_hi, t.h0);
             }
             if (t.rqlen) {
@@ -246,6 +249,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
                 if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i + idx0);
                 ++cr[c];
                 lane_work[c] += (uint64_t)t.rqlen;
+                if (bits == 8) work8_r += (uint64_t)t.rqlen;
                 if (lc >= 0) dep[lc] |= (uint8_t)(1u << c);
             }
         }
@@ -257,7 +261,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         bsw_dparams dpx;
         errs quiet;
         const bool group_ok = check_params(quiet, p, &dpx) == BSW_OK && bsw::lane_class_finishes(0, dpx, p->variant);
-        group = decide_lane_mode(kern, group_ok, bp, n_lane, n16, cl, cr, cw, cw16, dep);
+        group = decide_lane_mode(kern, group_ok, bp, n_lane, n16, cl, cr, cw, cw16, dep, work8_l, work8_r);
     }
     if (bp.lane_on && narrow_foldable(bp)) {
         uint64_t all8 = 0;

@@ -55,10 +55,15 @@ inline bool lane_bins_pay(uint32_t n_lane, const uint32_t *cl, const uint32_t *c
     const uint32_t sides = (l ? 1u : 0u) + (r ? 1u : 0u);
     return n_lane >= (uint32_t)LANE_AUTO_MIN * (sides ? sides : 1u);
 }
-/* Below that, a chunk with at least GROUP_AUTO_MIN 8-bit lane seeds per launched side runs its lane launches on
- * bsw_lane2g_kernel (a seed pair per group of eight lanes: 16 seeds per wavefront, a tenth of the lane kernels' wave
- * lifetime); smaller ones still take the general kernels (one wavefront per seed: every seed starts at once). */
-#define GROUP_AUTO_MIN 3000
+/* Between the two sits bsw_lane2g_kernel (a seed pair per group of eight lanes, 16 seeds per wavefront): its launch lasts
+ * ~0.55 ms per side where a lane launch lasts 1.0 and the general kernels need a wavefront per seed.  Measured, device-resident
+ * (profiles/r6/crossover_group.json; ms per batch, general / group / lane):
+ *     PE mixed bins   32 k seeds 1.28 / 1.09 / 1.97    49 k 1.83 / 1.28 / 1.97    65 k 2.39 / 1.44 / 1.96    131 k 4.59 / 2.13 / 1.95
+ *     150 bp one bin  13 k seeds 0.66 / 0.57 / 0.98    24 k 0.93 / 0.89 / 0.98    32 k 1.36 / 0.90 / 0.99     49 k 1.77 / 1.25 / 0.99
+ * Both workloads cross at the same WORK per launched side — the sum of the side's query lengths: the group kernel from ~1.5 M
+ * bases (28 k PE sides of ~55 bases, 11 k sides of 131), the lane kernels from ~5 M (100 k PE seeds, 38 k one-bin seeds). */
+#define GROUP_WORK_MIN 1500000ull
+#define LANE_WORK_MIN  5000000ull
 #define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
 #define RAW_FRONT 32                 /* ... and in front of the first one (reversed left queries) */
 
@@ -321,7 +326,7 @@ BSW_LOCAL size_t order_capacity(size_t n);
  * returns true — the 16-bit seeds then leave the lane lists for the general kernel: cw16 = their count per wave class, n16
  * their number) or no lane launches at all (bp.lane_on = 0).  group_ok: the scoring parameters allow the packed kernels. */
 BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint32_t &n_lane, uint32_t n16, uint32_t *cl, uint32_t *cr,
-                                uint32_t *cw, const uint32_t *cw16, uint8_t *dep);
+                                uint32_t *cw, const uint32_t *cw16, uint8_t *dep, uint64_t work8_l, uint64_t work8_r);
 BSW_LOCAL int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams &bp);
 BSW_LOCAL bool narrow_foldable(const bsw_binparams &bp);
 BSW_LOCAL void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_t *dep);

@@ -36,32 +36,58 @@ namespace bsw {
 
 namespace {
 
-template <int CTRL, int BANK = 0xf>
-__device__ __forceinline__ uint32_t gdpp(uint32_t old, uint32_t src)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, BANK, false);
-}
-/* the value of the lane N places to the left IN THE SAME GROUP of eight, 0 where there is none */
+/* DPP moves as asm statements WITH their wait states: the operands come out of inline-asm primitives (v_pk_*), which the
+ * compiler's hazard recogniser does not count as VALU writes — a DPP read of a VGPR needs two wait states behind the VALU
+ * write of it, and none would be inserted.  bound_ctrl:0 = lanes without a source read 0. */
+#define BSW_G_DPP(name, ctl)                                                                                              \
+    __device__ __forceinline__ uint32_t name(uint32_t x)                                                                  \
+    {                                                                                                                     \
+        uint32_t d;                                                                                                       \
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(d) : "v"(x)); \
+        return d;                                                                                                         \
+    }
+#ifdef BSW_L2G_SHFL      /* (debugging: the same moves through ds_bpermute) */
+#undef BSW_G_DPP
+#define BSW_G_DPP(name, ctl)
+__device__ __forceinline__ uint32_t shfl_from(uint32_t x, int src, bool ok) { const uint32_t y = (uint32_t)__shfl((int)x, src, 64); return ok ? y : 0u; }
+__device__ __forceinline__ uint32_t dpp_shr1(uint32_t x) { const int l = threadIdx.x & 63; return shfl_from(x, l - 1, (l & 15) >= 1); }
+__device__ __forceinline__ uint32_t dpp_shr2(uint32_t x) { const int l = threadIdx.x & 63; return shfl_from(x, l - 2, (l & 15) >= 2); }
+__device__ __forceinline__ uint32_t dpp_shr4(uint32_t x) { const int l = threadIdx.x & 63; return shfl_from(x, l - 4, (l & 15) >= 4); }
+__device__ __forceinline__ uint32_t dpp_shl7(uint32_t x) { const int l = threadIdx.x & 63; return shfl_from(x, l + 7, (l & 15) + 7 <= 15); }
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t x) { const int l = threadIdx.x & 63; return shfl_from(x, l ^ 1, true); }
+__device__ __forceinline__ uint32_t dpp_xor2(uint32_t x) { const int l = threadIdx.x & 63; return shfl_from(x, l ^ 2, true); }
+__device__ __forceinline__ uint32_t dpp_hmir(uint32_t x) { const int l = threadIdx.x & 63; return shfl_from(x, (l & ~7) | (7 - (l & 7)), true); }
+#endif
+BSW_G_DPP(dpp_shr1, "row_shr:1")
+BSW_G_DPP(dpp_shr2, "row_shr:2")
+BSW_G_DPP(dpp_shr4, "row_shr:4")
+BSW_G_DPP(dpp_shl7, "row_shl:7")
+BSW_G_DPP(dpp_xor1, "quad_perm:[1,0,3,2]")
+BSW_G_DPP(dpp_xor2, "quad_perm:[2,3,0,1]")
+BSW_G_DPP(dpp_hmir, "row_half_mirror")
+#undef BSW_G_DPP
+/* the value of the lane N places to the left IN THE SAME GROUP of eight, 0 where there is none (lanes 8 .. 8+N-1 of the
+ * 16-lane DPP row would read the other group: masked) */
 template <int N>
 __device__ __forceinline__ uint32_t gshr(uint32_t x, int g)
 {
-    const uint32_t y = gdpp<0x110 + N>(0u, x);          /* row_shr:N inside the 16-lane DPP row; lanes without a source keep 0 */
-    return g >= N ? y : 0u;                             /* lanes 8 .. 8+N-1 of the row read the other group: masked */
+    const uint32_t y = N == 1 ? dpp_shr1(x) : N == 2 ? dpp_shr2(x) : dpp_shr4(x);
+    return g >= N ? y : 0u;
 }
 /* lane 7 of the group, delivered to its lane 0 (row_shl:7; the other lanes get something nobody reads) */
-__device__ __forceinline__ uint32_t gfrom7(uint32_t x) { return gdpp<0x107>(0u, x); }
+__device__ __forceinline__ uint32_t gfrom7(uint32_t x) { return dpp_shl7(x); }
 /* butterflies inside the group: lane ^ 1, lane ^ 2, 7 - lane */
 __device__ __forceinline__ uint32_t gmax(uint32_t x)
 {
-    x = l2::pk_max(x, gdpp<0xB1>(0u, x));
-    x = l2::pk_max(x, gdpp<0x4E>(0u, x));
-    return l2::pk_max(x, gdpp<0x141>(0u, x));
+    x = l2::pk_max(x, dpp_xor1(x));
+    x = l2::pk_max(x, dpp_xor2(x));
+    return l2::pk_max(x, dpp_hmir(x));
 }
 __device__ __forceinline__ uint32_t gmin(uint32_t x)
 {
-    x = l2::pk_min(x, gdpp<0xB1>(0u, x));
-    x = l2::pk_min(x, gdpp<0x4E>(0u, x));
-    return l2::pk_min(x, gdpp<0x141>(0u, x));
+    x = l2::pk_min(x, dpp_xor1(x));
+    x = l2::pk_min(x, dpp_xor2(x));
+    return l2::pk_min(x, dpp_hmir(x));
 }
 
 /* bit b of each of the 8 nibbles of w gathered into 8 contiguous bits */
@@ -171,17 +197,27 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams 
             x = l2::pk_max(x, l2::pk_subs_vs(gshr<1>(x, g), E8));
             x = l2::pk_max(x, l2::pk_subs_vs(gshr<2>(x, g), E16));
             x = l2::pk_max(x, l2::pk_subs_vs(gshr<4>(x, g), E32));
-            uint32_t f = g == 0 ? Fc : gshr<1>(x, g);             /* what enters this lane's block */
+            /* (every cross-lane move is a statement of its own, in front of the select that uses it: inside a `g == 0 ? a : move`
+             * the compiler runs the move under the lanes' own EXEC mask, and a DPP read of a DISABLED lane returns 0 — lane 1
+             * of every group then saw nothing of lane 0) */
+            const uint32_t xs = gshr<1>(x, g);
+            uint32_t f = g == 0 ? Fc : xs;                        /* what enters this lane's block */
             uint32_t hl, mkb, nz8;
             if (__builtin_expect(nq, 0)) L::template phase_b<true>(S.T[s], si, rk, k, hl, f, mkb, nz8);
             else L::template phase_b<false>(S.T[s], si, rk, k, hl, f, mkb, nz8);
-            const uint32_t Hin = g == 0 ? Hc : gshr<1>(hl, g);
+            const uint32_t hs = gshr<1>(hl, g);
+            const uint32_t Hin = g == 0 ? Hc : hs;
             L::phase_c(S.T[s][0], nz8, si, k, Hin);
             L::foldv(mk2, Fnz, Lnz, mkb, nz8, J0d, k);
             hfin = l2::pk_max(hfin, L::hfin_cand(si, hl));
             Hc = gfrom7(hl);
             Fc = gfrom7(f);
         });
+#ifdef BSW_L2G_DEBUG
+        if (blockIdx.x == 0 && wv == 0 && grp == 0 && (i < 3 || (i >= 70 && i < 75)))
+            printf("i=%d g=%d BEG=%08x END=%08x mk2=%08x Lnz=%08x Fnz=%08x hfin=%08x T00=%08x T01=%08x T10=%08x T11=%08x tb=%d,%d mA=%08x,%08x\n", i, g, rk.BEG2, rk.END2, mk2, Lnz, Fnz, hfin,
+                   S.T[0][0], S.T[0][1], S.T[1][0], S.T[1][1], tb[0], tb[1], mA[0], mA[1]);
+#endif
         mk2 = gmax(mk2); Lnz = gmax(Lnz); Fnz = gmin(Fnz); hfin = gmax(hfin);
         l2::row_tail2<SYM>(S.p, k, i, r.ACT, L::hfin_of(rk, hfin), mk2, Fnz, Lnz);      /* K7, K8 for both seeds at once */
     }

@@ -80,7 +80,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     bsw_binparams &bp = ci.bp;
     uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cw16[BSW_MAX_WAVE_CLASSES] = {0};
     uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0, n16 = 0;
-    uint64_t acc = 0;
+    uint64_t acc = 0, w8l = 0, w8r = 0;
     int h0_lo = INT_MAX, h0_hi = 0;                /* h0 range of the left sides that go to lane classes (bsw_h0_bucket) */
     /* pass 1: where every batch's tasks and sequence words start (the batches' word counts side by side, then a prefix sum) */
     std::vector<uint64_t> wbase(nb + 1, 0), tbase(nb + 1, 0);
@@ -111,7 +111,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     }
     const double t_b = dbg ? tnow() : 0;
     /* pass 2 (parallel over batches): records, class counts, and the batch itself into pinned staging */
-    struct part { uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cw16[BSW_MAX_WAVE_CLASSES] = {0}, cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0, n16 = 0; int h0_lo = INT_MAX, h0_hi = 0; int rc = 0; errs e; };
+    struct part { uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cw16[BSW_MAX_WAVE_CLASSES] = {0}, cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0, n16 = 0; uint64_t w8l = 0, w8r = 0; int h0_lo = INT_MAX, h0_hi = 0; int rc = 0; errs e; };
     std::vector<part> parts(nth);
     /* class of a side / a seed by query length, looked up instead of searched per task (wire lengths are 8-bit fields) */
     uint8_t wcls[256], lcls8[256], lcls16[256];
@@ -168,6 +168,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
                     if (bits == 16) { ++pt.n16; ++pt.cw16[wc]; }
                     if (lq) { ++pt.cl[lc[lq]]; pt.h0_lo = std::min(pt.h0_lo, h0); pt.h0_hi = std::max(pt.h0_hi, h0); }
                     if (rq) ++pt.cr[lc[rq]];
+                    if (bits == 8) { pt.w8l += (uint64_t)lq; pt.w8r += (uint64_t)rq; }
                 }
                 st.h_tasks.p[ti] = d;
                 st.h_woff.p[ti] = wo;
@@ -188,10 +189,10 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
         if (pt.rc) { e = pt.e; return pt.rc; }
         for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) { cw_all[c] += pt.cw_all[c]; cw[c] += pt.cw[c]; cw16[c] += pt.cw16[c]; }
         for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { cl[c] += pt.cl[c]; cr[c] += pt.cr[c]; }
-        n_lane += pt.n_lane; n16 += pt.n16;
+        n_lane += pt.n_lane; n16 += pt.n16; w8l += pt.w8l; w8r += pt.w8r;
         h0_lo = std::min(h0_lo, pt.h0_lo); h0_hi = std::max(h0_hi, pt.h0_hi);
     }
-    const bool group = decide_lane_mode(ctx->cfg.kernel, bsw::lane_class_finishes(0, dp, variant), bp, n_lane, n16, cl, cr, cw, cw16, nullptr);
+    const bool group = decide_lane_mode(ctx->cfg.kernel, bsw::lane_class_finishes(0, dp, variant), bp, n_lane, n16, cl, cr, cw, cw16, nullptr, w8l, w8r);
     if (bp.lane_on && narrow_foldable(bp)) narrow_fold(bp, cl, cr, nullptr);     /* (wire-format groups: one launch per side) */
     if (!bp.lane_on) { memcpy(cw, cw_all, sizeof(cw)); memset(cl, 0, sizeof(cl)); memset(cr, 0, sizeof(cr)); n_lane = 0; }
     if (bp.lane_on && h0_hi >= h0_lo) bsw_set_h0_buckets(&bp, h0_lo, h0_hi);

@@ -56,7 +56,8 @@ assert EXT_TASK.itemsize == 40 and SYNTH.itemsize == 72 and CONFIG.itemsize == 1
 
 REFBATCH_IN_WORDS, REFBATCH_OUT_WORDS, REFBATCH_MAX_TASKS = 65536, 4096, 819
 KERNEL_AUTO, KERNEL_WAVE, KERNEL_LANE = 0, 1, 2
-LANE_AUTO_MIN = 26000          # BSW_KERNEL_AUTO uses lane bins only from this many eligible seeds PER LAUNCHED SIDE (bsw_internal.h)
+LANE_AUTO_MIN = 40000          # seeds of the 150 bp single bin (131-base sides) from which BSW_KERNEL_AUTO uses the lane bins: LANE_WORK_MIN = 5 M query bases per launched side (bsw_internal.h)
+LANE_WORK_MIN, GROUP_WORK_MIN = 5_000_000, 1_500_000   # per launched side: lane kernels / the group kernel (bsw_lane2g_kernel) from this many query bases
 VARIANT_H, VARIANT_M = 0, 1
 
 ERRORS = {0: "BSW_OK", -1: "BSW_E_NODEVICE", -2: "BSW_E_INVAL", -3: "BSW_E_LIMIT", -4: "BSW_E_HIP",

@@ -24,10 +24,10 @@ hipError_t launch_lane(int, int, const bsw_dparams &, int, const uint64_t *, con
 bool lane_class_finishes(int, const bsw_dparams &, int) { return true; }
 hipError_t launch_finalize(const bsw_dparams &, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, uint32_t *, uint32_t *, bsw_pair *, hipStream_t) { return hipSuccess; }
 hipError_t launch_pairs_from_results(const uint32_t *, uint32_t, const uint32_t *, const bsw_result *, bsw_pair *, hipStream_t) { return hipSuccess; }
-hipError_t launch_pack(const uint8_t *, const bsw_dtask *, const bsw_rawoff *, uint32_t, uint32_t, int, const uint8_t *, int64_t, const bsw_refx *, uint64_t *, hipStream_t) { return hipSuccess; }
+hipError_t launch_pack(const uint8_t *, const bsw_dtask *, const bsw_rawoff *, uint32_t, uint32_t, int, const uint8_t *, int64_t, const bsw_refx *, uint64_t *, uint8_t *, hipStream_t) { return hipSuccess; }
 hipError_t launch_wire_pack(const uint32_t *, const bsw_dtask *, const bsw_wireoff *, uint32_t, uint64_t *, hipStream_t) { return hipSuccess; }
 hipError_t launch_wire_results(const bsw_result *, const bsw_wireoff *, uint32_t, uint32_t *, size_t, hipStream_t) { return hipSuccess; }
-hipError_t launch_bin(const bsw_binparams &, const uint64_t *, const bsw_dtask *, uint32_t, uint32_t *, uint32_t *, hipStream_t) { return hipSuccess; }
+hipError_t launch_bin(const bsw_binparams &, const uint64_t *, const uint8_t *, const bsw_dtask *, uint32_t, uint32_t *, uint64_t *, uint32_t *, hipStream_t) { return hipSuccess; }
 int align_class_count() { return 6; }
 int align_class_of(int qlen, int byte_mode) { return qlen <= 128 ? (byte_mode ? 0 : 3) : (qlen <= 160 ? (byte_mode ? 1 : 4) : (qlen <= 256 ? (byte_mode ? 2 : 5) : -1)); }
 hipError_t launch_align(int, const bsw_dparams &, const uint64_t *, const bsw_adtask *, const uint32_t *, uint32_t, unsigned long long *, bsw_kswr *, hipStream_t) { return hipSuccess; }
