@@ -1551,7 +1551,12 @@ static int submit_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *task
                 acc += l * l + r * r;
             }
             const double mean = cnt ? acc / (double)cnt : 0.0;
-            if (mean > 1.0) chunk = (size_t)std::min(524288.0, std::max(65536.0, 131072.0 * (131.0 * 131.0) / mean));
+            /* ... and a big submit takes chunks of twice that: a launch that fills the machine twice over loses less to its
+             * longest waves (2 M resident PE seeds as chunks on two streams, no PCIe: 128 / 256 / 512 Ki -> 85 / 160 / 219 M
+             * seeds/s against 240 as one batch, profiles/r6/resident_chunks_pe.txt), as long as ~16 chunks are left to pipeline */
+            double base = 131072.0;
+            if (mean > 1.0) base = std::min(524288.0, std::max(65536.0, 131072.0 * (131.0 * 131.0) / mean));
+            chunk = (size_t)std::min(2.0 * base, std::max(base, (double)n / 16.0));
             chunk = (chunk + 8191) & ~(size_t)8191;
         }
     }
