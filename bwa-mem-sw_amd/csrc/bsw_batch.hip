@@ -16,6 +16,13 @@ static bool lane_matrix_ok(const bsw_params *p)
     return true;
 }
 
+static inline uint64_t thread_cpu_ns()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
 BSW_LOCAL size_t order_capacity(size_t n) { return 4 * n + 16; }   /* upper bound of plan.order_len + the 2 + BSW_MAX_WAVE_CLASSES counters behind it */
 
 /* ---- host pass over a chunk: validate, lay out, count per class ------------------------------ */
@@ -109,70 +116,129 @@ BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint
  * hands out seed i as a bsw_task (a pointer into the caller's array, or `tmp` filled on the fly — bsw_submit_ref never
  * materialises its tasks); NULL = error rc.  rawoff gets the low 32 bits of every host pointer: when the chunk goes
  * out by direct DMA the pack kernel subtracts raw_bias, otherwise gather_offsets() replaces them. */
+/* what one range of a chunk's seeds adds up to (the ranges of a chunk are walked side by side, then merged) */
+struct range_acc {
+    uint64_t words = 0, bytes = 0;                           /* sequence words / raw bytes the range needs */
+    const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
+    uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cw16[BSW_MAX_WAVE_CLASSES] = {0};
+    uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0, n16 = 0;
+    uint8_t dep[BSW_MAX_LANE_CLASSES] = {0};
+    uint64_t lane_work[BSW_MAX_LANE_CLASSES] = {0}, work8_l = 0, work8_r = 0;
+    int h0_lo = INT_MAX, h0_hi = 0;
+    /* packed input, first pass: the span of the words the range references and their number */
+    const uint8_t *pl0 = (const uint8_t *)UINTPTR_MAX, *ph0 = nullptr;
+    uint64_t psum = 0;
+    int rc = 0;
+    errs e;
+};
+
 template <class Src>
 static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, size_t n, bool dev_targets,
-                           bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left, bool packed = false, size_t idx0 = 0 /* index of the chunk's first seed in the caller's array: error texts name the caller's index */)
+                           bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left, bool packed = false, size_t idx0 = 0 /* index of the chunk's first seed in the caller's array: error texts name the caller's index */,
+                           int threads = 1 /* ranges walked side by side (helper threads started here; their CPU time -> *helper_ns) */, std::atomic<uint64_t> *helper_ns = nullptr)
 {
     ci.packed = packed;
     const int mx = mat_max(p->mat);
     int rc = fill_binparams(e, p, kern, ci.bp);
     if (rc) return rc;
     bsw_binparams &bp = ci.bp;
-    uint64_t acc = 0, accb = 0;
-    const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
-    uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cw16[BSW_MAX_WAVE_CLASSES] = {0};
-    uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0, n16 = 0;
-    uint8_t dep[BSW_MAX_LANE_CLASSES] = {0};
-    uint64_t lane_work[BSW_MAX_LANE_CLASSES] = {0};          /* sum of query lengths per lane class (narrow_fold) */
-    uint64_t work8_l = 0, work8_r = 0;                       /* ... of the 8-bit left / right sides (decide_lane_mode) */
-    int h0_lo = INT_MAX, h0_hi = 0;                          /* h0 range of the left sides that go to lane classes (bsw_h0_bucket) */
-    auto span = [&](const uint8_t *s, int len) {
-        if (len > 0) { if (s < lo) lo = s; if (s + len > hi) hi = s + len; }
+    /* H5/H6 per query length, for every length up front (two integer divisions each: per seed they were most of this pass) */
+    std::vector<uint16_t> gl5((size_t)BSW_MAX_QLEN + 1), gl3((size_t)BSW_MAX_QLEN + 1);
+    /* class of a seed / a side by query length, looked up instead of searched per seed (the searches' data-dependent branches
+     * were a fifth of this pass) */
+    std::vector<int8_t> wcls((size_t)BSW_MAX_QLEN + 1), lcls8((size_t)BSW_MAX_QLEN + 1), lcls16((size_t)BSW_MAX_QLEN + 1);
+    for (int q = 0; q <= BSW_MAX_QLEN; ++q) {
+        gl5[(size_t)q] = (uint16_t)gap_limit(p, mx, q, p->pen_clip5);
+        gl3[(size_t)q] = (uint16_t)gap_limit(p, mx, q, p->pen_clip3);
+        wcls[(size_t)q] = (int8_t)bsw_wave_class_of(&bp, q);
+        lcls8[(size_t)q] = (int8_t)bsw_side_lane_class(&bp, 8, q);
+        lcls16[(size_t)q] = (int8_t)bsw_side_lane_class(&bp, 16, q);
+    }
+    /* THE PASS IS WALKED BY `threads` THREADS SIDE BY SIDE (round 6).  At 22 - 40 ns per seed it was what bounded every
+     * PCIe-inclusive leg of bench.py: four slot threads = 100 - 140 M seeds/s of host-pass capacity against 240 M the GPU
+     * takes (profiles/r6/e2e_host_pass.txt).  The seeds are cut into ranges; a first, cheap walk sizes every range (words,
+     * bytes; packed input: the span of its words), a prefix sum gives every range its base, the second walk writes the records. */
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), n / 32768 + 1));
+    std::vector<range_acc> ra((size_t)T);
+    const size_t per = (n + (size_t)T - 1) / (size_t)T;
+    auto run_ranges = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        for (int k = 1; k < T; ++k)
+            th.emplace_back([&, k]() { const uint64_t c0 = thread_cpu_ns(); fn(k); if (helper_ns) *helper_ns += thread_cpu_ns() - c0; });
+        fn(0);
+        for (auto &t : th) t.join();
     };
-    bsw_task tmp;
-    /* H5/H6 per query length, computed once per length and chunk (two integer divisions each: with them per seed they were
-     * most of this pass) */
-    std::vector<uint16_t> gl5((size_t)BSW_MAX_QLEN + 1, 0), gl3((size_t)BSW_MAX_QLEN + 1, 0);
-    const auto glim = [&](std::vector<uint16_t> &tab, int qlen, int clip) -> uint16_t {
-        uint16_t &v = tab[(size_t)qlen];
-        if (!v) v = (uint16_t)gap_limit(p, mx, qlen, clip);       /* >= 1: zero means not computed yet */
-        return v;
-    };
-    /* packed input: whether the words can be DMA'd as they lie (registered, compact arena) decides the word offsets, and
-     * the staging records are write-combined memory that must not be read back — so the arena span is found first */
+    /* ---- walk 1 (only when something depends on the whole chunk): sizes per range; packed input: the words' span ---- */
     bool packed_direct = false;
     const uint8_t *plo = nullptr;
-    if (packed) {
-        const uint8_t *l0 = (const uint8_t *)UINTPTR_MAX, *h0 = nullptr;
-        uint64_t sum = 0;
-        auto sp = [&](const uint8_t *s, int len) {
-            if (len > 0 && s) { const size_t nb = 8 * nwords(len); sum += nb; if (s < l0) l0 = s; if (s + nb > h0) h0 = s + nb; }
-        };
-        for (size_t i = 0; i < n; ++i) {
-            const bsw_task *tp = src(i, tmp, rc);
-            if (!tp) return rc;
-            if (tp->lqlen > 0) { sp(tp->lquery, tp->lqlen); sp(tp->ltarget, tp->ltlen); }
-            if (tp->rqlen > 0) { sp(tp->rquery, tp->rqlen); sp(tp->rtarget, tp->rtlen); }
+    if (T > 1 || packed) {
+        run_ranges([&](int k) {
+            range_acc &A = ra[(size_t)k];
+            bsw_task tmp;
+            int rcl = 0;
+            const size_t i0 = std::min(n, per * (size_t)k), i1 = std::min(n, i0 + per);
+            auto sp = [&](const uint8_t *sq, int len) {
+                if (len > 0 && sq) { const size_t nb = 8 * nwords(len); A.psum += nb; if (sq < A.pl0) A.pl0 = sq; if (sq + nb > A.ph0) A.ph0 = sq + nb; }
+            };
+            for (size_t i = i0; i < i1; ++i) {
+                const bsw_task *tp = src(i, tmp, rcl);
+                if (!tp) { A.rc = rcl; return; }
+                /* (lengths outside the limits are rejected by walk 2; clamp what is summed here) */
+                const int lq = std::min(std::max(tp->lqlen, 0), BSW_MAX_QLEN), rq = std::min(std::max(tp->rqlen, 0), BSW_MAX_QLEN);
+                const int lt = std::min(std::max(tp->ltlen, 0), BSW_MAX_TLEN), rt = std::min(std::max(tp->rtlen, 0), BSW_MAX_TLEN);
+                if (lq) A.words += nwords(lq) + nwords(lt);
+                if (rq) A.words += nwords(rq) + nwords(rt);
+                if (packed) {
+                    if (lq) { sp(tp->lquery, lq); sp(tp->ltarget, lt); }
+                    if (rq) { sp(tp->rquery, rq); sp(tp->rtarget, rt); }
+                } else {
+                    if (lq) A.bytes += (uint64_t)lq + (dev_targets ? 0u : (uint64_t)lt);
+                    if (rq) A.bytes += (uint64_t)rq + (dev_targets ? 0u : (uint64_t)rt);
+                }
+            }
+        });
+        for (const range_acc &A : ra) if (A.rc) { if (!A.e.msg.empty()) e = A.e; return A.rc; }
+        if (packed) {
+            /* whether the words can be DMA'd as they lie (registered, compact arena) decides the word offsets, and the staging
+             * records are write-combined memory that must not be read back — so the arena span is known before they are written */
+            const uint8_t *l0 = (const uint8_t *)UINTPTR_MAX, *h0 = nullptr;
+            uint64_t sum = 0;
+            for (const range_acc &A : ra) { if (A.pl0 < l0) l0 = A.pl0; if (A.ph0 && A.ph0 > h0) h0 = A.ph0; sum += A.psum; }
+            const size_t spb = h0 ? (size_t)(h0 - l0) : 0;
+            packed_direct = spb > 0 && spb < (1ull << 32) - RAW_SLACK && spb <= 2 * sum + (1u << 20) && is_registered(l0, spb);
+            plo = l0;
         }
-        const size_t spb = h0 ? (size_t)(h0 - l0) : 0;
-        packed_direct = spb > 0 && spb < (1ull << 32) - RAW_SLACK && spb <= 2 * sum + (1u << 20) && is_registered(l0, spb);
-        plo = l0;
     }
-    for (size_t i = 0; i < n; ++i) {
-        const bsw_task *tp = src(i, tmp, rc);
-        if (!tp) return rc;
+    std::vector<uint64_t> base_w((size_t)T + 1, 0), base_b((size_t)T + 1, 0);
+    for (int k = 0; k < T; ++k) { base_w[(size_t)k + 1] = base_w[(size_t)k] + ra[(size_t)k].words; base_b[(size_t)k + 1] = base_b[(size_t)k] + ra[(size_t)k].bytes; }
+    /* ---- walk 2: validate, lay out, count ---- */
+    run_ranges([&](int k) {
+        range_acc &A = ra[(size_t)k];
+        errs &el = A.e;
+        bsw_task tmp;
+        int rcl = 0;
+        const size_t i0 = std::min(n, per * (size_t)k), i1 = std::min(n, i0 + per);
+        uint64_t acc = base_w[(size_t)k], accb = base_b[(size_t)k];
+        const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
+        auto span = [&](const uint8_t *sq, int len) {
+            if (len > 0) { if (sq < lo) lo = sq; if (sq + len > hi) hi = sq + len; }
+        };
+        auto bad = [&](int code) { A.rc = code; };
+    for (size_t i = i0; i < i1; ++i) {
+        const bsw_task *tp = src(i, tmp, rcl);
+        if (!tp) { A.rc = rcl; return; }
         const bsw_task &t = *tp;
         if (t.lqlen < 0 || t.rqlen < 0 || t.ltlen < 0 || t.rtlen < 0)
-            return fail(e, BSW_E_INVAL, "task %zu: negative length", i + idx0);
+            return bad(fail(el, BSW_E_INVAL, "task %zu: negative length", i + idx0));
         if (t.lqlen > BSW_MAX_QLEN || t.rqlen > BSW_MAX_QLEN || t.ltlen > BSW_MAX_TLEN || t.rtlen > BSW_MAX_TLEN)
-            return fail(e, BSW_E_LIMIT, "task %zu: length beyond BSW_MAX_QLEN/BSW_MAX_TLEN", i + idx0);
-        if (t.h0 <= 0) return fail(e, BSW_E_INVAL, "task %zu: h0 must be > 0", i + idx0);
+            return bad(fail(el, BSW_E_LIMIT, "task %zu: length beyond BSW_MAX_QLEN/BSW_MAX_TLEN", i + idx0));
+        if (t.h0 <= 0) return bad(fail(el, BSW_E_INVAL, "task %zu: h0 must be > 0", i + idx0));
         if ((int64_t)t.h0 + (int64_t)(t.lqlen + t.rqlen) * mx >= BSW_MAX_SCORE)
-            return fail(e, BSW_E_LIMIT, "task %zu: score range beyond BSW_MAX_SCORE", i + idx0);
+            return bad(fail(el, BSW_E_LIMIT, "task %zu: score range beyond BSW_MAX_SCORE", i + idx0));
         if ((t.lqlen && (!t.lquery || (t.ltlen && !t.ltarget && !dev_targets))) ||
             (t.rqlen && (!t.rquery || (t.rtlen && !t.rtarget && !dev_targets))))
-            return fail(e, BSW_E_INVAL, "task %zu: NULL sequence pointer", i + idx0);
-        if (t.wlim_l < 0 || t.wlim_r < 0) return fail(e, BSW_E_INVAL, "task %zu: negative wlim", i + idx0);
+            return bad(fail(el, BSW_E_INVAL, "task %zu: NULL sequence pointer", i + idx0));
+        if (t.wlim_l < 0 || t.wlim_r < 0) return bad(fail(el, BSW_E_INVAL, "task %zu: negative wlim", i + idx0));
         bsw_dtask d;                                /* built here, stored once: dt[] is write-combined staging */
         bsw_rawoff r;
         memset(&d, 0, sizeof(d));
@@ -182,7 +248,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
              * 8-byte boundary: the spans are whole words, rawoff keeps the pointers' low bits until the arena base is known */
             if ((t.lqlen && (((uintptr_t)t.lquery | (t.ltlen ? (uintptr_t)t.ltarget : 0)) & 7)) ||
                 (t.rqlen && (((uintptr_t)t.rquery | (t.rtlen ? (uintptr_t)t.rtarget : 0)) & 7)))
-                return fail(e, BSW_E_INVAL, "task %zu: packed sequences must start on 8-byte boundaries", i + idx0);
+                return bad(fail(el, BSW_E_INVAL, "task %zu: packed sequences must start on 8-byte boundaries", i + idx0));
             /* direct: the registered arena IS the device's seq buffer, word offsets relative to its lowest word (an empty
              * target takes its query's offset: word 0 of a target may be read even when no row is) */
             if (t.lqlen) {
@@ -220,39 +286,60 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
         d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
         /* H5/H6: host-supplied band limits win over the library's formula (proc_element.v:925,933) */
-        d.wlim_l = (uint16_t)(t.wlim_l > 0 ? std::min(t.wlim_l, 65535) : glim(gl5, t.lqlen, p->pen_clip5));
-        d.wlim_r = (uint16_t)(t.wlim_r > 0 ? std::min(t.wlim_r, 65535) : glim(gl3, t.rqlen, p->pen_clip3));
+        d.wlim_l = (uint16_t)(t.wlim_l > 0 ? std::min(t.wlim_l, 65535) : gl5[(size_t)t.lqlen]);
+        d.wlim_r = (uint16_t)(t.wlim_r > 0 ? std::min(t.wlim_r, 65535) : gl3[(size_t)t.rqlen]);
         d.h0 = t.h0; d.init_score = t.init_score; d.qbeg = t.qbeg; d.tag = t.tag;
         dt[i] = d;
         if (!packed) ro[i] = r;                     /* (packed input has no byte offsets) */
         /* class counts (the device sorts with the same functions) */
         const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
-        const int wc = bsw_wave_class_of(&bp, qm);
-        if (wc < 0) return fail(e, BSW_E_LIMIT, "task %zu: no kernel class", i + idx0);
-        ++cw_all[wc];
+        const int wc = wcls[(size_t)qm];
+        if (wc < 0) return bad(fail(el, BSW_E_LIMIT, "task %zu: no kernel class", i + idx0));
+        ++A.cw_all[wc];
         const int bits = bsw_seed_lane_bits(&bp, t.lqlen, t.rqlen, t.h0);
-        if (!bits) ++cw[wc];
+        if (!bits) ++A.cw[wc];
         else {
-            ++n_lane;
-            if (bits == 16) { ++n16; ++cw16[wc]; }
+            ++A.n_lane;
+            if (bits == 16) { ++A.n16; ++A.cw16[wc]; }
             int lc = -1;
             if (t.lqlen) {
-                const int c = lc = bsw_side_lane_class(&bp, bits, t.lqlen);
-                if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i + idx0);
-                ++cl[c];
-                lane_work[c] += (uint64_t)t.lqlen;
-                if (bits == 8) work8_l += (uint64_t)t.lqlen;
-                h0_lo = std::min(h0_lo, t.h0); h0_hi = std::max(h0_hi, t.h0);
+                const int c = lc = bits == 8 ? lcls8[(size_t)t.lqlen] : lcls16[(size_t)t.lqlen];
+                if (c < 0) return bad(fail(el, BSW_E_LIMIT, "task %zu: no lane class", i + idx0));
+                ++A.cl[c];
+                A.lane_work[c] += (uint64_t)t.lqlen;
+                if (bits == 8) A.work8_l += (uint64_t)t.lqlen;
+                A.h0_lo = std::min(A.h0_lo, t.h0); A.h0_hi = std::max(A.h0_hi, t.h0);
             }
             if (t.rqlen) {
-                const int c = bsw_side_lane_class(&bp, bits, t.rqlen);
-                if (c < 0) return fail(e, BSW_E_LIMIT, "task %zu: no lane class", i + idx0);
-                ++cr[c];
-                lane_work[c] += (uint64_t)t.rqlen;
-                if (bits == 8) work8_r += (uint64_t)t.rqlen;
-                if (lc >= 0) dep[lc] |= (uint8_t)(1u << c);
+                const int c = bits == 8 ? lcls8[(size_t)t.rqlen] : lcls16[(size_t)t.rqlen];
+                if (c < 0) return bad(fail(el, BSW_E_LIMIT, "task %zu: no lane class", i + idx0));
+                ++A.cr[c];
+                A.lane_work[c] += (uint64_t)t.rqlen;
+                if (bits == 8) A.work8_r += (uint64_t)t.rqlen;
+                if (lc >= 0) A.dep[lc] |= (uint8_t)(1u << c);
             }
         }
+    }
+        A.lo = lo; A.hi = hi;
+        A.words = acc - base_w[(size_t)k]; A.bytes = accb - base_b[(size_t)k];
+    });
+    /* merge the ranges (the first failure in seed order is the one reported) */
+    for (const range_acc &A : ra) if (A.rc) { if (!A.e.msg.empty()) e = A.e; return A.rc; }
+    uint64_t acc = 0, accb = 0;
+    const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
+    uint32_t cw_all[BSW_MAX_WAVE_CLASSES] = {0}, cw[BSW_MAX_WAVE_CLASSES] = {0}, cw16[BSW_MAX_WAVE_CLASSES] = {0};
+    uint32_t cl[BSW_MAX_LANE_CLASSES] = {0}, cr[BSW_MAX_LANE_CLASSES] = {0}, n_lane = 0, n16 = 0;
+    uint8_t dep[BSW_MAX_LANE_CLASSES] = {0};
+    uint64_t lane_work[BSW_MAX_LANE_CLASSES] = {0};          /* sum of query lengths per lane class (narrow_fold) */
+    uint64_t work8_l = 0, work8_r = 0;                       /* ... of the 8-bit left / right sides (decide_lane_mode) */
+    int h0_lo = INT_MAX, h0_hi = 0;                          /* h0 range of the left sides that go to lane classes (bsw_h0_bucket) */
+    for (const range_acc &A : ra) {
+        acc += A.words; accb += A.bytes;
+        if (A.hi) { if (A.lo < lo) lo = A.lo; if (A.hi > hi) hi = A.hi; }
+        for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) { cw_all[c] += A.cw_all[c]; cw[c] += A.cw[c]; cw16[c] += A.cw16[c]; }
+        for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) { cl[c] += A.cl[c]; cr[c] += A.cr[c]; dep[c] |= A.dep[c]; lane_work[c] += A.lane_work[c]; }
+        n_lane += A.n_lane; n16 += A.n16; work8_l += A.work8_l; work8_r += A.work8_r;
+        h0_lo = std::min(h0_lo, A.h0_lo); h0_hi = std::max(h0_hi, A.h0_hi);
     }
     if (acc >= (1ull << 32)) return fail(e, BSW_E_LIMIT, "batch sequence arena beyond 2^32 words; split the batch");
     if (accb >= (1ull << 32) - RAW_SLACK) return fail(e, BSW_E_LIMIT, "batch holds more than 4 GiB of bases; split the batch");
@@ -336,9 +423,10 @@ static void gather_offsets(const bsw_task *tasks, size_t n, bool dev_targets, bs
 }
 
 static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task *tasks, size_t n, bool dev_targets,
-                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left = false, bool packed = false, size_t idx0 = 0)
+                         bsw_dtask *dt, bsw_rawoff *ro, chunk_info &ci, bool rev_left = false, bool packed = false, size_t idx0 = 0,
+                         int threads = 1, std::atomic<uint64_t> *helper_ns = nullptr)
 {
-    int rc = prepare_chunk_t(e, p, kern, [tasks](size_t i, bsw_task &, int &) { return tasks + i; }, n, dev_targets, dt, ro, ci, rev_left, packed, idx0);
+    int rc = prepare_chunk_t(e, p, kern, [tasks](size_t i, bsw_task &, int &) { return tasks + i; }, n, dev_targets, dt, ro, ci, rev_left, packed, idx0, threads, helper_ns);
     if (!rc && !ci.direct && !packed) gather_offsets(tasks, n, dev_targets, ro);
     return rc;
 }
@@ -361,13 +449,6 @@ static void gather_packed(const bsw_task *tasks, const bsw_dtask *dt, size_t n, 
 }
 
 /* copy the sequences of tasks[0..n) into the pinned staging arena laid out by prepare_chunk */
-static inline uint64_t thread_cpu_ns()
-{
-    struct timespec ts;
-    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
-    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
-}
-
 /* helper_ns: CPU time of the helper threads started here (the calling thread accounts for itself) */
 static void gather_raw(const bsw_task *tasks, const bsw_rawoff *ro, size_t n, bool dev_targets, uint8_t *dst, int threads, bool rev_left = false,
                        std::atomic<uint64_t> *helper_ns = nullptr)
@@ -1374,6 +1455,9 @@ static void slot_main(bsw_ctx *ctx, size_t d, size_t s)
         bool passed = false, queued = false;         /* the DMA turn has been passed on; some async op of this chunk may be on the stream */
         const double t0 = dbg ? tnow() : 0;
         double t1 = t0, t2 = t0;
+        /* the host pass of a chunk on pass_threads threads side by side (this one + helpers started for the pass): the context's
+         * pack_threads spread over its slots, at least two */
+        const int pass_threads = std::max(2, ctx->cfg.pack_threads / (int)dev.slots.size() + 1);
         do {
             if (dev_err != hipSuccess) { rc = fail(e, BSW_E_HIP, "hipSetDevice: %s", hipGetErrorString(dev_err)); break; }
             if (t->abort) { rc = fail(e, BSW_E_HIP, "aborted: another chunk failed"); break; }
@@ -1385,11 +1469,15 @@ static void slot_main(bsw_ctx *ctx, size_t d, size_t s)
                 const bsw_ref_task *crt = t->rtasks + base;
                 bsw_refx *rx = st.h_desc.p;
                 size_t so = 0;
+                std::mutex emu;                      /* (the pass runs on several threads: a failing seed's text is written under it) */
                 rc = prepare_chunk_t(e, &p, ctx->cfg.kernel, [&](size_t i, bsw_task &tmp, int &erc) -> const bsw_task * {
-                    erc = ref_to_task(e, &p, t->ref->l_pac, crt[i], base + i, true, nullptr, so, tmp);
+                    errs le;
+                    size_t so_l = 0;                 /* (rev_left: nothing is written to scratch) */
+                    erc = ref_to_task(le, &p, t->ref->l_pac, crt[i], base + i, true, nullptr, so_l, tmp);
+                    if (erc) { std::lock_guard<std::mutex> lk(emu); e = le; }
                     rx[i] = bsw_refx{crt[i].seed.rbeg - 1, crt[i].seed.rbeg + crt[i].seed.len};
                     return erc ? nullptr : &tmp;
-                }, n, true, st.h_tasks.p, st.h_roff.p, ci, true, false, base);
+                }, n, true, st.h_tasks.p, st.h_roff.p, ci, true, false, base, pass_threads, &pp.helper_cpu_ns);
                 if (rc) break;
                 if (!ci.direct) {                   /* reads in pageable memory: materialise the tasks for the gather */
                     rt_tasks.resize(n);
@@ -1398,7 +1486,7 @@ static void slot_main(bsw_ctx *ctx, size_t d, size_t s)
                     ct = rt_tasks.data();
                     gather_offsets(ct, n, true, st.h_roff.p);
                 }
-            } else if ((rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci, false, t->packed, base))) break;
+            } else if ((rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci, false, t->packed, base, pass_threads, &pp.helper_cpu_ns))) break;
             if (!ci.direct) {
                 if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) { rc = fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)); break; }
                 if (t->packed) gather_packed(ct, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
