@@ -433,6 +433,7 @@ def main():
     ap.add_argument("--packed-chunk", type=int, default=0, help="seeds per chunk of the packed-input legs (0 = the library's choice: sized by the seeds' work, bsw_config.chunk_tasks = 0)")
     ap.add_argument("--e2e-chunk", type=int, default=0, help="seeds per chunk of the byte-input and device-reference legs (0 = the library's choice)")
     ap.add_argument("--e2e-slots", type=int, default=4, help="slot threads (= streams) of the PCIe-inclusive legs")
+    ap.add_argument("--e2e-pack-threads", type=int, default=8, help="bsw_config.pack_threads of the PCIe-inclusive legs: a chunk's host pass runs on 1 + this / slots threads")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bsw_submit (PCIe-inclusive) measurements")
     ap.add_argument("--e2e-reps", type=int, default=5, help="bsw_submit passes timed (median reported)")
     ap.add_argument("--stream-reps", type=int, default=8, help="batches of a stream leg (two submits in flight in ONE context)")
@@ -698,26 +699,26 @@ def main():
         out_buf = hout.view(host.RESULT, max(n_local, 1))[:n_local]
         out_buf2 = hout2.view(host.RESULT, max(n_local, 1))[:n_local]
         # -- byte per base in a registered arena: DMA'd as it is, packed and binned on the GPU
-        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.e2e_chunk) as c:
+        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=args.e2e_pack_threads, chunk_tasks=args.e2e_chunk) as c:
             runs, before = single_submits(c, lambda: c.extend_pairs(params, tasks, out=out_buf), args.e2e_reps)
             legs["e2e"] = {"runs": runs, "same": bool(out_buf.tobytes() == res.tobytes()), "host": host_cost(c, n_local, before)}
-        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=STREAM_CHUNK["bytes"]) as c:
+        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=args.e2e_pack_threads, chunk_tasks=STREAM_CHUNK["bytes"]) as c:
             d2, before = stream_two_deep(c, lambda o: c.submit(params, tasks, o), (out_buf, out_buf2), args.stream_reps)
             legs["e2e_stream"] = {"runs": [d2], "same": bool(out_buf.tobytes() == res.tobytes() and out_buf2.tobytes() == res.tobytes()), "host": host_cost(c, n_local, before)}
         # -- the same seeds handed over 4-BIT PACKED (the device layout; bsw_submit_packed): no pack kernel, ~0.6x the PCIe bytes
         need = int(host.lib().bsw_pack_tasks_bound(tasks.ctypes.data, len(tasks)))
         parena = host.HostArena(need + 64)
         ptasks, _w = host.pack_tasks(tasks, parena.view(np.uint64, need // 8 + 1))
-        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.packed_chunk) as c:
+        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=args.e2e_pack_threads, chunk_tasks=args.packed_chunk) as c:
             runs, before = single_submits(c, lambda: c.extend_pairs_packed(params, ptasks, out=out_buf), args.e2e_reps)
             legs["packed"] = {"runs": runs, "same": bool(out_buf.tobytes() == res.tobytes()), "host": host_cost(c, n_local, before), "bytes": need}
-        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=STREAM_CHUNK["packed"]) as c:
+        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=args.e2e_pack_threads, chunk_tasks=STREAM_CHUNK["packed"]) as c:
             d2, before = stream_two_deep(c, lambda o: c.submit_packed(params, ptasks, o), (out_buf, out_buf2), args.stream_reps)
             legs["packed_stream"] = {"runs": [d2], "same": bool(out_buf.tobytes() == res.tobytes() and out_buf2.tobytes() == res.tobytes()), "host": host_cost(c, n_local, before)}
         # -- the same submit handing back the RTL's 5-word record alone (BSW_RESULT_PAIR: 32 of the 96 result bytes per seed)
         pout = host.HostArena(max(n_local, 1) * host.PAIR.itemsize)
         pair_buf = pout.view(host.PAIR, max(n_local, 1))[:n_local]
-        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.packed_chunk, result_format=host.RESULT_PAIR) as c:
+        with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=args.e2e_pack_threads, chunk_tasks=args.packed_chunk, result_format=host.RESULT_PAIR) as c:
             runs, before = single_submits(c, lambda: c.extend_pairs_packed(params, ptasks, out=pair_buf), args.e2e_reps)
             legs["packed_pairs"] = {"runs": runs, "same": all(bool((pair_buf[f] == res[f]).all()) for f in host.PAIR.names), "host": host_cost(c, n_local, before)}
         pout.free()
@@ -727,7 +728,7 @@ def main():
             lp = args.ref_mbp * 1_000_000
             hreads = host.HostArena(spec["read_len"] * n_local + 4096)
             pac, rtasks, _ = host.synth_ref_tasks(n_local, lp, params, arena=hreads.u8, seed=3000 + rank, **spec)
-            with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=args.e2e_chunk) as c:
+            with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=args.e2e_pack_threads, chunk_tasks=args.e2e_chunk) as c:
                 gref = c.ref_upload(pac, lp)
 
                 def ref_call():
@@ -739,7 +740,7 @@ def main():
                                "bytes": int(rtasks["l_query"].astype(np.int64).sum()),
                                "same": bool(c.extend_ref(params, gref, rtasks[:nchk]).tobytes() == out_buf[:nchk].tobytes())}
                 c.ref_free(gref)
-            with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=4, chunk_tasks=STREAM_CHUNK["ref"]) as c:
+            with host.BswContext(device=local_rank, kernel=args.kernel, streams=args.e2e_slots, pack_threads=args.e2e_pack_threads, chunk_tasks=STREAM_CHUNK["ref"]) as c:
                 gref = c.ref_upload(pac, lp)
                 d2, before = stream_two_deep(c, lambda o: c.submit_ref(params, gref, rtasks, out=o), (out_buf, out_buf2), args.stream_reps)
                 legs["ref_stream"] = {"runs": [d2], "host": host_cost(c, n_local, before),
@@ -869,7 +870,7 @@ def main():
                     o["spread"] = spread(legs[name]["runs"], n_local)
                 else:
                     o["batches_timed"] = 2 * args.stream_reps
-                    o["in_flight"] = "two submits in ONE context (tickets: bsw_submit_t / bsw_wait_ticket), %d slot threads" % args.e2e_slots
+                    o["in_flight"] = "two submits in ONE context (tickets: bsw_submit_t / bsw_wait_ticket), %d slot threads + %d helpers each for the host pass" % (args.e2e_slots, args.e2e_pack_threads // max(args.e2e_slots, 1))
                 if extra:
                     o.update(extra)
                 return o

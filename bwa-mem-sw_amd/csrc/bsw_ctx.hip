@@ -128,7 +128,7 @@ extern "C" void bsw_default_config(bsw_config *c)
     c->device = 0;
     c->kernel = BSW_KERNEL_AUTO;
     c->streams = 4;
-    c->pack_threads = 4;
+    c->pack_threads = 8;              /* the host pass of a chunk runs on 1 + pack_threads / slots threads (bsw_batch.hip) */
     c->chunk_tasks = 0;               /* 0 = sized per submit by the seeds' work (bsw_batch.hip: submit_common) */
     c->n_devices = 0;
     c->timeout_ms = 0;                /* 0 = the library default: BSW_TIMEOUT_MS if set, else 120 s (bsw_effective_timeout_ms) */

@@ -302,7 +302,7 @@ class DeviceBatch:
 class BswContext:
     """One GPU context = one of the reference's PE arrays behind its batch manager."""
 
-    def __init__(self, device=0, kernel=KERNEL_AUTO, streams=4, pack_threads=4, chunk_tasks=0, devices=None,
+    def __init__(self, device=0, kernel=KERNEL_AUTO, streams=4, pack_threads=8, chunk_tasks=0, devices=None,
                  timeout_ms=0, result_format=RESULT_FULL, pin_threads=None):
         cfg = np.zeros(1, dtype=CONFIG)
         lib().bsw_default_config(cfg.ctypes.data)

@@ -130,8 +130,9 @@ typedef struct bsw_config {
     int32_t device;         /* HIP device ordinal (used when n_devices == 0)      */
     int32_t kernel;         /* BSW_KERNEL_*                                      */
     int32_t streams;        /* staging slots per device = streams = pipeline threads of bsw_submit (1..8, def 4) */
-    int32_t pack_threads;   /* extra host threads that gather sequences which are NOT in registered memory
-                               into pinned staging, shared by the slots (def 4; registered arenas need none) */
+    int32_t pack_threads;   /* helper threads of the slots (def 8): a chunk's host pass (validate, lay out, count) runs on
+                               1 + pack_threads / streams threads side by side, and so does the gather of sequences that
+                               are NOT in registered memory into pinned staging */
     size_t  chunk_tasks;    /* tasks per H2D/launch chunk in bsw_submit; 0 (def) = sized per submit by the seeds' work:
                                128 Ki seeds of 131-base sides, more of shorter ones (two chunks in flight fill the GPU) */
     /* One context can drive several GPUs, as the reference's batch manager drives its 4 PE arrays
