@@ -235,6 +235,8 @@ struct h2d_gate {
 struct refbatch_req {
     const uint32_t *in;
     uint32_t *out;
+    uint32_t nt;                      /* the batch's task count AS VALIDATED AT SUBMIT (<= BSW_REFBATCH_MAX_TASKS): the header is the
+                                         caller's memory until the wait, and nothing downstream re-reads the count from it */
 };
 
 struct pipeline;

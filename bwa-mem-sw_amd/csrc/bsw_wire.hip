@@ -16,7 +16,7 @@ extern "C" int bsw_refbatch_submit(bsw_ctx *ctx, const uint32_t *in_words, uint3
     if (rc) return rc;
     if (ctx->ref_queue.size() >= BSW_REFBATCH_MAX_INFLIGHT) return fail(ctx->err, BSW_E_BUSY, "%d task batches already in flight", BSW_REFBATCH_MAX_INFLIGHT);
     if (in_words[2] > BSW_REFBATCH_MAX_TASKS) return fail(ctx->err, BSW_E_LIMIT, "task batch announces %u tasks (> %d)", in_words[2], BSW_REFBATCH_MAX_TASKS);
-    ctx->ref_queue.push_back(refbatch_req{in_words, out_words});
+    ctx->ref_queue.push_back(refbatch_req{in_words, out_words, in_words[2]});
     return BSW_OK;
 }
 
@@ -48,7 +48,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     int rc = check_params(e, &p, &dp);
     if (rc) return rc;
     size_t n = 0;
-    for (size_t q = q0; q < q1; ++q) n += ctx->ref_queue[q].in[2];
+    for (size_t q = q0; q < q1; ++q) n += ctx->ref_queue[q].nt;       /* (the count snapshot of bsw_refbatch_submit, never the header again) */
     if (n == 0) {
         for (size_t q = q0; q < q1; ++q) memset(ctx->ref_queue[q].out, 0, BSW_REFBATCH_OUT_WORDS * sizeof(uint32_t));
         return BSW_OK;
@@ -68,7 +68,10 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     if (direct)
         for (size_t q = q0; q < q1;) {                 /* one DMA per run of batches that lie back to back in the caller's memory */
             size_t r1 = q + 1;
-            while (r1 < q1 && ctx->ref_queue[r1].in == ctx->ref_queue[r1 - 1].in + BSW_REFBATCH_IN_WORDS) ++r1;
+            /* (a run ends where the next batch is not adjacent OR the span would leave one registered range: two registrations
+             * that happen to touch are two DMAs) */
+            while (r1 < q1 && ctx->ref_queue[r1].in == ctx->ref_queue[r1 - 1].in + BSW_REFBATCH_IN_WORDS &&
+                   is_registered(ctx->ref_queue[q].in, (r1 + 1 - q) * (size_t)BSW_REFBATCH_IN_WORDS * sizeof(uint32_t))) ++r1;
             HIPCHK(e, hipMemcpyAsync(st.d_raw.p + (q - q0) * (size_t)BSW_REFBATCH_IN_WORDS * 4, ctx->ref_queue[q].in,
                                      (r1 - q) * (size_t)BSW_REFBATCH_IN_WORDS * 4, hipMemcpyHostToDevice, s));
             q = r1;
@@ -92,7 +95,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
         auto count = [&](size_t t) {
             for (size_t q = q0 + t; q < q1; q += nth) {
                 const uint32_t *W = ctx->ref_queue[q].in;
-                const uint32_t nt = W[2];
+                const uint32_t nt = ctx->ref_queue[q].nt;
                 uint64_t words = 0;
                 for (uint32_t i = 0; i < nt && 8 + 8 * (uint64_t)i + 1 < BSW_REFBATCH_IN_WORDS; ++i) {
                     const uint32_t *H = &W[8 + 8 * i];
@@ -124,7 +127,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
         part &pt = parts[t];
         for (size_t q = q0 + t; q < q1; q += nth) {
             const uint32_t *W = ctx->ref_queue[q].in;
-            const uint32_t nt = W[2];
+            const uint32_t nt = ctx->ref_queue[q].nt;
             uint64_t a2 = wbase[q - q0];
             size_t ti = (size_t)tbase[q - q0];
             if (nth == 1) tbase[q - q0 + 1] = tbase[q - q0] + nt;
@@ -266,7 +269,8 @@ static int refbatch_collect_issue(bsw_ctx *ctx, size_t q0, size_t q1, stage_t &s
     }
     for (size_t q = q0; q < q1;) {
         size_t r1 = q + 1;
-        while (r1 < q1 && ctx->ref_queue[r1].out == ctx->ref_queue[r1 - 1].out + bw) ++r1;
+        while (r1 < q1 && ctx->ref_queue[r1].out == ctx->ref_queue[r1 - 1].out + bw &&
+               is_registered(ctx->ref_queue[q].out, (r1 + 1 - q) * (size_t)bw * sizeof(uint32_t))) ++r1;
         HIPCHK(e, hipMemcpyAsync(ctx->ref_queue[q].out, st.d_wout.p + (q - q0) * bw, (r1 - q) * bw * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         q = r1;
     }
