@@ -158,7 +158,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
      * PCIe-inclusive leg of bench.py: four slot threads = 100 - 140 M seeds/s of host-pass capacity against 240 M the GPU
      * takes (profiles/r6/e2e_host_pass.txt).  The seeds are cut into ranges; a first, cheap walk sizes every range (words,
      * bytes; packed input: the span of its words), a prefix sum gives every range its base, the second walk writes the records. */
-    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), n / 32768 + 1));
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min(std::max(threads, 1), BSW_REBASE_MAX), n / 32768 + 1));
     std::vector<range_acc> ra((size_t)T);
     const size_t per = (n + (size_t)T - 1) / (size_t)T;
     auto run_ranges = [&](auto &&fn) {
@@ -168,49 +168,12 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         fn(0);
         for (auto &t : th) t.join();
     };
-    /* ---- walk 1 (only when something depends on the whole chunk): sizes per range; packed input: the words' span ---- */
-    bool packed_direct = false;
-    const uint8_t *plo = nullptr;
-    if (T > 1 || packed) {
-        run_ranges([&](int k) {
-            range_acc &A = ra[(size_t)k];
-            bsw_task tmp;
-            int rcl = 0;
-            const size_t i0 = std::min(n, per * (size_t)k), i1 = std::min(n, i0 + per);
-            auto sp = [&](const uint8_t *sq, int len) {
-                if (len > 0 && sq) { const size_t nb = 8 * nwords(len); A.psum += nb; if (sq < A.pl0) A.pl0 = sq; if (sq + nb > A.ph0) A.ph0 = sq + nb; }
-            };
-            for (size_t i = i0; i < i1; ++i) {
-                const bsw_task *tp = src(i, tmp, rcl);
-                if (!tp) { A.rc = rcl; return; }
-                /* (lengths outside the limits are rejected by walk 2; clamp what is summed here) */
-                const int lq = std::min(std::max(tp->lqlen, 0), BSW_MAX_QLEN), rq = std::min(std::max(tp->rqlen, 0), BSW_MAX_QLEN);
-                const int lt = std::min(std::max(tp->ltlen, 0), BSW_MAX_TLEN), rt = std::min(std::max(tp->rtlen, 0), BSW_MAX_TLEN);
-                if (lq) A.words += nwords(lq) + nwords(lt);
-                if (rq) A.words += nwords(rq) + nwords(rt);
-                if (packed) {
-                    if (lq) { sp(tp->lquery, lq); sp(tp->ltarget, lt); }
-                    if (rq) { sp(tp->rquery, rq); sp(tp->rtarget, rt); }
-                } else {
-                    if (lq) A.bytes += (uint64_t)lq + (dev_targets ? 0u : (uint64_t)lt);
-                    if (rq) A.bytes += (uint64_t)rq + (dev_targets ? 0u : (uint64_t)rt);
-                }
-            }
-        });
-        for (const range_acc &A : ra) if (A.rc) { if (!A.e.msg.empty()) e = A.e; return A.rc; }
-        if (packed) {
-            /* whether the words can be DMA'd as they lie (registered, compact arena) decides the word offsets, and the staging
-             * records are write-combined memory that must not be read back — so the arena span is known before they are written */
-            const uint8_t *l0 = (const uint8_t *)UINTPTR_MAX, *h0 = nullptr;
-            uint64_t sum = 0;
-            for (const range_acc &A : ra) { if (A.pl0 < l0) l0 = A.pl0; if (A.ph0 && A.ph0 > h0) h0 = A.ph0; sum += A.psum; }
-            const size_t spb = h0 ? (size_t)(h0 - l0) : 0;
-            packed_direct = spb > 0 && spb < (1ull << 32) - RAW_SLACK && spb <= 2 * sum + (1u << 20) && is_registered(l0, spb);
-            plo = l0;
-        }
-    }
-    std::vector<uint64_t> base_w((size_t)T + 1, 0), base_b((size_t)T + 1, 0);
-    for (int k = 0; k < T; ++k) { base_w[(size_t)k + 1] = base_w[(size_t)k] + ra[(size_t)k].words; base_b[(size_t)k + 1] = base_b[(size_t)k] + ra[(size_t)k].bytes; }
+    /* ONE walk.  Word offsets are written RELATIVE TO THE RANGE (every range counts from 0) and made absolute on the device:
+     * bsw_rebase_kernel adds the range's base — known only when all ranges are done — to the four offsets of each of its seeds
+     * (44 bytes read-modify-write per seed at HBM speed: nothing beside a second host walk, which is what the first version of
+     * the parallel pass spent half its time on).  Packed input that can be DMA'd as it lies takes its offsets from the POINTERS:
+     * rawoff (unused by packed input otherwise) carries (pointer >> 3) mod 2^32 per sequence, and the device adds
+     * -(arena base >> 3): whether the arena is compact and registered is decided after the walk, from the span it found. */
     /* ---- walk 2: validate, lay out, count ---- */
     run_ranges([&](int k) {
         range_acc &A = ra[(size_t)k];
@@ -218,7 +181,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         bsw_task tmp;
         int rcl = 0;
         const size_t i0 = std::min(n, per * (size_t)k), i1 = std::min(n, i0 + per);
-        uint64_t acc = base_w[(size_t)k], accb = base_b[(size_t)k];
+        uint64_t acc = 0, accb = 0;
         const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
         auto span = [&](const uint8_t *sq, int len) {
             if (len > 0) { if (sq < lo) lo = sq; if (sq + len > hi) hi = sq + len; }
@@ -249,21 +212,22 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
             if ((t.lqlen && (((uintptr_t)t.lquery | (t.ltlen ? (uintptr_t)t.ltarget : 0)) & 7)) ||
                 (t.rqlen && (((uintptr_t)t.rquery | (t.rtlen ? (uintptr_t)t.rtarget : 0)) & 7)))
                 return bad(fail(el, BSW_E_INVAL, "task %zu: packed sequences must start on 8-byte boundaries", i + idx0));
-            /* direct: the registered arena IS the device's seq buffer, word offsets relative to its lowest word (an empty
-             * target takes its query's offset: word 0 of a target may be read even when no row is) */
+            /* d: offsets for the gathered layout (range-relative); r: (pointer >> 3) mod 2^32, what the device turns into
+             * offsets into the arena when it is DMA'd as it lies (an empty target takes its query's word: word 0 of a target
+             * may be read even when no row is) */
             if (t.lqlen) {
-                d.lq_off = packed_direct ? (uint32_t)((t.lquery - plo) >> 3) : (uint32_t)acc;
-                acc += nwords(t.lqlen);
-                d.lt_off = packed_direct ? (uint32_t)(((t.ltlen ? t.ltarget : t.lquery) - plo) >> 3) : (uint32_t)acc;
-                acc += nwords(t.ltlen);
+                d.lq_off = (uint32_t)acc; acc += nwords(t.lqlen);
+                d.lt_off = (uint32_t)acc; acc += nwords(t.ltlen);
+                r.lq = (uint32_t)((uintptr_t)t.lquery >> 3);
+                r.lt = (uint32_t)((uintptr_t)(t.ltlen ? t.ltarget : t.lquery) >> 3);
                 accb += 8ull * (nwords(t.lqlen) + nwords(t.ltlen));
                 span(t.lquery, 8 * (int)nwords(t.lqlen)); span(t.ltarget, 8 * (int)nwords(t.ltlen));
             }
             if (t.rqlen) {
-                d.rq_off = packed_direct ? (uint32_t)((t.rquery - plo) >> 3) : (uint32_t)acc;
-                acc += nwords(t.rqlen);
-                d.rt_off = packed_direct ? (uint32_t)(((t.rtlen ? t.rtarget : t.rquery) - plo) >> 3) : (uint32_t)acc;
-                acc += nwords(t.rtlen);
+                d.rq_off = (uint32_t)acc; acc += nwords(t.rqlen);
+                d.rt_off = (uint32_t)acc; acc += nwords(t.rtlen);
+                r.rq = (uint32_t)((uintptr_t)t.rquery >> 3);
+                r.rt = (uint32_t)((uintptr_t)(t.rtlen ? t.rtarget : t.rquery) >> 3);
                 accb += 8ull * (nwords(t.rqlen) + nwords(t.rtlen));
                 span(t.rquery, 8 * (int)nwords(t.rqlen)); span(t.rtarget, 8 * (int)nwords(t.rtlen));
             }
@@ -290,7 +254,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         d.wlim_r = (uint16_t)(t.wlim_r > 0 ? std::min(t.wlim_r, 65535) : gl3[(size_t)t.rqlen]);
         d.h0 = t.h0; d.init_score = t.init_score; d.qbeg = t.qbeg; d.tag = t.tag;
         dt[i] = d;
-        if (!packed) ro[i] = r;                     /* (packed input has no byte offsets) */
+        ro[i] = r;
         /* class counts (the device sorts with the same functions) */
         const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
         const int wc = wcls[(size_t)qm];
@@ -321,7 +285,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         }
     }
         A.lo = lo; A.hi = hi;
-        A.words = acc - base_w[(size_t)k]; A.bytes = accb - base_b[(size_t)k];
+        A.words = acc; A.bytes = accb;
     });
     /* merge the ranges (the first failure in seed order is the one reported) */
     for (const range_acc &A : ra) if (A.rc) { if (!A.e.msg.empty()) e = A.e; return A.rc; }
@@ -397,9 +361,21 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         if (dbg) fprintf(stderr, "[bsw] chunk n=%zu: %s%s, span %zu B for %zu B referenced\n", n, packed ? "packed " : "", ci.direct ? "direct DMA" : "gather", spanb, ci.sum_len);
     }
     if (packed) {
-        ci.direct = packed_direct;
-        if (packed_direct) ci.words = spanb >> 3;
+        /* (span and bytes of packed input are whole words: lo / hi / sum_len were taken over 8 * nwords) */
+        ci.direct = spanb > 0 && spanb < (1ull << 32) - RAW_SLACK && spanb <= 2 * ci.sum_len + (1u << 20) && is_registered(lo, spanb);
+        ci.rev_left = false;
+        ci.raw_bias = 0;
+        if (ci.direct) ci.words = spanb >> 3;
     }
+    /* what bsw_rebase_kernel has to do to the records on the device */
+    ci.rb = bsw_rebase();
+    ci.rb.per = (uint32_t)std::max<size_t>(per, 1);
+    ci.rb.nr = (uint32_t)T;
+    uint64_t run = 0;
+    for (int k = 0; k < T; ++k) { ci.rb.base[k] = (uint32_t)run; run += ra[(size_t)k].words; }
+    ci.rb.use_ro = packed && ci.direct ? 1u : 0u;
+    ci.rb.delta = ci.rb.use_ro ? (uint32_t)(0u - (uint32_t)((uintptr_t)lo >> 3)) : 0u;
+    ci.rb_on = T > 1 || ci.rb.use_ro;
     return BSW_OK;
 }
 
@@ -432,11 +408,13 @@ static int prepare_chunk(errs &e, const bsw_params *p, int kern, const bsw_task 
 }
 
 /* packed sequences that are not in registered memory: their words go to the pinned staging arena in seq layout */
-static void gather_packed(const bsw_task *tasks, const bsw_dtask *dt, size_t n, uint64_t *dst)
+static void gather_packed(const bsw_task *tasks, const bsw_dtask *dt, size_t n, uint64_t *dst, const bsw_rebase &rb)
 {
     for (size_t i = 0; i < n; ++i) {
         const bsw_task &t = tasks[i];
-        const bsw_dtask &d = dt[i];
+        bsw_dtask d = dt[i];
+        const uint32_t base = rb.base[std::min<size_t>(i / rb.per, rb.nr - 1)];       /* (the records hold range-relative offsets until the device rebases them) */
+        d.lq_off += base; d.lt_off += base; d.rq_off += base; d.rt_off += base;
         if (t.lqlen) {
             memcpy(dst + d.lq_off, t.lquery, 8 * nwords(t.lqlen));
             if (t.ltlen) memcpy(dst + d.lt_off, t.ltarget, 8 * nwords(t.ltlen));
@@ -739,7 +717,7 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
             if (ci.words) ce = hipMemcpyAsync(st.d_seq.p, ci.direct ? (const void *)ci.lo : (const void *)st.h_raw.p, ci.words * 8, hipMemcpyHostToDevice, s);
         } else if (rawb) ce = hipMemcpyAsync(st.d_raw.p + RAW_FRONT, ci.direct ? ci.lo : st.h_raw.p, rawb, hipMemcpyHostToDevice, s);
         if (ce == hipSuccess) ce = hipMemcpyAsync(st.d_tasks.p, st.h_tasks.p, n * sizeof(bsw_dtask), hipMemcpyHostToDevice, s);
-        if (ce == hipSuccess && !ci.packed) ce = hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s);
+        if (ce == hipSuccess && (!ci.packed || ci.rb.use_ro)) ce = hipMemcpyAsync(st.d_roff.p, st.h_roff.p, n * sizeof(bsw_rawoff), hipMemcpyHostToDevice, s);
         if (ce == hipSuccess && n_desc) ce = hipMemcpyAsync(st.d_desc.p, st.h_desc.p, n_desc * sizeof(bsw_refx), hipMemcpyHostToDevice, s);
         if (turn) {
             if (ce == hipSuccess) ce = hipEventRecord(turn->ev, s);
@@ -751,6 +729,7 @@ static int stage_device(errs &e, stage_t &st, hipStream_t s, const chunk_info &c
         if (ce != hipSuccess) return fail(e, BSW_E_HIP, "input DMA: %s", hipGetErrorString(ce));
     }
     (void)dev_targets;
+    if (ci.rb_on) HIPCHK(e, bsw::launch_rebase(st.d_tasks.p, st.d_roff.p, (uint32_t)n, ci.rb, s));
     if (!ci.packed)
         HIPCHK(e, bsw::launch_pack(st.d_raw.p + RAW_FRONT, st.d_tasks.p, st.d_roff.p, ci.raw_bias, (uint32_t)n, ci.rev_left ? 1 : 0,
                                    ref ? ref->d_pac[dev_index] : nullptr, ref ? ref->l_pac : 0, ref ? st.d_desc.p : nullptr, st.d_seq.p, st.d_nflag.p, s));
@@ -871,7 +850,7 @@ static int upload_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *task
     if (rc) { bsw_free_batch(ctx, b); return rc; }
     if (!ci.direct) {
         if (st.h_raw.reserve(ci.sum_len + RAW_SLACK) != hipSuccess) { bsw_free_batch(ctx, b); return fail(e, BSW_E_NOMEM, "host staging"); }
-        if (packed) gather_packed(tasks, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
+        if (packed) gather_packed(tasks, st.h_tasks.p, n, (uint64_t *)st.h_raw.p, ci.rb);
         else gather_raw(tasks, st.h_roff.p, n, ref != nullptr, st.h_raw.p, ctx->cfg.pack_threads);
     }
     if (ref) {
@@ -1278,7 +1257,7 @@ BSW_LOCAL int run_chunk(bsw_ctx *ctx, errs &e, stage_t &st, hipStream_t s, hipEv
     const double t_b = dbg ? tnow() : 0;
     if (!ci.direct) {
         if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) return fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he));
-        if (packed) gather_packed(tasks, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
+        if (packed) gather_packed(tasks, st.h_tasks.p, n, (uint64_t *)st.h_raw.p, ci.rb);
         else gather_raw(tasks, st.h_roff.p, n, false, st.h_raw.p, gather_threads);
     }
     const double t_c = dbg ? tnow() : 0;
@@ -1489,7 +1468,7 @@ static void slot_main(bsw_ctx *ctx, size_t d, size_t s)
             } else if ((rc = prepare_chunk(e, &p, ctx->cfg.kernel, ct, n, false, st.h_tasks.p, st.h_roff.p, ci, false, t->packed, base, pass_threads, &pp.helper_cpu_ns))) break;
             if (!ci.direct) {
                 if ((he = st.h_raw.reserve(ci.sum_len + RAW_SLACK)) != hipSuccess) { rc = fail(e, BSW_E_NOMEM, "pinned staging: %s", hipGetErrorString(he)); break; }
-                if (t->packed) gather_packed(ct, st.h_tasks.p, n, (uint64_t *)st.h_raw.p);
+                if (t->packed) gather_packed(ct, st.h_tasks.p, n, (uint64_t *)st.h_raw.p, ci.rb);
                 else gather_raw(ct, st.h_roff.p, n, t->rtasks != nullptr, st.h_raw.p, std::max(1, ctx->cfg.pack_threads / (int)dev.slots.size()), t->rtasks != nullptr, &pp.helper_cpu_ns);
             }
         } while (0);

@@ -40,6 +40,16 @@ typedef struct bsw_rawoff {
     uint32_t lq, lt, rq, rt;
 } bsw_rawoff;
 
+/* what bsw_rebase_kernel does to the task records of a chunk: the host writes word offsets relative to the RANGE of seeds a
+ * thread walked (bsw_batch.hip: prepare_chunk_t), the device adds the range's base; packed input DMA'd as it lies takes its
+ * offsets from rawoff = (host pointer >> 3) mod 2^32 plus delta = -(arena base >> 3) */
+#define BSW_REBASE_MAX 16
+typedef struct bsw_rebase {
+    uint32_t per, nr;                          /* seeds per range, ranges */
+    uint32_t use_ro, delta;
+    uint32_t base[BSW_REBASE_MAX];
+} bsw_rebase;
+
 typedef struct bsw_dparams {
     int8_t  mat[25];
     int8_t  pad[3];

@@ -314,6 +314,8 @@ struct chunk_info {
                                          DMA'd straight into `seq`, no pack kernel */
     batch_plan plan;
     bsw_binparams bp;
+    bool rb_on = false;               /* the records' word offsets are still relative: bsw_rebase_kernel runs behind their DMA */
+    bsw_rebase rb{};
 };
 
 struct gate_turn {                    /* this chunk's place in its device's input-DMA order */

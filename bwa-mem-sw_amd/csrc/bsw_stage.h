@@ -54,6 +54,8 @@ hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_raw
 hipError_t launch_wire_pack(const uint32_t *wire, const bsw_dtask *tasks, const bsw_wireoff *woffs, uint32_t n, uint64_t *seq, hipStream_t s);
 /* the group's 16 KiB result batches, written on the device: wout[woffs[t].out_word .. + 4] = R0..R4 of task t, the rest zero */
 hipError_t launch_wire_results(const bsw_result *out, const bsw_wireoff *woffs, uint32_t n, uint32_t *wout, size_t wout_words, hipStream_t s);
+/* word offsets of tasks[0..n) made absolute (bsw_rebase in bsw_device.h) */
+hipError_t launch_rebase(bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, const bsw_rebase &rb, hipStream_t s);
 int global_class_count();
 int global_class_cols(int cls);
 hipError_t launch_global(int cls, const bsw_dparams &P, const uint64_t *seq, const bsw_gdtask *tasks, const uint32_t *order, uint32_t n,

@@ -429,7 +429,31 @@ __global__ __launch_bounds__(256) void bsw_wire_results_kernel(const bsw_result 
     R[4] = b.w;
 }
 
+/* ---- word offsets made absolute (the host's pass over a chunk runs on several threads, each counting from 0) ---- */
+__global__ __launch_bounds__(256) void bsw_rebase_kernel(bsw_dtask *__restrict__ tasks, const bsw_rawoff *__restrict__ roff, const uint32_t n, const bsw_rebase rb)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t *T = (uint32_t *)&tasks[i];                       /* lq_off, lt_off, rq_off, rt_off are its first four words */
+    if (rb.use_ro) {
+        const bsw_rawoff R = roff[i];
+        T[0] = R.lq + rb.delta; T[1] = R.lt + rb.delta; T[2] = R.rq + rb.delta; T[3] = R.rt + rb.delta;
+    } else {
+        uint32_t k = i / rb.per;
+        if (k >= rb.nr) k = rb.nr - 1u;
+        const uint32_t b = rb.base[k];
+        T[0] += b; T[1] += b; T[2] += b; T[3] += b;
+    }
+}
+
 /* ---- launchers ---- */
+hipError_t launch_rebase(bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t n, const bsw_rebase &rb, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(bsw_rebase_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, tasks, roff, n, rb);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack(const uint8_t *raw, const bsw_dtask *tasks, const bsw_rawoff *roff, uint32_t bias, uint32_t n, int rev_left,
                        const uint8_t *pac, int64_t l_pac, const bsw_refx *refx, uint64_t *seq, uint8_t *nflag, hipStream_t s)
 {

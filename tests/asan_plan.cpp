@@ -25,6 +25,7 @@ bool lane_class_finishes(int, const bsw_dparams &, int) { return true; }
 hipError_t launch_finalize(const bsw_dparams &, const bsw_dtask *, const uint32_t *, uint32_t, bsw_result *, uint32_t *, uint32_t *, bsw_pair *, hipStream_t) { return hipSuccess; }
 hipError_t launch_pairs_from_results(const uint32_t *, uint32_t, const uint32_t *, const bsw_result *, bsw_pair *, hipStream_t) { return hipSuccess; }
 hipError_t launch_pack(const uint8_t *, const bsw_dtask *, const bsw_rawoff *, uint32_t, uint32_t, int, const uint8_t *, int64_t, const bsw_refx *, uint64_t *, uint8_t *, hipStream_t) { return hipSuccess; }
+hipError_t launch_rebase(bsw_dtask *, const bsw_rawoff *, uint32_t, const bsw_rebase &, hipStream_t) { return hipSuccess; }
 hipError_t launch_wire_pack(const uint32_t *, const bsw_dtask *, const bsw_wireoff *, uint32_t, uint64_t *, hipStream_t) { return hipSuccess; }
 hipError_t launch_wire_results(const bsw_result *, const bsw_wireoff *, uint32_t, uint32_t *, size_t, hipStream_t) { return hipSuccess; }
 hipError_t launch_bin(const bsw_binparams &, const uint64_t *, const uint8_t *, const bsw_dtask *, uint32_t, uint32_t *, uint64_t *, uint32_t *, hipStream_t) { return hipSuccess; }
