@@ -142,18 +142,19 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     int rc = fill_binparams(e, p, kern, ci.bp);
     if (rc) return rc;
     bsw_binparams &bp = ci.bp;
-    /* H5/H6 per query length, for every length up front (two integer divisions each: per seed they were most of this pass) */
-    std::vector<uint16_t> gl5((size_t)BSW_MAX_QLEN + 1), gl3((size_t)BSW_MAX_QLEN + 1);
     /* class of a seed / a side by query length, looked up instead of searched per seed (the searches' data-dependent branches
-     * were a fifth of this pass) */
-    std::vector<int8_t> wcls((size_t)BSW_MAX_QLEN + 1), lcls8((size_t)BSW_MAX_QLEN + 1), lcls16((size_t)BSW_MAX_QLEN + 1);
-    for (int q = 0; q <= BSW_MAX_QLEN; ++q) {
-        gl5[(size_t)q] = (uint16_t)gap_limit(p, mx, q, p->pen_clip5);
-        gl3[(size_t)q] = (uint16_t)gap_limit(p, mx, q, p->pen_clip3);
-        wcls[(size_t)q] = (int8_t)bsw_wave_class_of(&bp, q);
-        lcls8[(size_t)q] = (int8_t)bsw_side_lane_class(&bp, 8, q);
-        lcls16[(size_t)q] = (int8_t)bsw_side_lane_class(&bp, 16, q);
-    }
+     * were a fifth of this pass) — for chunks that repay the table, and for the lengths nearly every query has */
+    constexpr int QTAB = 1024;
+    const bool use_tab = n >= 4096;
+    int8_t wcls[QTAB], lcls8[QTAB], lcls16[QTAB];
+    if (use_tab)
+        for (int q = 0; q < QTAB; ++q) {
+            wcls[q] = (int8_t)bsw_wave_class_of(&bp, q);
+            lcls8[q] = (int8_t)bsw_side_lane_class(&bp, 8, q);
+            lcls16[q] = (int8_t)bsw_side_lane_class(&bp, 16, q);
+        }
+    const auto wave_cls = [&](int q) { return use_tab && q < QTAB ? (int)wcls[q] : bsw_wave_class_of(&bp, q); };
+    const auto lane_cls = [&](int bits, int q) { return use_tab && q < QTAB ? (int)(bits == 8 ? lcls8[q] : lcls16[q]) : bsw_side_lane_class(&bp, bits, q); };
     /* THE PASS IS WALKED BY `threads` THREADS SIDE BY SIDE (round 6).  At 22 - 40 ns per seed it was what bounded every
      * PCIe-inclusive leg of bench.py: four slot threads = 100 - 140 M seeds/s of host-pass capacity against 240 M the GPU
      * takes (profiles/r6/e2e_host_pass.txt).  The seeds are cut into ranges; a first, cheap walk sizes every range (words,
@@ -183,6 +184,14 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         const size_t i0 = std::min(n, per * (size_t)k), i1 = std::min(n, i0 + per);
         uint64_t acc = 0, accb = 0;
         const uint8_t *lo = (const uint8_t *)UINTPTR_MAX, *hi = nullptr;
+        /* H5/H6 per query length, computed once per length and range (two integer divisions each: per seed they were most of
+         * this pass) */
+        std::vector<uint16_t> gl5((size_t)BSW_MAX_QLEN + 1, 0), gl3((size_t)BSW_MAX_QLEN + 1, 0);
+        const auto glim = [&](std::vector<uint16_t> &tab, int qlen, int clip) -> uint16_t {
+            uint16_t &v = tab[(size_t)qlen];
+            if (!v) v = (uint16_t)gap_limit(p, mx, qlen, clip);       /* >= 1: zero means not computed yet */
+            return v;
+        };
         auto span = [&](const uint8_t *sq, int len) {
             if (len > 0) { if (sq < lo) lo = sq; if (sq + len > hi) hi = sq + len; }
         };
@@ -250,14 +259,14 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         d.lqlen = (uint16_t)t.lqlen; d.rqlen = (uint16_t)t.rqlen;
         d.ltlen = (uint16_t)t.ltlen; d.rtlen = (uint16_t)t.rtlen;
         /* H5/H6: host-supplied band limits win over the library's formula (proc_element.v:925,933) */
-        d.wlim_l = (uint16_t)(t.wlim_l > 0 ? std::min(t.wlim_l, 65535) : gl5[(size_t)t.lqlen]);
-        d.wlim_r = (uint16_t)(t.wlim_r > 0 ? std::min(t.wlim_r, 65535) : gl3[(size_t)t.rqlen]);
+        d.wlim_l = (uint16_t)(t.wlim_l > 0 ? std::min(t.wlim_l, 65535) : glim(gl5, t.lqlen, p->pen_clip5));
+        d.wlim_r = (uint16_t)(t.wlim_r > 0 ? std::min(t.wlim_r, 65535) : glim(gl3, t.rqlen, p->pen_clip3));
         d.h0 = t.h0; d.init_score = t.init_score; d.qbeg = t.qbeg; d.tag = t.tag;
         dt[i] = d;
         ro[i] = r;
         /* class counts (the device sorts with the same functions) */
         const int qm = t.lqlen > t.rqlen ? t.lqlen : t.rqlen;
-        const int wc = wcls[(size_t)qm];
+        const int wc = wave_cls(qm);
         if (wc < 0) return bad(fail(el, BSW_E_LIMIT, "task %zu: no kernel class", i + idx0));
         ++A.cw_all[wc];
         const int bits = bsw_seed_lane_bits(&bp, t.lqlen, t.rqlen, t.h0);
@@ -267,7 +276,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
             if (bits == 16) { ++A.n16; ++A.cw16[wc]; }
             int lc = -1;
             if (t.lqlen) {
-                const int c = lc = bits == 8 ? lcls8[(size_t)t.lqlen] : lcls16[(size_t)t.lqlen];
+                const int c = lc = lane_cls(bits, t.lqlen);
                 if (c < 0) return bad(fail(el, BSW_E_LIMIT, "task %zu: no lane class", i + idx0));
                 ++A.cl[c];
                 A.lane_work[c] += (uint64_t)t.lqlen;
@@ -275,7 +284,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
                 A.h0_lo = std::min(A.h0_lo, t.h0); A.h0_hi = std::max(A.h0_hi, t.h0);
             }
             if (t.rqlen) {
-                const int c = bits == 8 ? lcls8[(size_t)t.rqlen] : lcls16[(size_t)t.rqlen];
+                const int c = lane_cls(bits, t.rqlen);
                 if (c < 0) return bad(fail(el, BSW_E_LIMIT, "task %zu: no lane class", i + idx0));
                 ++A.cr[c];
                 A.lane_work[c] += (uint64_t)t.rqlen;

@@ -105,7 +105,7 @@ extern "C" int bsw_global_batch(bsw_ctx *ctx, const bsw_params *p, const bsw_gta
     for (size_t i = 0; i < n; ++i) {
         const bsw_gtask &t = tasks[i];
         if (t.qlen < 0 || t.tlen < 0 || t.w < 0) return fail(e, BSW_E_INVAL, "global task %zu: negative length or band", i);
-        if (t.qlen > BSW_MAX_QLEN || t.tlen > BSW_MAX_TLEN || t.w > BSW_MAX_TLEN) return fail(e, BSW_E_LIMIT, "global task %zu: beyond BSW_MAX_QLEN/BSW_MAX_TLEN", i);
+        if (t.qlen > BSW_GLOBAL_MAX_QLEN || t.tlen > BSW_MAX_TLEN || t.w > BSW_MAX_TLEN) return fail(e, BSW_E_LIMIT, "global task %zu: beyond BSW_GLOBAL_MAX_QLEN/BSW_MAX_TLEN", i);
         if ((t.qlen && !t.query) || (t.tlen && !t.target)) return fail(e, BSW_E_INVAL, "global task %zu: NULL sequence pointer", i);
     }
     HIPCHK(e, hipSetDevice(ctx->device0()));

@@ -303,7 +303,11 @@ __global__ __launch_bounds__(256) void bsw_wave_kernel(const bsw_dparams P, cons
 hipError_t launch_quad(int cols, int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
                        const uint32_t *order, uint32_t n, const uint32_t *n_dev, uint32_t *next_slot, bsw_result *out, hipStream_t s);
 
-static const int kWaveClasses[] = {1, 2, 3, 4, 8, 16};
+/* columns per lane of the register kernels (64 .. 1 024 columns), then the two LDS-row classes of bsw_long_kernel.hip (2 048 and
+ * 8 192 columns: queries up to BSW_MAX_QLEN = 8 191) */
+static const int kWaveClasses[] = {1, 2, 3, 4, 8, 16, 32, 128};
+hipError_t launch_long(int cols, int variant, const bsw_dparams &P, const uint64_t *seq, const bsw_dtask *tasks,
+                       const uint32_t *order, uint32_t n, const uint32_t *n_dev, bsw_result *out, hipStream_t s);
 
 int wave_class_count() { return (int)(sizeof(kWaveClasses) / sizeof(kWaveClasses[0])); }
 int wave_class_cols(int cls) { return kWaveClasses[cls] * 64; }
@@ -337,6 +341,7 @@ hipError_t launch_wave(int cls, int variant, const bsw_dparams &P, const uint64_
      * up to 256 columns through it whatever the size (tests, measurements), BSW_QUAD=0 none. */
     static const int quad_mode = getenv("BSW_QUAD") ? atoi(getenv("BSW_QUAD")) : -1;
     const int cols = kWaveClasses[cls] * 64;
+    if (cols > 1024) return launch_long(cols, variant, P, seq, tasks, order, n, n_dev, out, s);
     /* (round 5 measured a third general kernel — one wavefront per seed whose lanes FOLLOW the live band, the eh[] row in LDS:
      * tools/experiments/bsw_band_kernel.hip, bit-exact, 95 VALU lane-instructions per cell against 129 here — at 6.49 ms per
      * 131 072 seeds of 131 x 257 against 7.00 here and 4.57 for the four-seed kernel, slower on PE mixed seeds and on a lone

@@ -51,7 +51,9 @@ extern "C" {
 #define BSW_E_BUSY       (-6)  /* BSW_MAX_INFLIGHT submits in flight already, or a synchronous call while one is */
 
 /* ---- device limits ------------------------------------------------------- */
-#define BSW_MAX_QLEN   1023    /* query side length per extension                 */
+#define BSW_MAX_QLEN   8191    /* query side length per extension (ksw_extend2 and the batch API; up to 1 023 in registers,
+                                  beyond that the eh[] row lives in LDS: bsw_long_kernel.hip)                          */
+#define BSW_GLOBAL_MAX_QLEN 1023 /* ksw_global2 / bsw_global_batch                 */
 #define BSW_MAX_TLEN   65535   /* target side length per extension                */
 #define BSW_MAX_SCORE  (1 << 20) /* h0 + qlen*max(mat) must stay below this       */
 
@@ -348,7 +350,7 @@ void     bsw_free_batch(bsw_ctx *ctx, bsw_dev_batch *b);
  * built on the host with the device's rules (lane sides: queries with an N first, each part longest first, left
  * sides of one length by h0 bucket — 8 buckets over the chunk's h0 range; inside one bin the device's order is arbitrary);
  * seg[] receives BSW_PLAN_SEGS+1 offsets into order[]:
- * segments 0..7 = wave-per-task classes (64,128,192,256,512,1024 columns, then 2 unused), 8 = all lane seeds,
+ * segments 0..7 = wave-per-task classes (64,128,192,256,512,1024,2048,8192 columns), 8 = all lane seeds,
  * 9..16 = lane left sides per lane class, 17..24 = lane right sides per lane class, 25 = redo list space.
  * kernel = BSW_KERNEL_*.  Returns the number of sequence words the batch needs, or <0. ---- */
 #define BSW_PLAN_SEGS 26

@@ -58,12 +58,14 @@ def test_250bp_w500(host, oracle, ctx):
     assert_same(got, want, tasks)
 
 
-# every kernel class boundary: columns per lane C in {1,2,3,4,8,16} <=> qlen+1 <= 64*C
-@pytest.mark.parametrize("qlen", [1, 2, 62, 63, 64, 126, 127, 128, 190, 191, 192, 254, 255, 256, 510, 511, 512, 1022, 1023])
+# every kernel class boundary: columns per lane C in {1,2,3,4,8,16} <=> qlen+1 <= 64*C of the register kernels, then the two
+# LDS-row classes of bsw_long_kernel.hip (2 048 and 8 192 columns: BSW_MAX_QLEN = 8 191)
+@pytest.mark.parametrize("qlen", [1, 2, 62, 63, 64, 126, 127, 128, 190, 191, 192, 254, 255, 256, 510, 511, 512, 1022, 1023,
+                                  1024, 1500, 2047, 2048, 4096, 8191])
 def test_class_boundaries(host, oracle, ctx, qlen):
     rng = np.random.default_rng(qlen)
     seeds = []
-    for k in range(24):
+    for k in range(24 if qlen < 1024 else 6):
         tl = int(qlen * 1.3) + 5
         t = rng.integers(0, 4, tl).astype(np.uint8)
         q = _gen.mutate(rng, t, qlen, 0.03, 0.01 if k % 2 else 0.0)
@@ -260,7 +262,7 @@ def test_reference_wire_format_end_to_end(host, oracle, ctx):
 
 def test_limits_are_errors_not_fallbacks(host, ctx):
     p = host.default_params()
-    t, a = host.make_tasks([dict(rq=np.zeros(1024, np.uint8), rt=np.zeros(10, np.uint8), h0=5)])
+    t, a = host.make_tasks([dict(rq=np.zeros(8192, np.uint8), rt=np.zeros(10, np.uint8), h0=5)])       # BSW_MAX_QLEN = 8191
     with pytest.raises(host.BswError) as ei:
         ctx.extend_pairs(p, t)
     assert ei.value.code == -3
@@ -334,3 +336,43 @@ def test_extend_batch_large_goes_through_lane_bins(host, oracle, ctx):
         want = oracle.ext_batch(p, et, nthreads=8)
         for f in EXTF:
             assert (got[f] == want[f]).all(), f
+
+
+def test_long_queries_through_every_entry_point(host, oracle, ctx):
+    """Queries beyond the register kernels' 1 023 bases (bwa's ksw_extend2 has no limit): a mixed batch of
+    short and long seeds through bsw_submit, a resident batch, the packed path and the drop-in scalar ksw_extend2; one base
+    more than BSW_MAX_QLEN is BSW_E_LIMIT, never a fallback."""
+    rng = np.random.default_rng(8191)
+    seeds = []
+    for k, qlen in enumerate([30, 1100, 131, 3000, 2047, 75, 5000, 1024, 8191, 400]):
+        tl = int(qlen * 1.2) + 20
+        t = rng.integers(0, 4, tl).astype(np.uint8)
+        q = _gen.mutate(rng, t, qlen, 0.04, 0.005)
+        s = {"rq": q, "rt": t, "h0": int(rng.integers(19, 60))}
+        if k % 2:
+            lq = _gen.mutate(rng, t[::-1].copy(), max(qlen // 3, 1), 0.03, 0.0)
+            s["lq"], s["lt"] = lq, t[::-1].copy()
+        seeds.append(s)
+    tasks, arena = host.make_tasks(seeds)
+    for variant, w in ((0, 100), (1, 37), (0, 2000)):
+        p = host.default_params(variant=variant, w=w)
+        want = oracle.pair_batch(p, tasks, nthreads=4)
+        assert_same(ctx.extend_pairs(p, tasks), want, tasks)
+        b = ctx.upload(p, tasks); ctx.run(b); got = ctx.download(b); b.free()
+        assert_same(got, want, tasks)
+        pt, pa = host.pack_tasks(tasks)
+        assert_same(ctx.extend_pairs_packed(p, pt), want, tasks)
+    # the drop-in scalar entry point on a 3 000-base query
+    q, t = host.task_seq(tasks, 3, "rquery", "rqlen"), host.task_seq(tasks, 3, "rtarget", "rtlen")
+    m = host.bwa_matrix()
+    outs = [C.c_int(0) for _ in range(5)]
+    r = host.lib().ksw_extend2(len(q), q.ctypes.data, len(t), t.ctypes.data, 5, m.ctypes.data, 6, 1, 6, 1, 100, 5, 100, 40,
+                               *[C.byref(o) for o in outs])
+    w = oracle.extend2(q, t, m, 6, 1, 6, 1, 100, 5, 100, 40)
+    assert (r, outs[0].value, outs[1].value, outs[2].value, outs[3].value, outs[4].value) == (w["score"], w["qle"], w["tle"], w["gtle"], w["gscore"], w["max_off"])
+    # one base too many
+    big = rng.integers(0, 4, 8192).astype(np.uint8)
+    bad, _a = host.make_tasks([{"rq": big, "rt": big, "h0": 20}])
+    with pytest.raises(host.BswError) as ei:
+        ctx.extend_pairs(host.default_params(), bad)
+    assert ei.value.code == -3
