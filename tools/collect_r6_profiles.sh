@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p profiles/r6
-for w in head single w250 mixed1m c72 wave quad; do
+for w in head single w250 mixed1m group c72 wave quad; do
     d=gpurun_out/r6prof/$w
     [ -d $d ] || continue
     ks=$(ls -t $d/trace/*/*_kernel_stats.csv | head -1)
@@ -16,3 +16,4 @@ python3 tools/make_pmc_latest.py gpurun_out/r6prof/head/summary.json 150bp_w100_
 python3 tools/make_pmc_latest.py gpurun_out/r6prof/single/summary.json 150bp_w100_single_bin 1000000 $(cells gpurun_out/r6prof/single/bench_trace.json)
 python3 tools/make_pmc_latest.py gpurun_out/r6prof/w250/summary.json 250bp_w500 1000000 $(cells gpurun_out/r6prof/w250/bench_trace.json)
 python3 tools/make_pmc_latest.py gpurun_out/r6prof/mixed1m/summary.json 150bp_w100_mixed_bins 1000000 $(cells gpurun_out/r6prof/mixed1m/bench_trace.json)
+[ -d gpurun_out/r6prof/group ] && python3 tools/make_pmc_latest.py gpurun_out/r6prof/group/summary.json 150bp_w100_mixed_bins 49152 $(cells gpurun_out/r6prof/group/bench_trace.json) 4 150bp_w100_mixed_bins@49152

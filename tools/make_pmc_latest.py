@@ -14,7 +14,7 @@ if d.endswith(".json"):                  # a kept tools/pmc_summary.py output in
     allk = json.load(open(d))
 else:
     allk = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), d, "bsw"]))
-step = {k: v for k, v in allk.items() if any(x in k for x in ("lane2_kernel", "lane2l_kernel", "lane_kernel", "pair_finalize", "wave_kernel", "quad_kernel"))}
+step = {k: v for k, v in allk.items() if any(x in k for x in ("lane2_kernel", "lane2l_kernel", "lane2g_kernel", "lane_kernel", "pair_finalize", "wave_kernel", "quad_kernel", "long_kernel"))}
 per_step = lambda v: max(1.0, v.get("calls", steps) / float(steps))
 fetch = sum(v.get("FETCH_SIZE", 0) * per_step(v) for v in step.values())
 write = sum(v.get("WRITE_SIZE", 0) * per_step(v) for v in step.values())

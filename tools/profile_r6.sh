@@ -18,6 +18,9 @@ TRAFFIC=1 tools/profile_quick.sh r6prof/w250 $BENCH_EXTRA --workload 250bp_w500 
 echo w250 done
 TRAFFIC=1 tools/profile_quick.sh r6prof/mixed1m $BENCH_EXTRA --workload 150bp_w100_mixed_bins --tasks 1000000 > /dev/null
 echo mixed1m done
+# the kernel between the general ones and the lane kernels: 49 152 PE seeds take bsw_lane2g_kernel under BSW_KERNEL_AUTO
+tools/profile_quick.sh r6prof/group $BENCH_EXTRA --workload 150bp_w100_mixed_bins --tasks 49152 > /dev/null
+echo group done
 if [ -z "$QUICK" ]; then
 tools/profile_quick.sh r6prof/c72 $BENCH_EXTRA --workload 150bp_w100_single_bin --tasks 1000000 --spec seed_len_min=79 --spec seed_len_max=79 > /dev/null
 BSW_QUAD=0 tools/profile_quick.sh r6prof/wave $BENCH_EXTRA --workload 150bp_w100_single_bin --kernel 1 --tasks 131072 > /dev/null
