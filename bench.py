@@ -398,6 +398,28 @@ def generate_seeds(host, spec, chunk_ids, sizes, seed_of, threads, arena=None, t
     with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
         for f in [pool.submit(one, k) for k in range(len(sizes))]:
             f.result()
+    # The chunks were generated side by side into slots of their arena BOUND (3.2x what a PE chunk uses): close the gaps, so that
+    # the arena is as compact as one a host would fill sequentially — bsw_submit DMAs a chunk's span as it lies only when the
+    # span holds little besides the chunk's sequences (<= 2x), and gathers through pinned staging otherwise.
+    base = arena.u8.ctypes.data
+    run = 0
+    for k in range(len(sizes)):
+        a, b = int(starts[k]), int(starts[k]) + sizes[k]
+        t = tg[a:b]
+        end = 0
+        for pf, lf in (("lquery", "lqlen"), ("ltarget", "ltlen"), ("rquery", "rqlen"), ("rtarget", "rtlen")):
+            m = t[pf] != 0
+            if m.any():
+                end = max(end, int((t[pf][m] + t[lf][m].astype(np.uint64)).max()))
+        lo = base + int(offs[k])
+        used = max(end - lo, 0)
+        shift = int(offs[k]) - run
+        if shift and used:
+            arena.u8[run:run + used] = arena.u8[int(offs[k]):int(offs[k]) + used]          # (slots never overlap what is already packed: run <= offs[k])
+            for pf in ("lquery", "ltarget", "rquery", "rtarget"):
+                m = t[pf] != 0
+                t[pf][m] -= np.uint64(shift)
+        run += (used + 63) & ~63
     return tg, arena
 
 
