@@ -862,6 +862,14 @@ def main():
                 "kernel_ms_avg": round(dp_avg, 4), "kernel_ms_is": "DP part of one step on rank 0: all DP launches of its %d resident batches (HIP events)" % nb,
                 "note": "integer max/add DP at ~0.02 B/cell: VALU issue binds, not HBM and not MFMA; see roofline_hbm",
             },
+            "roofline_staging": (None if tasks is None else (lambda raw, seqb, nn, orderb: {
+                "bound": "hbm", "kernels": "bsw_pack_kernel + bsw_bin_count / scan / scatter (the pack + bin part of a step)",
+                "achieved": round((raw + seqb + nn * (44 + 16 + 1) + nn * (44 + 1 + 8) + nn * 8 + orderb) / (st_avg * 1e-3) / 1e9, 1) if st_avg else None,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round((raw + seqb + nn * (44 + 16 + 1) + nn * (44 + 1 + 8) + nn * 8 + orderb) / (st_avg * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if st_avg else None,
+                "algorithmic_bytes_per_step": raw + seqb + nn * (44 + 16 + 1) + nn * (44 + 1 + 8) + nn * 8 + orderb,
+                "bytes_are": "pack: raw bases in, packed words out, task + offset records in, N flags out; bins: task records + flags in, keys out and in, launch lists out",
+                "ms_per_step": round(st_avg, 4)})(harena_used(tasks), info["in_bytes"] - n_local * 44 - 0, n_local, 0)),
             "roofline_hbm": {
                 "bound": "hbm", "achieved": round(alg_bytes / (dp_avg * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": round(alg_bytes / (dp_avg * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),

@@ -294,3 +294,21 @@ def test_default_config_leaves_the_watchdog_to_the_environment(host, monkeypatch
     monkeypatch.setenv("BSW_TIMEOUT_MS", "5000")
     assert host.lib().bsw_effective_timeout_ms(cfg.ctypes.data) == 250          # explicit wins
     assert host.lib().bsw_abi_version() == 6
+
+
+def test_auto_policy_by_work(host):
+    """BSW_KERNEL_AUTO decides by the WORK per launched side (sum of query lengths): below 1.5 M bases the general kernels,
+    up to 5 M bsw_lane2g_kernel (lane lists without the 16-bit seeds), above that the lane kernels (plan only: no GPU)."""
+    p = host.default_params()
+    t, a = host.synth_tasks(60000, seed=5)                               # 131-base right sides
+    lane = lambda n: (lambda seg: int(seg[9] - seg[8]))(host.plan_batch(p, t[:n], kernel=host.KERNEL_AUTO)[1])
+    assert lane(9000) == 0                                               # 1.18 M bases: general kernels
+    assert lane(13000) == 13000                                          # 1.70 M: group kernel
+    assert lane(45000) == 45000                                          # 5.9 M: lane kernels
+    t2 = t[:20000].copy()
+    t2["h0"][::10] = 300                                                 # 16-bit seeds in a group-sized chunk go to the wave classes
+    seg = host.plan_batch(p, t2, kernel=host.KERNEL_AUTO)[1]
+    assert int(seg[9] - seg[8]) == 18000 and int(seg[8] - seg[0]) == 2000
+    big = t.copy(); big["h0"][::10] = 300
+    seg = host.plan_batch(p, big, kernel=host.KERNEL_AUTO)[1]
+    assert int(seg[9] - seg[8]) == 60000                                 # lane-kernel-sized: the 16-bit class keeps them

@@ -340,3 +340,26 @@ def test_launch_chain_cannot_wedge(setting):
         assert int(m.group(1)) == 6, out.stdout          # two resident runs of a four-link chain: three waits each, all expired
                                                          # (extend_pairs streams through the slot pipeline, which does not chain)
     assert float(m.group(2)) < 30.0, out.stdout          # and a wait that expires costs 20 ms, not a watchdog
+
+
+def test_mid_sized_chunk_runs_the_group_kernel(host, oracle):
+    """Between the general kernels and the lane kernels: a resident batch whose launched sides hold 1.5 M - 5 M query bases runs
+    bsw_lane2g_kernel (a seed pair per group of eight lanes) under BSW_KERNEL_AUTO.  45 000 PE seeds, some of them outside the
+    8-bit score range (they leave the lane lists for the general kernel in this mode), both variants, separate gap penalties."""
+    n = 45_000
+    tasks, arena = host.synth_tasks(n, seed=77, seed_len_min=19, seed_len_max=60, seed_at_start=0, sub_rate=0.02, indel_rate=0.01,
+                                    junk_frac=0.1, n_rate=0.002)
+    tasks["h0"][::53] = 300                                              # 16-bit seeds
+    for variant, gaps in ((0, {}), (1, dict(o_del=5, e_del=2, o_ins=7, e_ins=1))):
+        p = host.default_params(variant=variant, **gaps)
+        order, seg, words = host.plan_batch(p, tasks, kernel=host.KERNEL_AUTO)
+        n16 = int((tasks["h0"] == 300).sum())
+        assert seg[9] - seg[8] == n - n16 - int(((tasks["lqlen"] == 0) & (tasks["rqlen"] == 0) & (tasks["h0"] != 300)).sum())      # lane seeds = the 8-bit ones
+        assert seg[8] - seg[0] >= n16                                     # the 16-bit ones sit in the wave classes
+        want = oracle.pair_batch(p, tasks, nthreads=8)
+        with host.BswContext(device=0) as c:
+            b = c.upload(p, tasks); c.run(b); got = c.download(b)
+            assert b.info()["launches"] >= 3                              # left + right group launches, the redo launch (+ wave classes)
+            b.free()
+            assert_same(got, want, tasks)
+            assert_same(c.extend_pairs(p, tasks), want, tasks)            # the same through a submit (one chunk)
