@@ -311,7 +311,10 @@ extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
      * hardware queue (profiles/r5/wire_format_timeline.txt; r3/e2e_hw_queues.txt).  A shallow queue keeps groups of 16 on the
      * general kernel, which finishes 13 k seeds sooner than two lane launches.  BSW_REFBATCH_GROUP overrides (measurements). */
     static const size_t grp_tune = getenv("BSW_REFBATCH_GROUP") ? (size_t)std::max(1, atoi(getenv("BSW_REFBATCH_GROUP"))) : 0;
-    const size_t grp_env = grp_tune ? grp_tune : (nq >= 96 ? std::max<size_t>(REFBATCH_GROUP_DEEP, (nq + 1) / 2) : (size_t)REFBATCH_GROUP);
+    /* (round 6) a queue of 40 - 95 batches runs as groups of 48 = 39 k seeds: that is bsw_lane2g_kernel's range (a seed pair per
+     * group of eight lanes, 1.1 ms per group where two lane launches take 2.0 and four 16-batch groups on the general kernel
+     * 2.7): 64 queued batches 19.2 -> 26.2 M seeds/s, 48: 20.9 -> 22.0 (profiles/r6/wire_format_group_sweep.txt) */
+    const size_t grp_env = grp_tune ? grp_tune : (nq >= 96 ? std::max<size_t>(REFBATCH_GROUP_DEEP, (nq + 1) / 2) : nq >= 40 ? (size_t)48 : (size_t)REFBATCH_GROUP);
     const size_t NS = std::max<size_t>(1, std::min<size_t>(REFBATCH_SLOTS, dev.slots.size()));
     const size_t slot_of[REFBATCH_SLOTS] = {0, 1, 2, 3};
     struct flight { bool active = false, issued = false, direct_out = false; size_t q0 = 0, q1 = 0; } fl[REFBATCH_SLOTS];
