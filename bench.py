@@ -301,6 +301,21 @@ def verify_rank_placement(bdf, orig_affinity, node_peers, sys_root="/sys"):
     return node, True, mine
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the cgroup grants this process (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited / unknown"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def kernel_source_hash():
     """sha256 (16 hex digits) over the kernel and batch-manager sources the library is built from: identifies the code a
     counter file was collected on (tools/make_pmc_latest.py stores it, pmc_summary() compares it)."""
@@ -1023,7 +1038,16 @@ def cpu_legs(host, params, tasks, res, args):
                    "impl": "scalar C oracle (bwa's ksw_extend is scalar code too)", "sample_seeds": ns,
                    "runs_s": "/".join("%.2f" % r for r in runs), "single_thread_gcups": round(c1 / d1 / 1e9, 4)},
     }}
-    if avail > ncpu and not args.cpu_threads:
+    quota = cgroup_cpu_quota()
+    out["cpu_baseline"]["cgroup_cpu_quota_cpus"] = quota
+    if quota is not None and quota <= ncpu + 0.5:
+        # the box grants this process `quota` CPUs' worth of time (cgroup cpu.max) however many CPUs its affinity names: more threads
+        # than that are throttled, not added (tools/diag/cpu_scaling.py, profiles/r6/cpu_baseline_scaling.txt: 41.9 GCUPS on 16
+        # threads, 38 / 35 / 30 on 32 / 64 / 128 with nr_throttled counting up)
+        out["cpu_baseline"]["all_cores"] = {"value": out["cpu_baseline"]["value"], "unit": "GCUPS", "cores": ncpu, "kind": "port",
+                                            "note": "cgroup cpu.max grants %.4g CPUs of time (affinity names %d): the %d-thread figure IS this box's all-core figure; "
+                                                    "threads beyond the quota are throttled" % (quota, avail, ncpu)}
+    elif avail > ncpu and not args.cpu_threads:
         sall, aruns = avx(avail)
         out["cpu_baseline"]["all_cores"] = {"value": round(cells_of(sall) / float(np.median(aruns)) / 1e9, 4), "unit": "GCUPS", "cores": avail, "kind": "port",
                                             "impl": "the same AVX2 port on every CPU the process may use", "runs_s": "/".join("%.2f" % r for r in aruns),
