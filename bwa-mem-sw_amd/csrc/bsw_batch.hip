@@ -92,12 +92,17 @@ BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint
     if (!bp.lane_on) return false;
     const uint32_t n8 = n_lane - n16;
     const uint64_t work = std::max(work8_l, work8_r);
+    /* what the group kernel's launch holds: one side's seeds — or, for a chunk that fuse_group_lists will fuse, both sides of
+     * every seed (one wave lifetime for the pair: the general kernels lose from ~13 k PE seeds, profiles/r6/crossover_group.json) */
+    static const int fenv = getenv("BSW_GROUP_FUSE") ? atoi(getenv("BSW_GROUP_FUSE")) : -1;
+    const bool fusable = fenv != 0 && work8_l && work8_r && (fenv == 1 || n8 <= GROUP_FUSE_MAX);
+    const uint64_t work_g = fusable ? work8_l + work8_r : work;
     bool group = false;
     if (genv == 1) group = group_ok && n8 > 0 && kern != BSW_KERNEL_WAVE;
     else if (kern == BSW_KERNEL_AUTO) {
         const bool lane = genv == 0 || !group_ok ? lane_bins_pay(n_lane, cl, cr) : (work >= LANE_WORK_MIN || lane_bins_pay(n16, cl, cr));
         if (!lane) {
-            group = genv != 0 && group_ok && work >= GROUP_WORK_MIN;
+            group = genv != 0 && group_ok && work_g >= GROUP_WORK_MIN;
             if (!group) { bp.lane_on = 0; return false; }
         }
     }
@@ -109,6 +114,30 @@ BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint
     for (int c = 0; c < BSW_MAX_WAVE_CLASSES; ++c) cw[c] += cw16[c];
     n_lane -= n16;
     return true;
+}
+
+/* See bsw_internal.h.  A seed's two sides add up to about one read length whatever the split, so a wavefront that runs the left
+ * sides of its seeds and then their right sides lives about as long as ONE launch of the longest sides does, and the chunk
+ * takes one wave lifetime instead of two — what a chunk below ~3 waves per SIMD (GROUP_FUSE_MAX seeds) is bound by.  Larger
+ * chunks are bound by throughput, and there a right-side list sorted by its own length packs better than the left list's
+ * order.  BSW_GROUP_FUSE=0 / 1: never / whenever the chunk has both kinds of sides (measurements, tests). */
+BSW_LOCAL int fuse_group_lists(bsw_binparams &bp, uint32_t n8, uint32_t *cl, uint32_t *cr)
+{
+    static const int fenv = getenv("BSW_GROUP_FUSE") ? atoi(getenv("BSW_GROUP_FUSE")) : -1;
+    if (fenv == 0 || (fenv != 1 && n8 > GROUP_FUSE_MAX)) return -1;
+    int cmax = -1;
+    uint32_t nl = 0, nr = 0;
+    for (int c = 0; c < bp.n_lane && c < BSW_MAX_LANE_CLASSES; ++c) {
+        if (bp.lane_bits[c] != 8) continue;
+        if (cl[c] || cr[c]) cmax = c;
+        nl += cl[c]; nr += cr[c];
+    }
+    const int c0 = bsw_side_lane_class(&bp, 8, 0);
+    if (cmax < 0 || c0 < 0 || !nl || !nr || nl > n8 || bp.lane_cols[cmax] > 256) return -1;       /* (a one-sided chunk has nothing to fuse) */
+    cl[c0] += n8 - nl;                                   /* the seeds without a left side: query length 0 */
+    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) cr[c] = 0;
+    bp.fused = 1;
+    return cmax;
 }
 
 /* tasks[0..n) -> dt[0..n) (device task records), ro[0..n) (gather layout of the raw bytes), class counts -> plan */
@@ -335,6 +364,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         memset(cr, 0, sizeof(cr));
         n_lane = 0;
     }
+    const int fused_cls = group && bp.lane_on ? fuse_group_lists(bp, n_lane, cl, cr) : -1;
     if (bp.lane_on && h0_hi >= h0_lo) bsw_set_h0_buckets(&bp, h0_lo, h0_hi);
     batch_plan &pl = ci.plan;
     pl = batch_plan();
@@ -350,7 +380,8 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     pl.redo_off = cur;
     pl.order_len = cur + n_lane;
     pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
-    pl.lane_group = group ? 1 : 0;
+    pl.lane_group = group ? (fused_cls >= 0 ? 2 : 1) : 0;
+    pl.fused_cls = fused_cls;
     memcpy(pl.dep, dep, sizeof(pl.dep));
     memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
     bp.lane_all_off = pl.lane_all_off;
@@ -629,7 +660,11 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
         bsw_result *d_out = J.d_out;
         bsw_pair *d_pair = J.d_pair;
         uint64_t *launches = J.launches;
-        if (!chain_pays) {
+        if (pl.lane_group == 2) {                                      /* both sides of every seed in one launch over all left lists */
+            const uint32_t off = pl.laneL_off[0], cnt = pl.laneL_off[BSW_MAX_LANE_CLASSES] - off;
+            HIPCHK(e, bsw::launch_lane(pl.fused_cls, variant, P, 2, d_seq, d_tasks, d_order + off, cnt, d_out, s, nullptr, nullptr, fin_of(j)));
+            if (launches) ++*launches;
+        } else if (!chain_pays) {
         const fork_t *fk1 = fk && fk->mode == 1 ? fk : nullptr;       /* (mode 2 without a chain that pays: plain launches on s) */
         /* The classes of a side side by side: the k-th non-empty class of a side (widest first: its waves run longest) goes
          * to stream k — the slot stream, then the auxiliary ones.  A right-side launch waits for exactly the left-side
@@ -791,8 +826,8 @@ extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, si
             const int bits = bsw_seed_lane_bits(&bp, T.lqlen, T.rqlen, T.h0);
             if (!bits) { k0 = BSW_BIN_WAVE0 + bsw_wave_class_of(&bp, std::max(T.lqlen, T.rqlen)); return; }
             k0 = BSW_BIN_LANEALL;
-            if (T.lqlen) k1 = BSW_BIN_L(bits == 16, has_n(tasks[i].lquery, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
-            if (T.rqlen) k2 = BSW_BIN_R(bits == 16, has_n(tasks[i].rquery, T.rqlen), T.rqlen);
+            if (T.lqlen || bp.fused) k1 = BSW_BIN_L(bits == 16, has_n(tasks[i].lquery, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
+            if (T.rqlen && !bp.fused) k2 = BSW_BIN_R(bits == 16, has_n(tasks[i].rquery, T.rqlen), T.rqlen);
         };
         for (size_t i = 0; i < n; ++i) {
             int k0, k1, k2;

@@ -106,6 +106,9 @@ typedef struct bsw_binparams {
     /* second sort key of the LEFT sides inside a query length: the seed's h0 in BSW_H0_BUCKETS buckets over the chunk's range
      * [hb_lo, ...], bucket = ((h0 - hb_lo) * hb_mul) >> 16 (hb_mul = 0: one bucket) */
     int32_t hb_lo, hb_mul;
+    /* 1: a mid-sized chunk whose two sides run in ONE launch (bsw_lane2g_kernel, side 2): every 8-bit lane seed is on the LEFT
+     * lists, by its left query length (0: it has no left side), and no right list is filled */
+    int32_t fused;
 } bsw_binparams;
 
 /* The lanes of a wave walk their rows in lockstep over the UNION of their [beg, end) ranges, and h0 sets how fast a seed's
@@ -163,7 +166,8 @@ typedef struct bsw_fin {
     bsw_pair *pairs;                           /* BSW_RESULT_PAIR: the dense 32-byte records; else NULL */
     int on;                                    /* 0: the lane kernels only store their side (bsw_pair_finalize follows) */
     int group;                                 /* 1: the chunk is mid-sized — its 8-bit lane launches run bsw_lane2g_kernel (a seed pair
-                                                  per group of eight lanes, 16 seeds per wavefront) instead of the 128-seed kernels */
+                                                  per group of eight lanes, 16 seeds per wavefront) instead of the 128-seed kernels;
+                                                  2: and both sides of a seed in one launch (bsw_binparams.fused) */
 } bsw_fin;
 
 #if defined(__HIPCC__) || defined(__HIP__)

@@ -102,8 +102,8 @@ __device__ __forceinline__ uint32_t nib_plane8(uint32_t w, int b)
 
 }  // namespace
 
-template <int NS, int WPS, bool VM, bool SYM>
-__global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams P, const int side,
+template <int NS, int WPS, bool VM, bool SYM, bool FUSED>
+__global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams P, const int side_arg,
                                                               const uint64_t *__restrict__ seq,
                                                               const bsw_dtask *__restrict__ tasks,
                                                               const uint32_t *__restrict__ order, const uint32_t n,
@@ -111,48 +111,60 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams 
 {
     using L = l2::lane2g<NS, VM, SYM>;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, grp = lane >> 3, g = lane & 7;
-    const uint32_t w16 = (blockIdx.x * 4u + (uint32_t)wv) * 16u;
+    const uint32_t w16s = (blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(wv)) * 16u;       /* the wavefront's first slot (uniform) */
 
+    int lsc[2] = {0, 0};                                /* (side == 2) the score after the left extension = the right side's h0 */
+
+    /* side == 2 (a mid-sized chunk of seeds with two sides each, bsw_fin.group == 2): the wavefront runs the LEFT sides of its 16
+     * seeds and then their RIGHT sides — a seed's two sides add up to about one read length whatever the split, so the wavefront
+     * lives about as long as one launch of the longest side did, and the chunk takes one such lifetime instead of two */
+    constexpr int side = FUSED ? 2 : 0;                 /* (the one-sided instantiation has no loop: its code is what it was) */
+    const int sd_first = FUSED ? 0 : side_arg, sd_last = FUSED ? 1 : side_arg;
+    for (int sd = sd_first; FUSED ? sd <= sd_last : sd == sd_first; ++sd) {
     typename L::state S;
     uint32_t mA[NS], mB[NS], WNs[NS], t_off[2], ti[2];
     int ntw[2];
-    bool valid[2];
+    bool valid[2], has[2];                              /* has: the seed exists and has this side (a list of one side holds only such seeds) */
     uint32_t nqs = 0;                                   /* bit s: some query of the wavefront has an N in stripe s */
     l2::sfor<2>([&](auto xi) {
         constexpr int x = decltype(xi)::value;
-        const uint32_t slot = w16 + (uint32_t)grp + 8u * x;
+        const uint32_t slot = l2::opaque_s(w16s) + (uint32_t)grp + 8u * x;         /* (worked out again per side: nothing but lsc is carried) */
         valid[x] = slot < n;
         ti[x] = valid[x] ? order[slot] : order[0];
         const bsw_dtask T = tasks[ti[x]];
         int qlen, tlen, wlim, h0;
         uint32_t q_off;
-        if (side == 0) {
+        if (sd == 0) {
             qlen = T.lqlen; tlen = T.ltlen; wlim = T.wlim_l; q_off = T.lq_off; t_off[x] = T.lt_off; h0 = T.h0;
         } else {
             qlen = T.rqlen; tlen = T.rtlen; wlim = T.wlim_r; q_off = T.rq_off; t_off[x] = T.rt_off;
-            h0 = T.lqlen > 0 ? out[ti[x]].left.score : T.h0;          /* h0 = score after the left ext (:1671) */
+            h0 = T.lqlen > 0 ? (side == 2 ? lsc[x] : out[ti[x]].left.score) : T.h0;          /* h0 = score after the left ext (:1671) */
         }
-        if (!valid[x]) tlen = 0;
+        has[x] = valid[x] && qlen > 0;
+        if (!has[x]) { tlen = 0; qlen = qlen > 0 ? qlen : 1; }
         ntw[x] = (tlen + 15) >> 4;
         l2::init_pair(S.p, x, qlen, tlen, h0, min(P.w, wlim));
         /* the lane's own columns of every stripe: 8 nibbles = half a packed word; per base the 8 match bits, and the N bits */
         l2::sfor<NS>([&](auto si) {
             constexpr int s = decltype(si)::value;
             const int wq = 4 * s + (g >> 1);
-            const uint64_t qw = (valid[x] && 16 * wq < qlen) ? seq[q_off + (uint32_t)wq] : 0ull;
+            const uint64_t qw = (has[x] && 16 * wq < qlen) ? seq[q_off + (uint32_t)wq] : 0ull;
             const uint32_t bits = (g & 1) ? (uint32_t)(qw >> 32) : (uint32_t)qw;
             const uint32_t p0 = nib_plane8(bits, 0), p1 = nib_plane8(bits, 1), p2 = nib_plane8(bits, 2);
             const uint32_t np2 = ~p2 & 0xffu;
             const uint32_t m0 = ~p0 & ~p1 & np2, m1 = p0 & ~p1 & np2, m2 = ~p0 & p1 & np2, m3 = p0 & p1 & np2;
             const uint32_t packed = (m0 & 0xffu) | ((m1 & 0xffu) << 8) | ((m2 & 0xffu) << 16) | ((m3 & 0xffu) << 24);
             if (x == 0) { mA[s] = packed; WNs[s] = p2; } else { mB[s] = packed; WNs[s] |= p2 << 16; }
-            if (__builtin_amdgcn_ballot_w64(valid[x] && p2 != 0) != 0) nqs |= 1u << s;
+            if (__builtin_amdgcn_ballot_w64(has[x] && p2 != 0) != 0) nqs |= 1u << s;
         });
     });
 
+    /* (the constants are worked out per side, behind the seeds' set-up as in the one-sided kernel: held across the side loop
+     * they cost 60 spilled registers, some of them inside the row loop) */
     l2::consts k;
-    k.a = P.mat[0]; k.pb = -P.mat[1]; k.pn = -P.mat[24];
-    k.o_del = P.o_del; k.e_del = P.e_del; k.oe_ins = P.o_ins + P.e_ins; k.e_ins = P.e_ins; k.zdrop = P.zdrop;
+    const auto again = [](int v) { return (int)l2::opaque_s((uint32_t)v); };      /* (an asm statement: not hoisted out of the side loop) */
+    k.a = again(P.mat[0]); k.pb = again(-P.mat[1]); k.pn = again(-P.mat[24]);
+    k.o_del = again(P.o_del); k.e_del = again(P.e_del); k.e_ins = again(P.e_ins); k.oe_ins = again(P.o_ins) + k.e_ins; k.zdrop = again(P.zdrop);
     l2::fill_packed_consts(k);
     const uint32_t E8 = l2::dup16(min(8 * k.e_ins, 255) << 8), E16 = l2::dup16(min(16 * k.e_ins, 255) << 8), E32 = l2::dup16(min(32 * k.e_ins, 255) << 8);
     L::init_row(S, k, g);
@@ -222,10 +234,14 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams 
         l2::row_tail2<SYM>(S.p, k, i, r.ACT, L::hfin_of(rk, hfin), mk2, Fnz, Lnz);      /* K7, K8 for both seeds at once */
     }
 
-    if (g != 0) return;                                           /* one lane of the group writes its two seeds */
+    l2::sfor<2>([&](auto xi) {                                   /* (every lane of the group holds the pair's state) */
+        constexpr int x = decltype(xi)::value;
+        if (has[x]) lsc[x] = l2::pair_result(S.p, x).mx;
+    });
+    if (g == 0)                                                   /* one lane of the group writes its two seeds */
     l2::sfor<2>([&](auto xi) {
         constexpr int x = decltype(xi)::value;
-        if (!valid[x]) return;
+        if (!has[x]) return;
         const l2::ext_out s = l2::pair_result(S.p, x);
         bsw_ext e;
         e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
@@ -234,16 +250,17 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams 
             /* the launch that computes a seed's LAST side finishes the seed: clip-vs-extend decision, band-retry test, the
              * whole record (or the redo list) — bsw_pair_decide (bsw_device.h), as in the other two-seeds-per-lane kernels */
             const bsw_dtask T = tasks[ti[x]];
-            if (side == 1 || T.rqlen == 0) {
+            if (sd == 1 || T.rqlen == 0) {
                 bsw_ext Lx = e;
-                if (side == 1 && T.lqlen > 0) Lx = out[ti[x]].left;
-                if (fin.pairs) { if (side == 0) out[ti[x]].left = e; else out[ti[x]].right = e; }      /* (pair format: the side records stay in scratch) */
+                if (sd == 1 && T.lqlen > 0) Lx = out[ti[x]].left;
+                if (fin.pairs) { if (sd == 0) out[ti[x]].left = e; else out[ti[x]].right = e; }      /* (pair format: the side records stay in scratch) */
                 bsw_pair_decide(P, T, ti[x], Lx, e, out, fin.redo, fin.redo_cnt, fin.pairs);
                 return;
             }
         }
-        if (side == 0) out[ti[x]].left = e; else out[ti[x]].right = e;
+        if (sd == 0) out[ti[x]].left = e; else out[ti[x]].right = e;
     });
+    }
 }
 
 /* cols = eh[] columns of the lane class (<= 192: three stripes, <= 256: four) */
@@ -255,15 +272,17 @@ hipError_t launch_lane2g(int cols, const bsw_dparams &P, int variant, int side, 
     if (n == 0) return hipSuccess;
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins, vm = variant == BSW_VARIANT_M;
     const dim3 grid((n + 63u) / 64u), block(256);
-#define BSW_L2G_GO(NS, WPS)                                                                                                  \
+#define BSW_L2G_GO2(NS, WPS, F)                                                                                              \
     do {                                                                                                                     \
-        if (!vm && sym) hipLaunchKernelGGL((bsw_lane2g_kernel<NS, WPS, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out, fin);   \
-        else if (!vm) hipLaunchKernelGGL((bsw_lane2g_kernel<NS, WPS, false, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out, fin);    \
-        else if (sym) hipLaunchKernelGGL((bsw_lane2g_kernel<NS, WPS, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out, fin);      \
-        else hipLaunchKernelGGL((bsw_lane2g_kernel<NS, WPS, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out, fin);              \
+        if (!vm && sym) hipLaunchKernelGGL((bsw_lane2g_kernel<NS, WPS, false, true, F>), grid, block, 0, s, P, side, seq, tasks, order, n, out, fin);   \
+        else if (!vm) hipLaunchKernelGGL((bsw_lane2g_kernel<NS, WPS, false, false, F>), grid, block, 0, s, P, side, seq, tasks, order, n, out, fin);    \
+        else if (sym) hipLaunchKernelGGL((bsw_lane2g_kernel<NS, WPS, true, true, F>), grid, block, 0, s, P, side, seq, tasks, order, n, out, fin);      \
+        else hipLaunchKernelGGL((bsw_lane2g_kernel<NS, WPS, true, false, F>), grid, block, 0, s, P, side, seq, tasks, order, n, out, fin);              \
     } while (0)
+#define BSW_L2G_GO(NS, WPS) do { if (side == 2) BSW_L2G_GO2(NS, WPS, true); else BSW_L2G_GO2(NS, WPS, false); } while (0)
     if (cols <= 192) BSW_L2G_GO(3, 3);
     else BSW_L2G_GO(4, 2);
+#undef BSW_L2G_GO2
 #undef BSW_L2G_GO
     return hipGetLastError();
 }

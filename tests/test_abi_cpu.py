@@ -312,3 +312,33 @@ def test_auto_policy_by_work(host):
     big = t.copy(); big["h0"][::10] = 300
     seg = host.plan_batch(p, big, kernel=host.KERNEL_AUTO)[1]
     assert int(seg[9] - seg[8]) == 60000                                 # lane-kernel-sized: the 16-bit class keeps them
+
+
+def test_auto_policy_fuses_the_two_sides_of_mid_sized_chunks(host):
+    """A group-kernel chunk of two-sided seeds up to GROUP_FUSE_MAX (49 152) runs both sides of a seed in one launch: every 8-bit
+    lane seed on the LEFT lists (the ones without a left side last in their class, at query length 0), no right list; the
+    group kernel then starts at 1.5 M query bases over BOTH sides.  Larger chunks keep one list per side (plan only: no GPU)."""
+    p = host.default_params()
+    spec = dict(seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.05)
+    t, a = host.synth_tasks(70000, seed=6, **spec)
+    t["lqlen"][7::50] = 0                                                # some seeds without a left side
+    both = lambda x: int((x["lqlen"].astype(np.int64) + x["rqlen"]).sum())
+    lists = lambda seg: (int(seg[9] - seg[8]), int(seg[17] - seg[9]), int(seg[25] - seg[17]))       # lane seeds, left entries, right entries
+    n_small = 9000
+    assert both(t[:n_small]) < 1_500_000
+    assert lists(host.plan_batch(p, t[:n_small], kernel=host.KERNEL_AUTO)[1]) == (0, 0, 0)           # general kernels
+    n_mid = 20000
+    assert both(t[:n_mid]) >= 1_500_000 and max(int(t[:n_mid]["lqlen"].sum()), int(t[:n_mid]["rqlen"].sum())) < 1_500_000
+    order, seg, _ = host.plan_batch(p, t[:n_mid], kernel=host.KERNEL_AUTO)
+    has_side = int(((t[:n_mid]["lqlen"] > 0) | (t[:n_mid]["rqlen"] > 0)).sum())
+    assert lists(seg) == (has_side, has_side, 0)                         # fused: one list, every seed once
+    left = order[seg[9]:seg[17]]
+    assert len(np.unique(left)) == has_side
+    ql = t[:n_mid]["lqlen"][left].astype(np.int64)
+    nq = np.array([int((np.frombuffer(C.string_at(int(t[:n_mid]["lquery"][i]), int(t[:n_mid]["lqlen"][i])), dtype=np.uint8) >= 4).any()) if t[:n_mid]["lqlen"][i] else 0 for i in left])
+    for flag in (1, 0):                                                  # queries with an N first; inside each: longest left side first, length 0 last
+        part = ql[nq == flag]
+        assert (np.diff(part) <= 0).all()
+    n_big = 60000
+    l, le, re_ = lists(host.plan_batch(p, t[:n_big], kernel=host.KERNEL_AUTO)[1])
+    assert l > 49152 and le == int((t[:n_big]["lqlen"] > 0).sum()) and re_ == int((t[:n_big]["rqlen"] > 0).sum())      # a list per side

@@ -363,3 +363,46 @@ def test_mid_sized_chunk_runs_the_group_kernel(host, oracle):
             b.free()
             assert_same(got, want, tasks)
             assert_same(c.extend_pairs(p, tasks), want, tasks)            # the same through a submit (one chunk)
+
+
+@pytest.mark.parametrize("read_len,n", [(150, 30_000), (250, 20_000)])
+def test_group_kernel_runs_both_sides_of_a_seed_in_one_launch(host, oracle, read_len, n):
+    """A mid-sized chunk of two-sided seeds (up to GROUP_FUSE_MAX of them): ONE bsw_lane2g_kernel launch over all left lists — a
+    wavefront runs the left sides of its 16 seeds, then their right sides with the scores it just found as h0 — so the chunk
+    takes one wave lifetime instead of two.  Seeds without a left side (they sit at query length 0 of the left lists), without
+    a right side (finished by the first half), 16-bit seeds (general kernel), Ns, both variants, separate gap penalties, full
+    and pair records; 250 bp reads take the four-stripe instantiation."""
+    spec = dict(read_len=read_len, seed_len_min=19, seed_len_max=60, seed_at_start=0, sub_rate=0.02, indel_rate=0.01, junk_frac=0.1, n_rate=0.002)
+    if read_len == 250:
+        spec.update(w=500, seed_len_max=20)                               # (h0 + 231 + b <= 255: longer seeds of 250 bp reads are 16-bit seeds)
+    ta, a1 = host.synth_tasks(n, seed=91, **spec)
+    tb, a2 = host.synth_tasks(n // 8, seed=92, **dict(spec, seed_at_start=1))       # no left side
+    tasks = np.concatenate([ta, tb])
+    tasks["tag"] = np.arange(len(tasks), dtype=np.uint32)
+    noright = np.arange(5, len(ta), 23)
+    tasks["rqlen"][noright] = 0
+    tasks["rtlen"][noright] = 0
+    tasks["h0"][::61] = 300                                              # 16-bit seeds
+    rng = np.random.default_rng(5)
+    tasks = tasks[rng.permutation(len(tasks))]
+    n8 = int(((tasks["h0"] != 300) & ((tasks["lqlen"] > 0) | (tasks["rqlen"] > 0))).sum())
+    for variant, gaps in ((0, {}), (1, dict(o_del=5, e_del=2, o_ins=7, e_ins=1))):
+        p = host.default_params(variant=variant, w=spec.get("w", 100), **gaps)
+        order, seg, words = host.plan_batch(p, tasks, kernel=host.KERNEL_AUTO)
+        assert seg[17] - seg[9] == n8 and seg[25] - seg[17] == 0         # every 8-bit lane seed on the left lists, no right list
+        left = order[seg[9]:seg[17]]
+        assert len(np.unique(left)) == n8
+        want = oracle.pair_batch(p, tasks, nthreads=8)
+        with host.BswContext(device=0) as c:
+            b = c.upload(p, tasks); c.run(b); got = c.download(b)
+            nwave = int(sum(1 for k in range(8) if seg[k + 1] - seg[k]))
+            assert b.info()["launches"] == nwave + 2                      # the general classes, ONE group launch, the redo launch
+            b.free()
+            assert_same(got, want, tasks)
+            assert_same(c.extend_pairs(p, tasks), want, tasks)            # the same through a submit (one chunk)
+            pt, pwords = host.pack_tasks(tasks)
+            assert_same(c.extend_pairs_packed(p, pt), want, tasks)
+        with host.BswContext(device=0, result_format=host.RESULT_PAIR) as c:
+            gp = c.extend_pairs(p, tasks)
+            for f in ("tag", "qb", "qe", "rb", "re", "score", "truesc", "w"):
+                assert (gp[f] == want[f]).all(), f

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The three ways a resident batch can run, by batch size: general kernels (one / four seeds per wavefront), the GROUP
-kernel (bsw_lane2g_kernel: 16 seeds per wavefront) and the lane kernels (128 per wavefront).  PE mixed bins and the
+kernel (bsw_lane2g_kernel: 16 seeds per wavefront; one launch per side, or both sides of a seed in one launch) and the lane kernels (128 per wavefront).  PE mixed bins and the
 150 bp single bin.  The switches are read once per process: every (mode, workload) runs in a child process.
 python tools/crossover_group.py > profiles/r6/crossover_group.json"""
 import json, os, subprocess, sys
@@ -32,7 +32,11 @@ print(json.dumps(row))
 out = {}
 for wl in ("pe_mixed", "single_bin"):
     out[wl] = {}
-    for name, kern, env in (("general_ms", 1, {}), ("group_ms", 0, {"BSW_GROUP": "1"}), ("lane_ms", 2, {"BSW_GROUP": "0"}), ("auto_ms", 0, {})):
+    modes = (("general_ms", 1, {}), ("group_ms", 0, {"BSW_GROUP": "1", "BSW_GROUP_FUSE": "0"}), ("group_fused_ms", 0, {"BSW_GROUP": "1", "BSW_GROUP_FUSE": "1"}),
+             ("lane_ms", 2, {"BSW_GROUP": "0"}), ("auto_ms", 0, {}))
+    if len(sys.argv) > 1:
+        modes = tuple(m for m in modes if m[0] in sys.argv[1:])
+    for name, kern, env in modes:
         r = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT), wl, str(kern)], env=dict(os.environ, **env), capture_output=True, text=True)
         out[wl][name] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else r.stderr[-500:]
 print(json.dumps(out, indent=1))
