@@ -84,7 +84,7 @@ BSW_LOCAL void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_
 
 /* work8_l / work8_r: the summed query lengths of the chunk's 8-bit left / right lane sides */
 BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint32_t &n_lane, uint32_t n16, uint32_t *cl, uint32_t *cr,
-                                uint32_t *cw, const uint32_t *cw16, uint8_t *dep, uint64_t work8_l, uint64_t work8_r)
+                                uint32_t *cw, const uint32_t *cw16, uint8_t *dep, uint64_t work8_l, uint64_t work8_r, bool streaming)
 {
     /* BSW_GROUP=0: never the group kernel (the lane kernels then start at round 5's seed count); 1: the group kernel for every
      * chunk with 8-bit lane seeds (tests, measurements) */
@@ -97,10 +97,19 @@ BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint
     static const int fenv = getenv("BSW_GROUP_FUSE") ? atoi(getenv("BSW_GROUP_FUSE")) : -1;
     const bool fusable = fenv != 0 && work8_l && work8_r && (fenv == 1 || n8 <= GROUP_FUSE_MAX);
     const uint64_t work_g = fusable ? work8_l + work8_r : work;
+    /* ... and past the group kernel's fused range the LANE kernels run such a chunk in one launch (bsw_lane2_kernel's fused
+     * instantiation, 136 columns: 1.2 - 1.7 ms for 65 k - 262 k PE seeds where two lane launches take 2.0 and two group launches
+     * 1.4 - 4.0, profiles/r6/crossover_group.json): lane bins from LANE_WORK_MIN bases over both sides */
+    static const int lenv = getenv("BSW_LANE_FUSE") ? atoi(getenv("BSW_LANE_FUSE")) : -1;
+    int cmax8 = -1;
+    for (int c = 0; c < bp.n_lane && c < BSW_MAX_LANE_CLASSES; ++c)
+        if (bp.lane_bits[c] == 8 && (cl[c] || cr[c])) cmax8 = c;
+    const bool lane_fusable = group_ok && lenv != 0 && !fusable && (!streaming || lenv == 1) && work8_l && work8_r && n8 <= LANE_FUSE_MAX && cmax8 >= 0 && bp.lane_cols[cmax8] <= 136;
     bool group = false;
     if (genv == 1) group = group_ok && n8 > 0 && kern != BSW_KERNEL_WAVE;
     else if (kern == BSW_KERNEL_AUTO) {
-        const bool lane = genv == 0 || !group_ok ? lane_bins_pay(n_lane, cl, cr) : (work >= LANE_WORK_MIN || lane_bins_pay(n16, cl, cr));
+        const bool lane = genv == 0 || !group_ok ? lane_bins_pay(n_lane, cl, cr)
+                                                 : (work >= LANE_WORK_MIN || lane_bins_pay(n16, cl, cr) || (lane_fusable && work8_l + work8_r >= LANE_WORK_MIN));
         if (!lane) {
             group = genv != 0 && group_ok && work_g >= GROUP_WORK_MIN;
             if (!group) { bp.lane_on = 0; return false; }
@@ -117,14 +126,18 @@ BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint
 }
 
 /* See bsw_internal.h.  A seed's two sides add up to about one read length whatever the split, so a wavefront that runs the left
- * sides of its seeds and then their right sides lives about as long as ONE launch of the longest sides does, and the chunk
- * takes one wave lifetime instead of two — what a chunk below ~3 waves per SIMD (GROUP_FUSE_MAX seeds) is bound by.  Larger
- * chunks are bound by throughput, and there a right-side list sorted by its own length packs better than the left list's
- * order.  BSW_GROUP_FUSE=0 / 1: never / whenever the chunk has both kinds of sides (measurements, tests). */
-BSW_LOCAL int fuse_group_lists(bsw_binparams &bp, uint32_t n8, uint32_t *cl, uint32_t *cr)
+ * sides of its seeds and then their right sides lives little longer than ONE launch of the longest sides does, and the chunk
+ * takes one wave lifetime instead of two — what a chunk that does not fill the machine (GROUP_FUSE_MAX seeds at 16 per
+ * wavefront, LANE_FUSE_MAX at 128) is bound by.  Larger chunks are bound by throughput, and there a right-side list sorted by
+ * its own length packs better than the left list's order.  BSW_GROUP_FUSE / BSW_LANE_FUSE = 0 / 1: never / whenever the chunk
+ * has both kinds of sides (measurements, tests). */
+BSW_LOCAL int fuse_lists(bsw_binparams &bp, int kern, bool group, bool packed_ok, uint32_t n8, uint32_t *cl, uint32_t *cr, bool streaming)
 {
-    static const int fenv = getenv("BSW_GROUP_FUSE") ? atoi(getenv("BSW_GROUP_FUSE")) : -1;
-    if (fenv == 0 || (fenv != 1 && n8 > GROUP_FUSE_MAX)) return -1;
+    static const int genv = getenv("BSW_GROUP_FUSE") ? atoi(getenv("BSW_GROUP_FUSE")) : -1;
+    static const int lenv = getenv("BSW_LANE_FUSE") ? atoi(getenv("BSW_LANE_FUSE")) : -1;
+    const int fenv = group ? genv : lenv;
+    if (!bp.lane_on || !packed_ok || fenv == 0 || (fenv != 1 && n8 > (group ? GROUP_FUSE_MAX : LANE_FUSE_MAX))) return -1;
+    if (!group && fenv != 1 && (kern != BSW_KERNEL_AUTO || streaming)) return -1;      /* (forced lane bins keep a list per side: BSW_KERNEL_LANE is what the tests of that path use) */
     int cmax = -1;
     uint32_t nl = 0, nr = 0;
     for (int c = 0; c < bp.n_lane && c < BSW_MAX_LANE_CLASSES; ++c) {
@@ -133,11 +146,28 @@ BSW_LOCAL int fuse_group_lists(bsw_binparams &bp, uint32_t n8, uint32_t *cl, uin
         nl += cl[c]; nr += cr[c];
     }
     const int c0 = bsw_side_lane_class(&bp, 8, 0);
-    if (cmax < 0 || c0 < 0 || !nl || !nr || nl > n8 || bp.lane_cols[cmax] > 256) return -1;       /* (a one-sided chunk has nothing to fuse) */
+    if (cmax < 0 || c0 < 0 || !nl || !nr || nl > n8) return -1;       /* (a one-sided chunk has nothing to fuse) */
+    if (bp.lane_cols[cmax] > (group ? 256 : 136)) return -1;           /* (the lane kernels: bsw_lane2_kernel<17>; the 232-column class has no fused form) */
     cl[c0] += n8 - nl;                                   /* the seeds without a left side: query length 0 */
-    for (int c = 0; c < BSW_MAX_LANE_CLASSES; ++c) cr[c] = 0;
+    for (int c = 0; c < bp.n_lane && c < BSW_MAX_LANE_CLASSES; ++c)
+        if (bp.lane_bits[c] == 8) cr[c] = 0;
     bp.fused = 1;
     return cmax;
+}
+
+/* ... and where that launch finds its seeds, once the plan's lists are laid out */
+BSW_LOCAL void plan_fused(batch_plan &pl, const bsw_binparams &bp, int fused_cls, bool group, const uint32_t *cl)
+{
+    pl.lane_group = group ? (fused_cls >= 0 ? 2 : 1) : 0;
+    pl.fused_cls = fused_cls;
+    pl.fused_off = pl.fused_cnt = 0;
+    if (fused_cls < 0) return;
+    bool first = true;
+    for (int c = 0; c < bp.n_lane && c < BSW_MAX_LANE_CLASSES; ++c) {
+        if (bp.lane_bits[c] != 8) continue;
+        if (first) { pl.fused_off = pl.laneL_off[c]; first = false; }
+        pl.fused_cnt += cl[c];
+    }
 }
 
 /* tasks[0..n) -> dt[0..n) (device task records), ro[0..n) (gather layout of the raw bytes), class counts -> plan */
@@ -345,12 +375,12 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     }
     if (acc >= (1ull << 32)) return fail(e, BSW_E_LIMIT, "batch sequence arena beyond 2^32 words; split the batch");
     if (accb >= (1ull << 32) - RAW_SLACK) return fail(e, BSW_E_LIMIT, "batch holds more than 4 GiB of bases; split the batch");
-    bool group = false;
+    bool group = false, packed_ok = false;
     {
         bsw_dparams dpx;
         errs quiet;
-        const bool group_ok = check_params(quiet, p, &dpx) == BSW_OK && bsw::lane_class_finishes(0, dpx, p->variant);
-        group = decide_lane_mode(kern, group_ok, bp, n_lane, n16, cl, cr, cw, cw16, dep, work8_l, work8_r);
+        packed_ok = check_params(quiet, p, &dpx) == BSW_OK && bsw::lane_class_finishes(0, dpx, p->variant);
+        group = decide_lane_mode(kern, packed_ok, bp, n_lane, n16, cl, cr, cw, cw16, dep, work8_l, work8_r, ci.streaming);
     }
     if (bp.lane_on && narrow_foldable(bp)) {
         uint64_t all8 = 0;
@@ -364,7 +394,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
         memset(cr, 0, sizeof(cr));
         n_lane = 0;
     }
-    const int fused_cls = group && bp.lane_on ? fuse_group_lists(bp, n_lane, cl, cr) : -1;
+    const int fused_cls = fuse_lists(bp, kern, group, packed_ok, group ? n_lane : n_lane - n16, cl, cr, ci.streaming);
     if (bp.lane_on && h0_hi >= h0_lo) bsw_set_h0_buckets(&bp, h0_lo, h0_hi);
     batch_plan &pl = ci.plan;
     pl = batch_plan();
@@ -380,8 +410,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     pl.redo_off = cur;
     pl.order_len = cur + n_lane;
     pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
-    pl.lane_group = group ? (fused_cls >= 0 ? 2 : 1) : 0;
-    pl.fused_cls = fused_cls;
+    plan_fused(pl, bp, fused_cls, group, cl);
     memcpy(pl.dep, dep, sizeof(pl.dep));
     memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
     bp.lane_all_off = pl.lane_all_off;
@@ -600,7 +629,7 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
     int nchain = 0;
     bool chain_pays = false;
     bool any_group = false;
-    for (int j = 0; j < nj; ++j) any_group = any_group || jobs[j].pl->lane_group;
+    for (int j = 0; j < nj; ++j) any_group = any_group || jobs[j].pl->lane_group || jobs[j].pl->fused_cls >= 0;      /* (nor for a fused launch) */
     if (fk && fk->mode == 2 && !any_group) {        /* (the group kernel's launches are short: nothing for a chain to fill) */
         bool fits = true;
         for (int side = 0; side < 2; ++side)
@@ -660,18 +689,20 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
         bsw_result *d_out = J.d_out;
         bsw_pair *d_pair = J.d_pair;
         uint64_t *launches = J.launches;
-        if (pl.lane_group == 2) {                                      /* both sides of every seed in one launch over all left lists */
-            const uint32_t off = pl.laneL_off[0], cnt = pl.laneL_off[BSW_MAX_LANE_CLASSES] - off;
-            HIPCHK(e, bsw::launch_lane(pl.fused_cls, variant, P, 2, d_seq, d_tasks, d_order + off, cnt, d_out, s, nullptr, nullptr, fin_of(j)));
+        if (pl.fused_cls >= 0 && pl.fused_cnt) {                       /* both sides of every 8-bit seed in one launch over their left lists */
+            HIPCHK(e, bsw::launch_lane(pl.fused_cls, variant, P, 2, d_seq, d_tasks, d_order + pl.fused_off, pl.fused_cnt, d_out, s, nullptr, nullptr, fin_of(j)));
             if (launches) ++*launches;
-        } else if (!chain_pays) {
+        }
+        if (!chain_pays) {
         const fork_t *fk1 = fk && fk->mode == 1 ? fk : nullptr;       /* (mode 2 without a chain that pays: plain launches on s) */
         /* The classes of a side side by side: the k-th non-empty class of a side (widest first: its waves run longest) goes
          * to stream k — the slot stream, then the auxiliary ones.  A right-side launch waits for exactly the left-side
          * launches that hold one of its seeds (plan.dep); streams are in-order, so only other streams' launches need an event. */
         hipStream_t lstream[BSW_MAX_LANE_CLASSES] = {nullptr}, rstream[BSW_MAX_LANE_CLASSES] = {nullptr};
         int nl = 0, nr = 0;
+        const auto in_fused = [&](int c) { return pl.fused_cls >= 0 && bsw::lane_class_bits(c) == 8; };      /* (their seeds ran above) */
         for (int c = nlc - 1; c >= 0; --c) {
+            if (in_fused(c)) continue;
             if (pl.laneL_off[c + 1] - pl.laneL_off[c]) { lstream[c] = (fk1 && nl > 0 && nl <= BSW_FORK_AUX) ? fk1->aux[nl - 1] : s; ++nl; }
             if (pl.laneR_off[c + 1] - pl.laneR_off[c]) { rstream[c] = (fk1 && nr > 0 && nr <= BSW_FORK_AUX) ? fk1->aux[nr - 1] : s; ++nr; }
         }
@@ -682,14 +713,14 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
         }
         for (int c = nlc - 1; c >= 0; --c) {
             const uint32_t cnt = pl.laneL_off[c + 1] - pl.laneL_off[c];
-            if (!cnt) continue;
+            if (!cnt || in_fused(c)) continue;
             HIPCHK(e, bsw::launch_lane(c, variant, P, 0, d_seq, d_tasks, d_order + pl.laneL_off[c], cnt, d_out, lstream[c], nullptr, nullptr, fin_of(j)));
             if (forked) HIPCHK(e, hipEventRecord(fk1->ev_left[c], lstream[c]));
             if (launches) ++*launches;
         }
         for (int c = nlc - 1; c >= 0; --c) {
             const uint32_t cnt = pl.laneR_off[c + 1] - pl.laneR_off[c];
-            if (!cnt) continue;
+            if (!cnt || in_fused(c)) continue;
             if (forked)
                 for (int lc = 0; lc < nlc; ++lc)
                     if (lstream[lc] && lstream[lc] != rstream[c] && ((pl.dep[lc] >> c) & 1)) HIPCHK(e, hipStreamWaitEvent(rstream[c], fk1->ev_left[lc], 0));
@@ -826,8 +857,9 @@ extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, si
             const int bits = bsw_seed_lane_bits(&bp, T.lqlen, T.rqlen, T.h0);
             if (!bits) { k0 = BSW_BIN_WAVE0 + bsw_wave_class_of(&bp, std::max(T.lqlen, T.rqlen)); return; }
             k0 = BSW_BIN_LANEALL;
-            if (T.lqlen || bp.fused) k1 = BSW_BIN_L(bits == 16, has_n(tasks[i].lquery, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
-            if (T.rqlen && !bp.fused) k2 = BSW_BIN_R(bits == 16, has_n(tasks[i].rquery, T.rqlen), T.rqlen);
+            const bool fz = bp.fused && bits == 8;
+            if (T.lqlen || fz) k1 = BSW_BIN_L(bits == 16, has_n(tasks[i].lquery, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
+            if (T.rqlen && !fz) k2 = BSW_BIN_R(bits == 16, has_n(tasks[i].rquery, T.rqlen), T.rqlen);
         };
         for (size_t i = 0; i < n; ++i) {
             int k0, k1, k2;
@@ -1380,6 +1412,7 @@ struct ticket_t {
     bool packed = false;
     size_t n = 0;
     std::atomic<size_t> remaining{0};           /* chunks whose results have not been handed over yet */
+    size_t nchunks = 0;                         /* chunks the submit was cut into */
     std::atomic<int> abort{0};                  /* a chunk failed: the others do nothing any more */
     std::mutex emu;
     int rc = 0;                                 /* the failure itself, not the chunks it made give up */
@@ -1475,6 +1508,7 @@ static void slot_main(bsw_ctx *ctx, size_t d, size_t s)
         int rc = BSW_OK;
         hipError_t he;
         chunk_info ci;
+        ci.streaming = t->nchunks >= 3;
         bool passed = false, queued = false;         /* the DMA turn has been passed on; some async op of this chunk may be on the stream */
         const double t0 = dbg ? tnow() : 0;
         double t1 = t0, t2 = t0;
@@ -1675,6 +1709,7 @@ static int submit_common(bsw_ctx *ctx, const bsw_params *p, const bsw_task *task
     size_t total = 0;
     for (const auto &v : chunks) total += v.size();
     t->remaining = total;
+    t->nchunks = total;
     t->done = total == 0;
     {
         std::lock_guard<std::mutex> lk(pp.mu);

@@ -64,7 +64,8 @@ inline bool lane_bins_pay(uint32_t n_lane, const uint32_t *cl, const uint32_t *c
  * bases (28 k PE sides of ~55 bases, 11 k sides of 131), the lane kernels from ~5 M (100 k PE seeds, 38 k one-bin seeds). */
 #define GROUP_WORK_MIN 1500000ull
 #define LANE_WORK_MIN  5000000ull
-#define GROUP_FUSE_MAX 49152u        /* 8-bit lane seeds up to which a group chunk runs both sides in one launch (fuse_group_lists): 3 waves per SIMD */
+#define GROUP_FUSE_MAX 49152u        /* 8-bit lane seeds up to which a group chunk runs both sides in one launch (fuse_lists): 3 waves per SIMD */
+#define LANE_FUSE_MAX  262144u       /* ... and a lane-kernel chunk (bsw_lane2_kernel<17, 2, ., ., true>): 2 waves per SIMD */
 #define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
 #define RAW_FRONT 32                 /* ... and in front of the first one (reversed left queries) */
 
@@ -78,8 +79,11 @@ struct batch_plan {
     uint32_t order_len = 0;          /* entries before the redo counter */
     int redo_cls = 0;
     int lane_group = 0;              /* 1: the lane launches of this chunk run the eight-lanes-per-seed-pair kernel (bsw_fin.group);
-                                        2: ONE such launch for both sides of every seed, over all left lists (fuse_group_lists) */
-    int fused_cls = -1;              /* lane_group == 2: the lane class whose instantiation holds every side of the chunk */
+                                        2: ONE such launch for both sides of every seed, over all 8-bit left lists (fuse_lists) */
+    int fused_cls = -1;              /* >= 0: the chunk's 8-bit lane seeds run both sides in ONE launch (the group kernel when lane_group == 2,
+                                        else bsw_lane2_kernel's fused instantiation) of this class — it holds every side of the chunk —
+                                        over order[fused_off .. fused_off + fused_cnt): all 8-bit left lists */
+    uint32_t fused_off = 0, fused_cnt = 0;
     /* dep[lc] bit rc: some seed has its left side in lane class lc and its right side in lane class rc — the right-side
      * launch of class rc then has to wait for the left-side launch of class lc (h0 of the right extension is the score
      * after the left one, sw_pe_array_proc_element.v:1671).  All ones = not known. */
@@ -317,6 +321,8 @@ struct chunk_info {
                                          DMA'd straight into `seq`, no pack kernel */
     batch_plan plan;
     bsw_binparams bp;
+    bool streaming = false;           /* (set by the caller) one of MANY chunks of a submit: the slots keep the GPU full, so the chunk is bound by
+                                         throughput whatever its size — the lane kernels then keep a list per side (no fused launch) */
     bool rb_on = false;               /* the records' word offsets are still relative: bsw_rebase_kernel runs behind their DMA */
     bsw_rebase rb{};
 };
@@ -332,11 +338,13 @@ BSW_LOCAL size_t order_capacity(size_t n);
 /* AUTO policy of a chunk once its seeds are counted: lane bins (128 seeds per wavefront), the group kernel (16 per wavefront;
  * returns true — the 16-bit seeds then leave the lane lists for the general kernel: cw16 = their count per wave class, n16
  * their number) or no lane launches at all (bp.lane_on = 0).  group_ok: the scoring parameters allow the packed kernels. */
-/* A group chunk with two-sided seeds as ONE launch: every 8-bit lane seed goes on the left lists (n8 of them; cl / cr: the counted
- * lists), the right lists are emptied, bp.fused is set.  Returns the class for the launch, -1: not fused (lists untouched). */
-BSW_LOCAL int fuse_group_lists(bsw_binparams &bp, uint32_t n8, uint32_t *cl, uint32_t *cr);
+/* A mid-sized chunk with two-sided seeds as ONE launch: every 8-bit lane seed goes on the left lists (n8 of them; cl / cr: the counted
+ * lists), the 8-bit right lists are emptied, bp.fused is set.  kern: bsw_config.kernel; group: the chunk runs the group kernel (else the lane kernels;
+ * packed_ok: the scoring parameters allow the packed kernels).  Returns the class for the launch, -1: not fused (lists untouched). */
+BSW_LOCAL int fuse_lists(bsw_binparams &bp, int kern, bool group, bool packed_ok, uint32_t n8, uint32_t *cl, uint32_t *cr, bool streaming = false);
+BSW_LOCAL void plan_fused(batch_plan &pl, const bsw_binparams &bp, int fused_cls, bool group, const uint32_t *cl);
 BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint32_t &n_lane, uint32_t n16, uint32_t *cl, uint32_t *cr,
-                                uint32_t *cw, const uint32_t *cw16, uint8_t *dep, uint64_t work8_l, uint64_t work8_r);
+                                uint32_t *cw, const uint32_t *cw16, uint8_t *dep, uint64_t work8_l, uint64_t work8_r, bool streaming = false);
 BSW_LOCAL int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams &bp);
 BSW_LOCAL bool narrow_foldable(const bsw_binparams &bp);
 BSW_LOCAL void narrow_fold(bsw_binparams &bp, uint32_t *cl, uint32_t *cr, uint8_t *dep);

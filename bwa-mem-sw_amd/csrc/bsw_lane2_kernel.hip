@@ -80,8 +80,8 @@ __device__ __forceinline__ uint32_t nib_plane(uint64_t w, int b)
 
 #define BSW_L2_TCHUNK 4         /* target words staged per seed in LDS = 64 DP rows */
 
-template <int QB, int WPS, bool VM, bool SYM>
-__global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P, const int side,
+template <int QB, int WPS, bool VM, bool SYM, bool FUSED>
+__global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P, const int side_arg,
                                                              const uint64_t *__restrict__ seq,
                                                              const bsw_dtask *__restrict__ tasks,
                                                              const uint32_t *__restrict__ order, const uint32_t n,
@@ -115,10 +115,19 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
     }
     __syncthreads();                                                /* the only barrier: the table is shared by the four waves */
 
+    /* FUSED (a mid-sized chunk of seeds with two sides each, bsw_binparams.fused): the wavefront runs the LEFT sides of its 128
+     * seeds and then their RIGHT sides, the score it found as the right side's h0 — a seed's two sides add up to about one read
+     * length whatever the split, so the wavefront lives little longer than one launch of the longest side did and the chunk
+     * takes one such lifetime instead of two.  Nothing but the two scores is carried from one side to the other: the seeds,
+     * the constants and the operands in LDS are set up again (the one-sided instantiation has no loop: its code is what it was). */
+    uint32_t lsc2 = 0;                                              /* the left scores of the lane's two seeds (low / high half) */
+    /* (one side = one call of this closure: the one-sided instantiation is straight-line code as before — wrapped in a loop of
+     * one pass the compiler spilled 336 registers of the 136-column kernel — and the fused one holds two copies, run in turn) */
+    const auto run_side = [&](const int side) __attribute__((always_inline)) {
     typename L::state S;
     uint32_t t_off[2], ti[2], nblk = 0, q2[2][NW];
     int ntw[2];
-    bool valid[2];
+    bool valid[2], has[2];                                          /* has: the seed exists and has this side (a one-sided list holds only such seeds) */
     l2::sfor<2>([&](auto xi) {
         constexpr int x = decltype(xi)::value;
         const uint32_t slot = w0 + 64u * x;
@@ -131,9 +140,10 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
             qlen = T.lqlen; tlen = T.ltlen; wlim = T.wlim_l; q_off = T.lq_off; t_off[x] = T.lt_off; h0 = T.h0;
         } else {
             qlen = T.rqlen; tlen = T.rtlen; wlim = T.wlim_r; q_off = T.rq_off; t_off[x] = T.rt_off;
-            h0 = T.lqlen > 0 ? out[ti[x]].left.score : T.h0;          /* h0 = score after the left ext (:1671) */
+            h0 = T.lqlen > 0 ? (FUSED ? (int)((lsc2 >> (16 * x)) & 0xffffu) : out[ti[x]].left.score) : T.h0;          /* h0 = score after the left ext (:1671) */
         }
-        if (!valid[x]) tlen = 0;
+        has[x] = valid[x] && qlen > 0;
+        if (!has[x]) { tlen = 0; qlen = qlen > 0 ? qlen : 1; t_off[x] = 0; }      /* (the target staging reads word t_off + 0 of every lane: a seed without this side has no offset worth reading at) */
         ntw[x] = (tlen + 15) >> 4;
         l2::init_pair(S.p, x, qlen, tlen, h0, min(P.w, wlim));
         uint32_t mb[4][NW];
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
             for (int hlf = 0; hlf < 2; ++hlf) {
                 const int v = wd * 2 + hlf;
                 if (v < (QMAX + 15) / 16) {
-                    const uint64_t qw = (valid[x] && v * 16 < qlen) ? seq[q_off + v] : 0ull;
+                    const uint64_t qw = (has[x] && v * 16 < qlen) ? seq[q_off + v] : 0ull;
                     p0 |= nib_plane(qw, 0) << (hlf * 16);
                     p1 |= nib_plane(qw, 1) << (hlf * 16);
                     p2 |= nib_plane(qw, 2) << (hlf * 16);
@@ -171,8 +181,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         lds_wn[wv][c][lane] = ((q2[0][c >> 1] >> (16 * (c & 1))) & 0xffffu) | ((q2[1][c >> 1] >> (16 * (c & 1))) << 16);
 
     l2::consts k;
-    k.a = P.mat[0]; k.pb = -P.mat[1]; k.pn = -P.mat[24];
-    k.o_del = P.o_del; k.e_del = P.e_del; k.oe_ins = P.o_ins + P.e_ins; k.e_ins = P.e_ins; k.zdrop = P.zdrop;
+    const auto again = [](int v) { return FUSED ? (int)l2::opaque_s((uint32_t)v) : v; };      /* (an asm statement: the constants are not kept from one side to the other) */
+    k.a = again(P.mat[0]); k.pb = again(-P.mat[1]); k.pn = again(-P.mat[24]);
+    k.o_del = again(P.o_del); k.e_del = again(P.e_del); k.e_ins = again(P.e_ins); k.oe_ins = again(P.o_ins) + k.e_ins; k.zdrop = again(P.zdrop);
     l2::fill_packed_consts(k);
     L::init_row(S, k);
 
@@ -259,9 +270,13 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         L2_STAMP(4);
     }
 
+    if (FUSED && side == 0) {
+        const int s0 = has[0] ? l2::pair_result(S.p, 0).mx : 0, s1 = has[1] ? l2::pair_result(S.p, 1).mx : 0;
+        lsc2 = (uint32_t)s0 | ((uint32_t)s1 << 16);                 /* (8-bit scores) */
+    }
     l2::sfor<2>([&](auto xi) {
         constexpr int x = decltype(xi)::value;
-        if (!valid[x]) return;
+        if (!has[x]) return;
         const l2::ext_out s = l2::pair_result(S.p, x);
         bsw_ext e;
         e.score = s.mx; e.qle = s.max_j + 1; e.tle = s.max_i + 1; e.gtle = s.max_ie + 1;
@@ -291,6 +306,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2_kernel(const bsw_dparams P
         }
         if (side == 0) out[ti[x]].left = e; else out[ti[x]].right = e;
     });
+    };
+    if constexpr (FUSED) { run_side(0); run_side(1); }
+    else run_side(side_arg);
 }
 
 /* what the packed formulation needs from the scoring parameters (everything else takes bsw_lane_kernel): a bwa-style
@@ -313,17 +331,20 @@ hipError_t launch_lane2(int qb, const bsw_dparams &P, int variant, int side, con
     const bool sym = P.o_del == P.o_ins && P.e_del == P.e_ins, vm = variant == BSW_VARIANT_M;
     const dim3 grid((n + 511u) / 512u), block(256);
     if (tail_flag && tail_target) *tail_target = grid.x;              /* the flag's value once every workgroup has started */
-#define BSW_L2_GO(QB, WPS)                                                                                                    \
+#define BSW_L2_GO2(QB, WPS, F)                                                                                                \
     do {                                                                                                                      \
-        if (!vm && sym) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, false, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);   \
-        else if (!vm) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, false, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);    \
-        else if (sym) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, true, true>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);      \
-        else hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, true, false>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);              \
+        if (!vm && sym) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, false, true, F>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);   \
+        else if (!vm) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, false, false, F>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);    \
+        else if (sym) hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, true, true, F>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);      \
+        else hipLaunchKernelGGL((bsw_lane2_kernel<QB, WPS, true, false, F>), grid, block, 0, s, P, side, seq, tasks, order, n, out, tail_flag, fin);              \
     } while (0)
+#define BSW_L2_GO(QB, WPS) BSW_L2_GO2(QB, WPS, false)
     /* 72 columns: 72 row registers + the working set = 168 VGPRs, three waves per SIMD (the spills the compiler takes at
      * that bound sit in the prologue and in the cold target-staging / query-N code, none in the row loop: tests/test_isa_audit.py) */
-    if (qb == 9) BSW_L2_GO(9, 3);
+    if (side == 2) BSW_L2_GO2(17, 2, true);                             /* both sides of every seed (136 columns hold either) */
+    else if (qb == 9) BSW_L2_GO(9, 3);
     else BSW_L2_GO(17, 2);
+#undef BSW_L2_GO2
 #undef BSW_L2_GO
     return hipGetLastError();
 }

@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams 
     /* side == 2 (a mid-sized chunk of seeds with two sides each, bsw_fin.group == 2): the wavefront runs the LEFT sides of its 16
      * seeds and then their RIGHT sides — a seed's two sides add up to about one read length whatever the split, so the wavefront
      * lives about as long as one launch of the longest side did, and the chunk takes one such lifetime instead of two */
-    constexpr int side = FUSED ? 2 : 0;                 /* (the one-sided instantiation has no loop: its code is what it was) */
-    const int sd_first = FUSED ? 0 : side_arg, sd_last = FUSED ? 1 : side_arg;
-    for (int sd = sd_first; FUSED ? sd <= sd_last : sd == sd_first; ++sd) {
+    constexpr int side = FUSED ? 2 : 0;
+    /* (one side = one call of this closure: straight-line code in the one-sided instantiation, two copies run in turn in the
+     * fused one — as a loop over the sides the compiler spilled 26 - 75 registers, some inside the row loop) */
+    const auto run_side = [&](const int sd) __attribute__((always_inline)) {
     typename L::state S;
     uint32_t mA[NS], mB[NS], WNs[NS], t_off[2], ti[2];
     int ntw[2];
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams 
     uint32_t nqs = 0;                                   /* bit s: some query of the wavefront has an N in stripe s */
     l2::sfor<2>([&](auto xi) {
         constexpr int x = decltype(xi)::value;
-        const uint32_t slot = l2::opaque_s(w16s) + (uint32_t)grp + 8u * x;         /* (worked out again per side: nothing but lsc is carried) */
+        const uint32_t slot = w16s + (uint32_t)grp + 8u * x;
         valid[x] = slot < n;
         ti[x] = valid[x] ? order[slot] : order[0];
         const bsw_dtask T = tasks[ti[x]];
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams 
     /* (the constants are worked out per side, behind the seeds' set-up as in the one-sided kernel: held across the side loop
      * they cost 60 spilled registers, some of them inside the row loop) */
     l2::consts k;
-    const auto again = [](int v) { return (int)l2::opaque_s((uint32_t)v); };      /* (an asm statement: not hoisted out of the side loop) */
+    const auto again = [](int v) { return FUSED ? (int)l2::opaque_s((uint32_t)v) : v; };      /* (an asm statement: the constants are not kept from one side to the other) */
     k.a = again(P.mat[0]); k.pb = again(-P.mat[1]); k.pn = again(-P.mat[24]);
     k.o_del = again(P.o_del); k.e_del = again(P.e_del); k.e_ins = again(P.e_ins); k.oe_ins = again(P.o_ins) + k.e_ins; k.zdrop = again(P.zdrop);
     l2::fill_packed_consts(k);
@@ -260,7 +261,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams 
         }
         if (sd == 0) out[ti[x]].left = e; else out[ti[x]].right = e;
     });
-    }
+    };
+    if constexpr (FUSED) { run_side(0); run_side(1); }
+    else run_side(side_arg);
 }
 
 /* cols = eh[] columns of the lane class (<= 192: three stripes, <= 256: four) */

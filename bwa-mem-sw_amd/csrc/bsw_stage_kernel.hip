@@ -235,8 +235,9 @@ __device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const ui
     } else {
         s.k0 = BSW_BIN_LANEALL;
         const int nf = nflag ? (int)nflag[ti] : -1;
-        if (T.lqlen || bp.fused) s.k1 = BSW_BIN_L(bits == 16, nf >= 0 ? (nf & 1) : packed_has_n(seq, T.lq_off, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
-        if (T.rqlen && !bp.fused) s.k2 = BSW_BIN_R(bits == 16, nf >= 0 ? ((nf >> 1) & 1) : packed_has_n(seq, T.rq_off, T.rqlen), T.rqlen);
+        const bool fz = bp.fused && bits == 8;       /* both sides of an 8-bit seed in one launch: on the left lists whatever its left side, on no right list */
+        if (T.lqlen || fz) s.k1 = BSW_BIN_L(bits == 16, nf >= 0 ? (nf & 1) : packed_has_n(seq, T.lq_off, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
+        if (T.rqlen && !fz) s.k2 = BSW_BIN_R(bits == 16, nf >= 0 ? ((nf >> 1) & 1) : packed_has_n(seq, T.rq_off, T.rqlen), T.rqlen);
     }
     return s;
 }

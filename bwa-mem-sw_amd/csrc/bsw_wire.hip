@@ -195,10 +195,11 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
         n_lane += pt.n_lane; n16 += pt.n16; w8l += pt.w8l; w8r += pt.w8r;
         h0_lo = std::min(h0_lo, pt.h0_lo); h0_hi = std::max(h0_hi, pt.h0_hi);
     }
-    const bool group = decide_lane_mode(ctx->cfg.kernel, bsw::lane_class_finishes(0, dp, variant), bp, n_lane, n16, cl, cr, cw, cw16, nullptr, w8l, w8r);
+    const bool packed_ok = bsw::lane_class_finishes(0, dp, variant);
+    const bool group = decide_lane_mode(ctx->cfg.kernel, packed_ok, bp, n_lane, n16, cl, cr, cw, cw16, nullptr, w8l, w8r);
     if (bp.lane_on && narrow_foldable(bp)) narrow_fold(bp, cl, cr, nullptr);     /* (wire-format groups: one launch per side) */
     if (!bp.lane_on) { memcpy(cw, cw_all, sizeof(cw)); memset(cl, 0, sizeof(cl)); memset(cr, 0, sizeof(cr)); n_lane = 0; }
-    const int fused_cls = group && bp.lane_on ? fuse_group_lists(bp, n_lane, cl, cr) : -1;
+    const int fused_cls = fuse_lists(bp, ctx->cfg.kernel, group, packed_ok, group ? n_lane : n_lane - n16, cl, cr);
     if (bp.lane_on && h0_hi >= h0_lo) bsw_set_h0_buckets(&bp, h0_lo, h0_hi);
     batch_plan &pl = ci.plan;
     pl = batch_plan();
@@ -211,8 +212,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     pl.laneR_off[BSW_MAX_LANE_CLASSES] = cur;
     pl.redo_off = cur; pl.order_len = cur + n_lane;
     pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
-    pl.lane_group = group ? (fused_cls >= 0 ? 2 : 1) : 0;
-    pl.fused_cls = fused_cls;
+    plan_fused(pl, bp, fused_cls, group, cl);
     /* (pl.dep stays all ones: the wire-format groups run their classes on one stream) */
     memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
     bp.lane_all_off = pl.lane_all_off;
@@ -318,8 +318,12 @@ extern "C" int bsw_refbatch_wait(bsw_ctx *ctx, int variant, int zdrop)
      * general kernels 0.85), and three or four such groups overlap their DMAs with each other's kernels: 32 queued batches
      * 17.5 -> 20.3 M seeds/s, 48: 21.5 -> 25.7, 64: 19.2 (round 5's rule) -> 29.1 (profiles/r6/wire_format_group_sweep.txt;
      * groups of 48, one launch per side, were the first version of this rule: 26.2 at 64).  At most three groups: a fourth shares a
-     * hardware queue (96 batches as four groups of 24: 27.5 M, as three of 32: 33.1). */
-    const size_t grp_env = grp_tune ? grp_tune : (nq >= 96 ? std::max<size_t>(REFBATCH_GROUP_DEEP, (nq + 1) / 2) : nq >= 24 ? std::max<size_t>(24, (nq + 2) / 3) : (size_t)REFBATCH_GROUP);
+     * hardware queue (96 batches as four groups of 24: 27.5 M, as three of 32: 33.1).
+     * A deep queue (>= 96 batches) now goes in groups of up to 128 batches = 105 k seeds: the lane kernels run both sides of such
+     * a group in ONE launch (bsw_lane2_kernel's fused instantiation, 1.3 ms where two launches took 2.0), so one big group beats
+     * two halves in flight: 96 batches 28.3 -> 35.1 M seeds/s, 128: 36.7 -> 40.7, 192: 45.9 -> 48.9, 256: 53 (second table of
+     * profiles/r6/wire_format_group_sweep.txt). */
+    const size_t grp_env = grp_tune ? grp_tune : (nq >= 96 ? std::min<size_t>(nq, 2 * REFBATCH_GROUP_DEEP) : nq >= 24 ? std::max<size_t>(24, (nq + 2) / 3) : (size_t)REFBATCH_GROUP);
     const size_t NS = std::max<size_t>(1, std::min<size_t>(REFBATCH_SLOTS, dev.slots.size()));
     const size_t slot_of[REFBATCH_SLOTS] = {0, 1, 2, 3};
     struct flight { bool active = false, issued = false, direct_out = false; size_t q0 = 0, q1 = 0; } fl[REFBATCH_SLOTS];

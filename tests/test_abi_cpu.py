@@ -317,7 +317,8 @@ def test_auto_policy_by_work(host):
 def test_auto_policy_fuses_the_two_sides_of_mid_sized_chunks(host):
     """A group-kernel chunk of two-sided seeds up to GROUP_FUSE_MAX (49 152) runs both sides of a seed in one launch: every 8-bit
     lane seed on the LEFT lists (the ones without a left side last in their class, at query length 0), no right list; the
-    group kernel then starts at 1.5 M query bases over BOTH sides.  Larger chunks keep one list per side (plan only: no GPU)."""
+    group kernel then starts at 1.5 M query bases over BOTH sides.  Up to LANE_FUSE_MAX (262 144) the lane kernels do the same
+    (bsw_lane2_kernel's fused instantiation); larger chunks keep one list per side (plan only: no GPU)."""
     p = host.default_params()
     spec = dict(seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.05)
     t, a = host.synth_tasks(70000, seed=6, **spec)
@@ -339,6 +340,12 @@ def test_auto_policy_fuses_the_two_sides_of_mid_sized_chunks(host):
     for flag in (1, 0):                                                  # queries with an N first; inside each: longest left side first, length 0 last
         part = ql[nq == flag]
         assert (np.diff(part) <= 0).all()
-    n_big = 60000
+    n_big = 60000                                                        # past the group kernel's fused range: the lane kernels' fused launch (up to LANE_FUSE_MAX = 262 144)
     l, le, re_ = lists(host.plan_batch(p, t[:n_big], kernel=host.KERNEL_AUTO)[1])
-    assert l > 49152 and le == int((t[:n_big]["lqlen"] > 0).sum()) and re_ == int((t[:n_big]["rqlen"] > 0).sum())      # a list per side
+    assert l > 49152 and le == l and re_ == 0
+    l, le, re_ = lists(host.plan_batch(p, t[:n_big], kernel=host.KERNEL_LANE)[1])
+    assert le == int((t[:n_big]["lqlen"] > 0).sum()) and re_ == int((t[:n_big]["rqlen"] > 0).sum())      # forced lane bins: a list per side
+    t3, a3 = host.synth_tasks(300000, seed=7, **spec)
+    l, le, re_ = lists(host.plan_batch(p, t3, kernel=host.KERNEL_AUTO)[1])
+    assert l == 300000 - int(((t3["lqlen"] == 0) & (t3["rqlen"] == 0)).sum())
+    assert le == int((t3["lqlen"] > 0).sum()) and re_ == int((t3["rqlen"] > 0).sum())                    # throughput-bound: a list per side

@@ -365,13 +365,15 @@ def test_mid_sized_chunk_runs_the_group_kernel(host, oracle):
             assert_same(c.extend_pairs(p, tasks), want, tasks)            # the same through a submit (one chunk)
 
 
-@pytest.mark.parametrize("read_len,n", [(150, 30_000), (250, 20_000)])
+@pytest.mark.parametrize("read_len,n", [(150, 30_000), (250, 20_000), (150, 90_000)])
 def test_group_kernel_runs_both_sides_of_a_seed_in_one_launch(host, oracle, read_len, n):
     """A mid-sized chunk of two-sided seeds (up to GROUP_FUSE_MAX of them): ONE bsw_lane2g_kernel launch over all left lists — a
     wavefront runs the left sides of its 16 seeds, then their right sides with the scores it just found as h0 — so the chunk
     takes one wave lifetime instead of two.  Seeds without a left side (they sit at query length 0 of the left lists), without
     a right side (finished by the first half), 16-bit seeds (general kernel), Ns, both variants, separate gap penalties, full
-    and pair records; 250 bp reads take the four-stripe instantiation."""
+    and pair records; 250 bp reads take the four-stripe instantiation.  Past GROUP_FUSE_MAX seeds (the third case) the LANE kernels
+    do the same up to LANE_FUSE_MAX (bsw_lane2_kernel's fused instantiation); there the 16-bit seeds keep their own lane class with a
+    list per side."""
     spec = dict(read_len=read_len, seed_len_min=19, seed_len_max=60, seed_at_start=0, sub_rate=0.02, indel_rate=0.01, junk_frac=0.1, n_rate=0.002)
     if read_len == 250:
         spec.update(w=500, seed_len_max=20)                               # (h0 + 231 + b <= 255: longer seeds of 250 bp reads are 16-bit seeds)
@@ -389,14 +391,17 @@ def test_group_kernel_runs_both_sides_of_a_seed_in_one_launch(host, oracle, read
     for variant, gaps in ((0, {}), (1, dict(o_del=5, e_del=2, o_ins=7, e_ins=1))):
         p = host.default_params(variant=variant, w=spec.get("w", 100), **gaps)
         order, seg, words = host.plan_batch(p, tasks, kernel=host.KERNEL_AUTO)
-        assert seg[17] - seg[9] == n8 and seg[25] - seg[17] == 0         # every 8-bit lane seed on the left lists, no right list
+        lane_mode = n8 > 49152                                            # (the 16-bit seeds then sit in the 16-bit lane class, not in the wave classes)
+        w16 = tasks["h0"] == 300
+        n16l, n16r = (int((w16 & (tasks["lqlen"] > 0)).sum()), int((w16 & (tasks["rqlen"] > 0)).sum())) if lane_mode else (0, 0)
+        assert seg[17] - seg[9] == n8 + n16l and seg[25] - seg[17] == n16r          # every 8-bit lane seed on the left lists, on no right list
         left = order[seg[9]:seg[17]]
-        assert len(np.unique(left)) == n8
+        assert len(np.unique(left[~w16[left]])) == n8
         want = oracle.pair_batch(p, tasks, nthreads=8)
         with host.BswContext(device=0) as c:
             b = c.upload(p, tasks); c.run(b); got = c.download(b)
             nwave = int(sum(1 for k in range(8) if seg[k + 1] - seg[k]))
-            assert b.info()["launches"] == nwave + 2                      # the general classes, ONE group launch, the redo launch
+            assert b.info()["launches"] == nwave + 2 + (2 + 1 if lane_mode else 0)       # the general classes, ONE fused launch, the redo launch (+ the 16-bit class: two sides, bsw_pair_finalize)
             b.free()
             assert_same(got, want, tasks)
             assert_same(c.extend_pairs(p, tasks), want, tasks)            # the same through a submit (one chunk)
