@@ -60,8 +60,11 @@ inline bool lane_bins_pay(uint32_t n_lane, const uint32_t *cl, const uint32_t *c
  * (profiles/r6/crossover_group.json; ms per batch, general / group / lane):
  *     PE mixed bins   32 k seeds 1.28 / 1.09 / 1.97    49 k 1.83 / 1.28 / 1.97    65 k 2.39 / 1.44 / 1.96    131 k 4.59 / 2.13 / 1.95
  *     150 bp one bin  13 k seeds 0.66 / 0.57 / 0.98    24 k 0.93 / 0.89 / 0.98    32 k 1.36 / 0.90 / 0.99     49 k 1.77 / 1.25 / 0.99
- * Both workloads cross at the same WORK per launched side — the sum of the side's query lengths: the group kernel from ~1.5 M
- * bases (28 k PE sides of ~55 bases, 11 k sides of 131), the lane kernels from ~5 M (100 k PE seeds, 38 k one-bin seeds). */
+ * Both workloads cross at the same WORK per launch — the sum of the query lengths of the sides it holds: the group kernel from
+ * ~1.5 M bases (28 k PE sides of ~55 bases, 11 k sides of 131), the lane kernels from ~5 M (100 k PE seeds, 38 k one-bin seeds).
+ * A chunk of two-sided seeds that does not fill the machine runs BOTH sides of every seed in one launch (fuse_lists: one wave
+ * lifetime instead of two; the launch then holds both sides' bases): PE mixed bins general / group fused / lane fused / AUTO
+ *     16 k seeds 0.75 / 0.69 / 1.23 / 0.69    49 k 1.85 / 1.16 / 1.22 / 1.17    131 k 4.62 / 2.62 / 1.33 / 1.33    262 k 9.08 / 4.69 / 1.65 / 1.64 */
 #define GROUP_WORK_MIN 1500000ull
 #define LANE_WORK_MIN  5000000ull
 #define GROUP_FUSE_MAX 49152u        /* 8-bit lane seeds up to which a group chunk runs both sides in one launch (fuse_lists): 3 waves per SIMD */
