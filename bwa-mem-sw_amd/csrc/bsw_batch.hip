@@ -151,7 +151,7 @@ BSW_LOCAL int fuse_lists(bsw_binparams &bp, int kern, bool group, bool packed_ok
     cl[c0] += n8 - nl;                                   /* the seeds without a left side: query length 0 */
     for (int c = 0; c < bp.n_lane && c < BSW_MAX_LANE_CLASSES; ++c)
         if (bp.lane_bits[c] == 8) cr[c] = 0;
-    bp.fused = 1;
+    bp.fused = group ? 1 : 2;                            /* (the two differ in where the queries with an N go: bsw_stage_kernel.hip, seed_keys) */
     return cmax;
 }
 
@@ -858,7 +858,8 @@ extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, si
             if (!bits) { k0 = BSW_BIN_WAVE0 + bsw_wave_class_of(&bp, std::max(T.lqlen, T.rqlen)); return; }
             k0 = BSW_BIN_LANEALL;
             const bool fz = bp.fused && bits == 8;
-            if (T.lqlen || fz) k1 = BSW_BIN_L(bits == 16, has_n(tasks[i].lquery, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
+            if (fz) k1 = BSW_BIN_L(0, has_n(tasks[i].lquery, T.lqlen) | (bp.fused == 1 ? has_n(tasks[i].rquery, T.rqlen) : 0), bsw_h0_bucket(&bp, T.h0), T.lqlen);
+            else if (T.lqlen) k1 = BSW_BIN_L(bits == 16, has_n(tasks[i].lquery, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
             if (T.rqlen && !fz) k2 = BSW_BIN_R(bits == 16, has_n(tasks[i].rquery, T.rqlen), T.rqlen);
         };
         for (size_t i = 0; i < n; ++i) {

@@ -106,8 +106,8 @@ typedef struct bsw_binparams {
     /* second sort key of the LEFT sides inside a query length: the seed's h0 in BSW_H0_BUCKETS buckets over the chunk's range
      * [hb_lo, ...], bucket = ((h0 - hb_lo) * hb_mul) >> 16 (hb_mul = 0: one bucket) */
     int32_t hb_lo, hb_mul;
-    /* 1: a mid-sized chunk whose two sides run in ONE launch (bsw_lane2g_kernel, side 2): every 8-bit lane seed is on the LEFT
-     * lists, by its left query length (0: it has no left side), and no right list is filled */
+    /* != 0: a mid-sized chunk whose two sides run in ONE launch (1: bsw_lane2g_kernel, 2: bsw_lane2_kernel; side 2): every 8-bit lane
+     * seed is on the LEFT lists, by its left query length (0: it has no left side), and no 8-bit right list is filled */
     int32_t fused;
 } bsw_binparams;
 

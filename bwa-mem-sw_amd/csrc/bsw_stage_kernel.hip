@@ -236,7 +236,13 @@ __device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const ui
         s.k0 = BSW_BIN_LANEALL;
         const int nf = nflag ? (int)nflag[ti] : -1;
         const bool fz = bp.fused && bits == 8;       /* both sides of an 8-bit seed in one launch: on the left lists whatever its left side, on no right list */
-        if (T.lqlen || fz) s.k1 = BSW_BIN_L(bits == 16, nf >= 0 ? (nf & 1) : packed_has_n(seq, T.lq_off, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
+        /* (a fused launch runs both queries of a seed.  The group kernel's — fused == 1 — puts the seeds with an N in EITHER query in
+         * front, so that the other wavefronts hold no N in either half: 32 k PE seeds with Ns 1.10 -> 1.00 ms.  The lane kernel's
+         * — fused == 2 — keeps the left query's N alone as the key: a wavefront with an N in nearly every block of BOTH halves is
+         * the launch's longest, 131 k seeds 2.27 -> 3.0 ms; tools/diag/ab_nfirst.py) */
+        const int nmask = bp.fused == 1 ? 3 : 1;
+        if (fz) s.k1 = BSW_BIN_L(0, nf >= 0 ? ((nf & nmask) != 0) : (packed_has_n(seq, T.lq_off, T.lqlen) | (nmask == 3 ? packed_has_n(seq, T.rq_off, T.rqlen) : 0)), bsw_h0_bucket(&bp, T.h0), T.lqlen);
+        else if (T.lqlen) s.k1 = BSW_BIN_L(bits == 16, nf >= 0 ? (nf & 1) : packed_has_n(seq, T.lq_off, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
         if (T.rqlen && !fz) s.k2 = BSW_BIN_R(bits == 16, nf >= 0 ? ((nf >> 1) & 1) : packed_has_n(seq, T.rq_off, T.rqlen), T.rqlen);
     }
     return s;

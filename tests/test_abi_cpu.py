@@ -320,7 +320,7 @@ def test_auto_policy_fuses_the_two_sides_of_mid_sized_chunks(host):
     group kernel then starts at 1.5 M query bases over BOTH sides.  Up to LANE_FUSE_MAX (262 144) the lane kernels do the same
     (bsw_lane2_kernel's fused instantiation); larger chunks keep one list per side (plan only: no GPU)."""
     p = host.default_params()
-    spec = dict(seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.05)
+    spec = dict(seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.05, n_rate=0.002)
     t, a = host.synth_tasks(70000, seed=6, **spec)
     t["lqlen"][7::50] = 0                                                # some seeds without a left side
     both = lambda x: int((x["lqlen"].astype(np.int64) + x["rqlen"]).sum())
@@ -336,8 +336,14 @@ def test_auto_policy_fuses_the_two_sides_of_mid_sized_chunks(host):
     left = order[seg[9]:seg[17]]
     assert len(np.unique(left)) == has_side
     ql = t[:n_mid]["lqlen"][left].astype(np.int64)
-    nq = np.array([int((np.frombuffer(C.string_at(int(t[:n_mid]["lquery"][i]), int(t[:n_mid]["lqlen"][i])), dtype=np.uint8) >= 4).any()) if t[:n_mid]["lqlen"][i] else 0 for i in left])
-    for flag in (1, 0):                                                  # queries with an N first; inside each: longest left side first, length 0 last
+    tm = t[:n_mid]
+
+    def has_n(ptr, ln):
+        return bool(ln) and bool((np.frombuffer(C.string_at(int(ptr), int(ln)), dtype=np.uint8) >= 4).any())
+    nq = np.array([int(has_n(tm["lquery"][i], tm["lqlen"][i]) or has_n(tm["rquery"][i], tm["rqlen"][i])) for i in left])      # an N in EITHER query
+    assert 0.1 < nq.mean() < 0.5
+    assert (np.diff(nq) <= 0).all()                                      # the seeds with an N in either query sit in front
+    for flag in (1, 0):                                                  # seeds with an N in either query first; inside each: longest left side first, length 0 last
         part = ql[nq == flag]
         assert (np.diff(part) <= 0).all()
     n_big = 60000                                                        # past the group kernel's fused range: the lane kernels' fused launch (up to LANE_FUSE_MAX = 262 144)

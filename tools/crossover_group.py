@@ -14,6 +14,8 @@ host = graft.load_package().host
 p = host.default_params()
 wl, kern = sys.argv[1], int(sys.argv[2])
 spec = dict(seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.05) if wl == "pe_mixed" else {}
+if os.environ.get("CROSSOVER_N_RATE"):
+    spec["n_rate"] = float(os.environ["CROSSOVER_N_RATE"])          # (bench.py's workloads have 0.001)
 tasks, arena = host.synth_tasks(262144, seed=51, **spec)
 row = {}
 for n in (1024, 2048, 4096, 8192, 13104, 16384, 24576, 32768, 49152, 65536, 131072, 262144):
