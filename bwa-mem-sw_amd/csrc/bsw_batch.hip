@@ -23,7 +23,7 @@ static inline uint64_t thread_cpu_ns()
     return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
 
-BSW_LOCAL size_t order_capacity(size_t n) { return 4 * n + 16; }   /* upper bound of plan.order_len + the 2 + BSW_MAX_WAVE_CLASSES counters behind it */
+BSW_LOCAL size_t order_capacity(size_t n) { return 5 * n + 32; }   /* upper bound of plan.order_len (with the N list of bsw_binparams.nsplit) + the 3 + BSW_MAX_WAVE_CLASSES counters behind it */
 
 /* ---- host pass over a chunk: validate, lay out, count per class ------------------------------ */
 
@@ -168,6 +168,29 @@ BSW_LOCAL void plan_fused(batch_plan &pl, const bsw_binparams &bp, int fused_cls
         if (first) { pl.fused_off = pl.laneL_off[c]; first = false; }
         pl.fused_cnt += cl[c];
     }
+}
+
+/* See bsw_device.h (bsw_binparams.nsplit).  For chunks that do not fill the machine; BSW_NSPLIT = 0 / 1: never / every chunk with
+ * 8-bit lane seeds (measurements, tests).  The host does not know which queries hold an N (it never reads a base): the lists keep
+ * their counted sizes and the device leaves the places of the seeds it moved unfilled. */
+BSW_LOCAL bool nsplit_pays(int kern, const bsw_binparams &bp, bool packed_ok, uint32_t n8, bool streaming)
+{
+    static const int env = getenv("BSW_NSPLIT") ? atoi(getenv("BSW_NSPLIT")) : -1;
+    if (!bp.lane_on || !packed_ok || !n8 || env == 0) return false;
+    if (env == 1) return true;
+    return kern == BSW_KERNEL_AUTO && !streaming && n8 <= NSPLIT_MAX;
+}
+
+BSW_LOCAL void plan_nsplit(batch_plan &pl, bsw_binparams &bp, bool nsplit, uint32_t n_lane)
+{
+    pl.nsplit = nsplit ? 1 : 0;
+    bp.nsplit = pl.nsplit;
+    if (!nsplit) return;
+    pl.nlist_off = pl.order_len;                         /* behind the redo list */
+    pl.order_len += n_lane;
+    pl.nlist_cnt_at = pl.order_len + 2 + BSW_MAX_WAVE_CLASSES;      /* (behind the words enqueue_parts zeroes) */
+    bp.nlist_off = pl.nlist_off; bp.nlist_cap = n_lane; bp.nlist_cnt_at = pl.nlist_cnt_at;
+    bp.fill_off = pl.lane_all_off; bp.fill_len = pl.order_len - pl.lane_all_off;      /* the lane lists, the redo list, the N list */
 }
 
 /* tasks[0..n) -> dt[0..n) (device task records), ro[0..n) (gather layout of the raw bytes), class counts -> plan */
@@ -411,6 +434,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     pl.order_len = cur + n_lane;
     pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
     plan_fused(pl, bp, fused_cls, group, cl);
+    plan_nsplit(pl, bp, nsplit_pays(kern, bp, packed_ok, group ? n_lane : n_lane - n16, ci.streaming), n_lane);
     memcpy(pl.dep, dep, sizeof(pl.dep));
     memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
     bp.lane_all_off = pl.lane_all_off;
@@ -568,13 +592,14 @@ struct lane_job {
 static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, const fork_t *fk)
 {
     const int nc = bsw::wave_class_count(), nlc = bsw::lane_class_count();
+    bool nlist_side = false;                                       /* the N list's launch (bsw_binparams.nsplit) runs on a borrowed stream */
     for (int j = 0; j < nj; ++j) {
         const lane_job &J = jobs[j];
         const batch_plan &pl = *J.pl;
         /* device words behind the order lists: [0] the redo list's length, [1 + c] the work counter of wave class c's launch,
          * [1 + BSW_MAX_WAVE_CLASSES] the redo launch's — zeroed here, on the stream, before anything counts in them */
         uint32_t *redo_cnt = J.d_order + pl.order_len;
-        HIPCHK(e, hipMemsetAsync(redo_cnt, 0, (2 + BSW_MAX_WAVE_CLASSES) * sizeof(uint32_t), s));
+        HIPCHK(e, hipMemsetAsync(redo_cnt, 0, (2 + BSW_MAX_WAVE_CLASSES) * sizeof(uint32_t), s));      /* (the word behind them: the N list's length, plan.nlist_cnt_at) */
         /* The general-kernel classes of a part side by side (round 5).  A batch below the lane kernels' threshold is a few
          * thousand wavefronts in two or three classes (PE seeds: 64 / 128 / 192 columns); launched one after the other each class
          * leaves most of the machine idle for one wave's lifetime.  With idle streams at hand (the fork set of stream 0: resident
@@ -607,6 +632,24 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
                     HIPCHK(e, hipEventRecord(fk->ev_left[a], fk->aux[a]));
                     HIPCHK(e, hipStreamWaitEvent(s, fk->ev_left[a], 0));
                 }
+        if (pl.nsplit && pl.lane_all_cnt) {
+            /* bsw_binparams.nsplit: the lane seeds with an N in a query, one wavefront each, BESIDE the lane launches — on a borrowed
+             * stream, joined behind them (below); without one, in front of them on the slot stream */
+            const bool side = nj == 1 && fk && fk->ok && fk->naux > 0 && (fk->mode == 1 || fk->mode == 2);
+            hipStream_t ns = s;
+            if (side) {
+                /* (the FIRST borrowed stream: the last one shares a hardware queue with the slot stream — the list's launch then
+                 * ran in front of the lane launches instead of beside them, 16 k PE seeds 0.86 ms against 0.70) */
+                ns = fk->aux[0];
+                HIPCHK(e, hipEventRecord(fk->ev_fork_r, s));            /* the bins, the zeroed counters */
+                HIPCHK(e, hipStreamWaitEvent(ns, fk->ev_fork_r, 0));
+            }
+            HIPCHK(e, bsw::launch_wave(pl.redo_cls, J.variant, *J.P, J.d_seq, J.d_tasks, J.d_order + pl.nlist_off, pl.lane_all_cnt, J.d_order + pl.nlist_cnt_at, nullptr, J.d_out, ns));
+            if (J.d_pair) HIPCHK(e, bsw::launch_pairs_from_results(J.d_order + pl.nlist_off, pl.lane_all_cnt, J.d_order + pl.nlist_cnt_at, J.d_out, J.d_pair, ns));
+            if (side) HIPCHK(e, hipEventRecord(fk->ev_link[2 * BSW_MAX_LANE_CLASSES - 1], ns));
+            nlist_side = side;
+            if (J.launches) ++*J.launches;
+        }
     }
     /* Does every lane launch of a part run a kernel that finishes its seeds itself (bsw_fin: the launch that computes a seed's
      * last side takes the pair-level decision)?  Then bsw_pair_finalize is not launched for it: one launch and a 96-byte
@@ -629,7 +672,7 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
     int nchain = 0;
     bool chain_pays = false;
     bool any_group = false;
-    for (int j = 0; j < nj; ++j) any_group = any_group || jobs[j].pl->lane_group || jobs[j].pl->fused_cls >= 0;      /* (nor for a fused launch) */
+    for (int j = 0; j < nj; ++j) any_group = any_group || jobs[j].pl->lane_group || jobs[j].pl->fused_cls >= 0 || jobs[j].pl->nsplit;      /* (nor for a fused launch, nor beside the N list's) */
     if (fk && fk->mode == 2 && !any_group) {        /* (the group kernel's launches are short: nothing for a chain to fill) */
         bool fits = true;
         for (int side = 0; side < 2; ++side)
@@ -745,6 +788,7 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
         if (d_pair) HIPCHK(e, bsw::launch_pairs_from_results(d_order + pl.redo_off, pl.lane_all_cnt, redo_cnt, d_out, d_pair, s));
         if (launches) *launches += folded ? 1 : 2;
     }
+    if (nlist_side) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_link[2 * BSW_MAX_LANE_CLASSES - 1], 0));       /* join: the N list's launch */
     return BSW_OK;
 }
 
@@ -857,6 +901,7 @@ extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, si
             const int bits = bsw_seed_lane_bits(&bp, T.lqlen, T.rqlen, T.h0);
             if (!bits) { k0 = BSW_BIN_WAVE0 + bsw_wave_class_of(&bp, std::max(T.lqlen, T.rqlen)); return; }
             k0 = BSW_BIN_LANEALL;
+            if (bp.nsplit && bits == 8 && (has_n(tasks[i].lquery, T.lqlen) | has_n(tasks[i].rquery, T.rqlen))) { k0 = BSW_BIN_NLIST; return; }
             const bool fz = bp.fused && bits == 8;
             if (fz) k1 = BSW_BIN_L(0, has_n(tasks[i].lquery, T.lqlen) | (bp.fused == 1 ? has_n(tasks[i].rquery, T.rqlen) : 0), bsw_h0_bucket(&bp, T.h0), T.lqlen);
             else if (T.lqlen) k1 = BSW_BIN_L(bits == 16, has_n(tasks[i].lquery, T.lqlen), bsw_h0_bucket(&bp, T.h0), T.lqlen);
@@ -884,6 +929,8 @@ extern "C" int64_t bsw_plan_batch(const bsw_params *p, const bsw_task *tasks, si
             }
         for (int c = 0; c < bp.n_wave; ++c) cur[(size_t)(BSW_BIN_WAVE0 + c)] = bp.wave_start[c];
         cur[BSW_BIN_LANEALL] = bp.lane_all_off;
+        cur[BSW_BIN_NLIST] = bp.nlist_off;
+        if (bp.nsplit) for (uint32_t q = 0; q < bp.fill_len; ++q) order[bp.fill_off + q] = BSW_ORDER_NONE;
         for (size_t i = 0; i < n; ++i) {
             int k0, k1, k2;
             keys(i, k0, k1, k2);

@@ -109,7 +109,15 @@ typedef struct bsw_binparams {
     /* != 0: a mid-sized chunk whose two sides run in ONE launch (1: bsw_lane2g_kernel, 2: bsw_lane2_kernel; side 2): every 8-bit lane
      * seed is on the LEFT lists, by its left query length (0: it has no left side), and no 8-bit right list is filled */
     int32_t fused;
+    /* 1: a chunk that does not fill the machine — its launches last as long as their slowest wavefront, and a wavefront of the
+     * two-seeds-per-lane kernels that holds queries with an N runs 1.6 - 2x as long as the others (its N bodies are cold code,
+     * meant for a stray block).  The 8-bit lane seeds with an N in either query then go on a list of their own, order[nlist_off ..],
+     * for the general kernel (one wavefront per seed, N or not), and sit on no lane list; the lists' unused tails hold
+     * 0xffffffff (BSW_ORDER_NONE).  The list's length is left in order[nlist_cnt_at]. */
+    int32_t nsplit;
+    uint32_t nlist_off, nlist_cap, nlist_cnt_at, fill_off, fill_len;
 } bsw_binparams;
+#define BSW_ORDER_NONE 0xffffffffu
 
 /* The lanes of a wave walk their rows in lockstep over the UNION of their [beg, end) ranges, and h0 sets how fast a seed's
  * range opens (end ~ 2 i + h0 - o) and where its beg runs later: seeds of one query length but h0 = 19 .. 60 spread their range ends

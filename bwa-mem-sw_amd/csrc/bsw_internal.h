@@ -69,6 +69,9 @@ inline bool lane_bins_pay(uint32_t n_lane, const uint32_t *cl, const uint32_t *c
 #define LANE_WORK_MIN  5000000ull
 #define GROUP_FUSE_MAX 49152u        /* 8-bit lane seeds up to which a group chunk runs both sides in one launch (fuse_lists): 3 waves per SIMD */
 #define LANE_FUSE_MAX  262144u       /* ... and a lane-kernel chunk (bsw_lane2_kernel<17, 2, ., ., true>): 2 waves per SIMD */
+#define NSPLIT_MAX     131072u       /* lane seeds up to which a chunk's queries with an N go to the general kernel (bsw_binparams.nsplit):
+                                        262 144 PE seeds with an N in one query of nine — bench.py's generator, ten times a sequencer's
+                                        rate — would put 58 k seeds on one wavefront each (3.5 ms where the lane kernels alone take 2.3) */
 #define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
 #define RAW_FRONT 32                 /* ... and in front of the first one (reversed left queries) */
 
@@ -87,6 +90,9 @@ struct batch_plan {
                                         else bsw_lane2_kernel's fused instantiation) of this class — it holds every side of the chunk —
                                         over order[fused_off .. fused_off + fused_cnt): all 8-bit left lists */
     uint32_t fused_off = 0, fused_cnt = 0;
+    int nsplit = 0;                  /* 1: the chunk's 8-bit lane seeds with an N in a query sit on order[nlist_off ..] for the general kernel
+                                        (bsw_binparams.nsplit); their number: the device word order[nlist_cnt_at] */
+    uint32_t nlist_off = 0, nlist_cnt_at = 0;
     /* dep[lc] bit rc: some seed has its left side in lane class lc and its right side in lane class rc — the right-side
      * launch of class rc then has to wait for the left-side launch of class lc (h0 of the right extension is the score
      * after the left one, sw_pe_array_proc_element.v:1671).  All ones = not known. */
@@ -346,6 +352,10 @@ BSW_LOCAL size_t order_capacity(size_t n);
  * packed_ok: the scoring parameters allow the packed kernels).  Returns the class for the launch, -1: not fused (lists untouched). */
 BSW_LOCAL int fuse_lists(bsw_binparams &bp, int kern, bool group, bool packed_ok, uint32_t n8, uint32_t *cl, uint32_t *cr, bool streaming = false);
 BSW_LOCAL void plan_fused(batch_plan &pl, const bsw_binparams &bp, int fused_cls, bool group, const uint32_t *cl);
+/* bsw_binparams.nsplit for a chunk (policy), and the N list's place behind the redo list once pl.redo_off / pl.order_len are set
+ * (order_len grows by the list; call before bp's offsets are copied from the plan) */
+BSW_LOCAL bool nsplit_pays(int kern, const bsw_binparams &bp, bool packed_ok, uint32_t n8, bool streaming);
+BSW_LOCAL void plan_nsplit(batch_plan &pl, bsw_binparams &bp, bool nsplit, uint32_t n_lane);
 BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint32_t &n_lane, uint32_t n16, uint32_t *cl, uint32_t *cr,
                                 uint32_t *cw, const uint32_t *cw16, uint8_t *dep, uint64_t work8_l, uint64_t work8_r, bool streaming = false);
 BSW_LOCAL int fill_binparams(errs &e, const bsw_params *p, int kern, bsw_binparams &bp);

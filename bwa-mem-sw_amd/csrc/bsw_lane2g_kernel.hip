@@ -130,8 +130,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2g_kernel(const bsw_dparams 
     l2::sfor<2>([&](auto xi) {
         constexpr int x = decltype(xi)::value;
         const uint32_t slot = w16s + (uint32_t)grp + 8u * x;
-        valid[x] = slot < n;
-        ti[x] = valid[x] ? order[slot] : order[0];
+        const uint32_t oslot = slot < n ? order[slot] : BSW_ORDER_NONE;
+        valid[x] = oslot != BSW_ORDER_NONE;                          /* (a list's unused tail: bsw_binparams.nsplit) */
+        ti[x] = valid[x] ? oslot : 0u;
         const bsw_dtask T = tasks[ti[x]];
         int qlen, tlen, wlim, h0;
         uint32_t q_off;

@@ -234,8 +234,9 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
     l2::sfor<2>([&](auto xi) {
         constexpr int x = decltype(xi)::value;
         const uint32_t slot = w0 + 64u * x;
-        valid[x] = slot < n;
-        ti[x] = valid[x] ? order[slot] : order[0];
+        const uint32_t oslot = slot < n ? order[slot] : BSW_ORDER_NONE;
+        valid[x] = oslot != BSW_ORDER_NONE;                          /* (a list's unused tail: bsw_binparams.nsplit) */
+        ti[x] = valid[x] ? oslot : 0u;
         const bsw_dtask T = tasks[ti[x]];
         int qlen, tlen, wlim, h0;
         uint32_t q_off;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256, WPS) void bsw_lane2l_kernel(const bsw_dparams 
             qlen = T.rqlen; tlen = T.rtlen; wlim = T.wlim_r; q_off = T.rq_off; t_off[x] = T.rt_off;
             h0 = T.lqlen > 0 ? out[ti[x]].left.score : T.h0;          /* h0 = score after the left ext (:1671) */
         }
-        if (!valid[x]) tlen = 0;
+        if (!valid[x]) { tlen = 0; qlen = 1; q_off = 0; t_off[x] = 0; }      /* (task 0's record stands in: it need not have this side) */
         ntw[x] = (tlen + 15) >> 4;
         l2::init_pair(S.p, x, qlen, tlen, h0, min(P.w, wlim));
         uint32_t mb[4][NW];

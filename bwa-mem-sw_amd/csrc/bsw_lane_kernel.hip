@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) void bsw_pair_finalize(const bsw_dparams P, co
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     if (slot >= n) return;
     const uint32_t ti = order[slot];
+    if (ti == BSW_ORDER_NONE) return;                       /* (a list's unused tail: bsw_binparams.nsplit) */
     const bsw_dtask T = tasks[ti];
     const bsw_result r = out[ti];
     bsw_pair_decide(P, T, ti, r.left, r.right, out, redo, redo_cnt, pairs);

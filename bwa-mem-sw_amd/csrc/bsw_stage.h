@@ -15,6 +15,7 @@
 #define BSW_BIN_R(b16, has_n, q) (BSW_BIN_R0 + ((b16) * 2 + (has_n)) * BSW_LANE_QBINS + (q))
 #define BSW_BIN_WAVE0   (BSW_BIN_R0 + 2 * 2 * BSW_LANE_QBINS)
 #define BSW_BIN_LANEALL (BSW_BIN_WAVE0 + BSW_MAX_WAVE_CLASSES)
+#define BSW_BIN_NLIST   (BSW_BIN_LANEALL + 1)     /* bsw_binparams.nsplit: the 8-bit lane seeds with an N in a query (general kernel) */
 #define BSW_BIN_WORDS   (BSW_BIN_LANEALL + 8)
 
 /* where a task's nibble stream starts inside the uploaded wire batches (256 batches x 65 536 words x 8 nibbles = 2^27), where

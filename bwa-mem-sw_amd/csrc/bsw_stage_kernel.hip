@@ -235,6 +235,10 @@ __device__ __forceinline__ seed_bins seed_keys(const bsw_binparams &bp, const ui
     } else {
         s.k0 = BSW_BIN_LANEALL;
         const int nf = nflag ? (int)nflag[ti] : -1;
+        if (bp.nsplit && bits == 8 && (nf >= 0 ? (nf & 3) != 0 : (packed_has_n(seq, T.lq_off, T.lqlen) | packed_has_n(seq, T.rq_off, T.rqlen)) != 0)) {
+            s.k0 = BSW_BIN_NLIST;               /* (bsw_binparams.nsplit) */
+            return s;
+        }
         const bool fz = bp.fused && bits == 8;       /* both sides of an 8-bit seed in one launch: on the left lists whatever its left side, on no right list */
         /* (a fused launch runs both queries of a seed.  The group kernel's — fused == 1 — puts the seeds with an N in EITHER query in
          * front, so that the other wavefronts hold no N in either half: 32 k PE seeds with Ns 1.10 -> 1.00 ms.  The lane kernel's
@@ -315,7 +319,13 @@ __global__ __launch_bounds__(256) void bsw_bin_scan(const bsw_binparams bp, uint
             }
         }
     if (t < bp.n_wave) bins[BSW_BIN_WAVE0 + t] = bp.wave_start[t];
-    if (t == 0) bins[BSW_BIN_LANEALL] = bp.lane_all_off;
+    if (t == 0) { bins[BSW_BIN_LANEALL] = bp.lane_all_off; bins[BSW_BIN_NLIST] = bp.nlist_off; }
+}
+
+/* bsw_binparams.nsplit: the N list's length where the general kernel's launch reads it */
+__global__ void bsw_nlist_count(const uint32_t *__restrict__ bins, const uint32_t nlist_off, uint32_t *__restrict__ dst)
+{
+    *dst = bins[BSW_BIN_NLIST] - nlist_off;
 }
 
 /* BSW_SCATTER_TPT tasks per thread: the two passes over the cursor table (9 232 words) are shared by 1 024 tasks.  The class
@@ -491,10 +501,12 @@ hipError_t launch_bin(const bsw_binparams &bp, const uint64_t *seq, const uint8_
     if (n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(bins, 0, BSW_BIN_WORDS * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
+    if (bp.nsplit && bp.fill_len && (e = hipMemsetAsync(order + bp.fill_off, 0xff, (size_t)bp.fill_len * sizeof(uint32_t), s)) != hipSuccess) return e;
     const uint32_t blocks = (n + 255u) / 256u, sblocks = (n + 256u * BSW_SCATTER_TPT - 1u) / (256u * BSW_SCATTER_TPT);
     hipLaunchKernelGGL(bsw_bin_count, dim3(blocks > 2048u ? 2048u : blocks), dim3(256), 0, s, bp, seq, nflag, tasks, n, bins, keys);
     hipLaunchKernelGGL(bsw_bin_scan, dim3(1), dim3(256), 0, s, bp, bins);
     hipLaunchKernelGGL(bsw_bin_scatter, dim3(sblocks), dim3(256), 0, s, keys, n, bins, order);
+    if (bp.nsplit) hipLaunchKernelGGL(bsw_nlist_count, dim3(1), dim3(1), 0, s, bins, bp.nlist_off, order + bp.nlist_cnt_at);
     return hipGetLastError();
 }
 

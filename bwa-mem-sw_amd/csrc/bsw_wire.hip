@@ -213,6 +213,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
     pl.redo_off = cur; pl.order_len = cur + n_lane;
     pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
     plan_fused(pl, bp, fused_cls, group, cl);
+    plan_nsplit(pl, bp, nsplit_pays(ctx->cfg.kernel, bp, packed_ok, group ? n_lane : n_lane - n16, false), n_lane);
     /* (pl.dep stays all ones: the wire-format groups run their classes on one stream) */
     memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
     bp.lane_all_off = pl.lane_all_off;

@@ -611,7 +611,7 @@ PLAN_SEGS = 26
 def plan_batch(params, tasks, kernel=KERNEL_AUTO, pack_threads=1):
     """Batch manager's launch plan for a task batch (host only; the order is the host replay of the device's
     binning rules).  Returns (order, seg, seq_words)."""
-    order = np.zeros(4 * len(tasks) + 16, dtype=np.uint32)
+    order = np.zeros(5 * len(tasks) + 32, dtype=np.uint32)
     seg = np.zeros(PLAN_SEGS + 1, dtype=np.uint32)
     w = lib().bsw_plan_batch(params.ctypes.data, tasks.ctypes.data, len(tasks), kernel, pack_threads, order.ctypes.data, seg.ctypes.data)
     if w < 0:

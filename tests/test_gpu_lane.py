@@ -394,14 +394,16 @@ def test_group_kernel_runs_both_sides_of_a_seed_in_one_launch(host, oracle, read
         lane_mode = n8 > 49152                                            # (the 16-bit seeds then sit in the 16-bit lane class, not in the wave classes)
         w16 = tasks["h0"] == 300
         n16l, n16r = (int((w16 & (tasks["lqlen"] > 0)).sum()), int((w16 & (tasks["rqlen"] > 0)).sum())) if lane_mode else (0, 0)
-        assert seg[17] - seg[9] == n8 + n16l and seg[25] - seg[17] == n16r          # every 8-bit lane seed on the left lists, on no right list
+        assert seg[17] - seg[9] == n8 + n16l and seg[25] - seg[17] == n16r          # a place for every 8-bit lane seed on the left lists, none on a right list
         left = order[seg[9]:seg[17]]
-        assert len(np.unique(left[~w16[left]])) == n8
+        left = left[left != 0xffffffff]                                   # (the seeds with an N in a query are on the general kernel's N list: bsw_binparams.nsplit)
+        nsplit = int(n8 - len(np.unique(left[~w16[left]])))
+        assert 0 < nsplit < n8 // 2
         want = oracle.pair_batch(p, tasks, nthreads=8)
         with host.BswContext(device=0) as c:
             b = c.upload(p, tasks); c.run(b); got = c.download(b)
             nwave = int(sum(1 for k in range(8) if seg[k + 1] - seg[k]))
-            assert b.info()["launches"] == nwave + 2 + (2 + 1 if lane_mode else 0)       # the general classes, ONE fused launch, the redo launch (+ the 16-bit class: two sides, bsw_pair_finalize)
+            assert b.info()["launches"] == nwave + 3 + (2 + 1 if lane_mode else 0)       # the general classes, the N list, ONE fused launch, the redo launch (+ the 16-bit class: two sides, bsw_pair_finalize)
             b.free()
             assert_same(got, want, tasks)
             assert_same(c.extend_pairs(p, tasks), want, tasks)            # the same through a submit (one chunk)
@@ -411,3 +413,32 @@ def test_group_kernel_runs_both_sides_of_a_seed_in_one_launch(host, oracle, read
             gp = c.extend_pairs(p, tasks)
             for f in ("tag", "qb", "qe", "rb", "re", "score", "truesc", "w"):
                 assert (gp[f] == want[f]).all(), f
+
+
+@pytest.mark.parametrize("n", [20_000, 60_000])
+def test_queries_with_an_n_leave_the_lane_lists_of_a_chunk_that_does_not_fill_the_machine(host, oracle, n):
+    """bsw_binparams.nsplit (BSW_KERNEL_AUTO, up to NSPLIT_MAX lane seeds, not for chunks of a streaming submit): a launch that does
+    not fill the machine lasts as long as its slowest wavefront, and a wavefront of the two-seeds-per-lane kernels whose queries
+    hold Ns runs 1.6 - 2x as long as the others.  The 8-bit lane seeds with an N in a query go on a list of their own for the
+    general kernel (beside the lane launches); the lane lists keep their counted sizes, unused tails marked.  One-sided seeds
+    (nothing to fuse): 20 000 run the group kernel, 60 000 the lane kernels.  Bytes, packed and pair-record paths."""
+    tasks, arena = host.synth_tasks(n, seed=23, sub_rate=0.02, indel_rate=0.005, junk_frac=0.05, n_rate=0.003)
+    p = host.default_params()
+    order, seg, _ = host.plan_batch(p, tasks, kernel=host.KERNEL_AUTO)
+    right = order[seg[17]:seg[25]]
+    hn = _gen.query_has_n(tasks, arena, 1)
+    kept = right[right != 0xffffffff]
+    assert 0 < hn.sum() < n // 2 and len(kept) == n - int(hn.sum()) and not hn[kept].any()
+    want = oracle.pair_batch(p, tasks, nthreads=8)
+    with host.BswContext(device=0) as c:
+        b = c.upload(p, tasks); c.run(b); got = c.download(b)
+        assert b.info()["launches"] == 3                                  # the N list, the right sides, the redo launch
+        b.free()
+        assert_same(got, want, tasks)
+        assert_same(c.extend_pairs(p, tasks), want, tasks)
+        pt, pwords = host.pack_tasks(tasks)
+        assert_same(c.extend_pairs_packed(p, pt), want, tasks)
+    with host.BswContext(device=0, result_format=host.RESULT_PAIR) as c:
+        gp = c.extend_pairs(p, tasks)
+        for f in ("tag", "qb", "qe", "rb", "re", "score", "truesc", "w"):
+            assert (gp[f] == want[f]).all(), f

@@ -35,7 +35,7 @@ out = {}
 for wl in ("pe_mixed", "single_bin"):
     out[wl] = {}
     modes = (("general_ms", 1, {}), ("group_ms", 0, {"BSW_GROUP": "1", "BSW_GROUP_FUSE": "0"}), ("group_fused_ms", 0, {"BSW_GROUP": "1", "BSW_GROUP_FUSE": "1"}),
-             ("lane_ms", 2, {"BSW_GROUP": "0", "BSW_LANE_FUSE": "0"}), ("lane_fused_ms", 2, {"BSW_GROUP": "0", "BSW_LANE_FUSE": "1"}), ("auto_ms", 0, {}))
+             ("lane_ms", 2, {"BSW_GROUP": "0", "BSW_LANE_FUSE": "0"}), ("lane_fused_ms", 2, {"BSW_GROUP": "0", "BSW_LANE_FUSE": "1"}), ("auto_ms", 0, {}), ("auto_nosplit_ms", 0, {"BSW_NSPLIT": "0"}))
     if len(sys.argv) > 1:
         modes = tuple(m for m in modes if m[0] in sys.argv[1:])
     for name, kern, env in modes:
