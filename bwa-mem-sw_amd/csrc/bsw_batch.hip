@@ -95,21 +95,24 @@ BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint
     /* what the group kernel's launch holds: one side's seeds — or, for a chunk that fuse_group_lists will fuse, both sides of
      * every seed (one wave lifetime for the pair: the general kernels lose from ~13 k PE seeds, profiles/r6/crossover_group.json) */
     static const int fenv = getenv("BSW_GROUP_FUSE") ? atoi(getenv("BSW_GROUP_FUSE")) : -1;
-    const bool fusable = fenv != 0 && work8_l && work8_r && (fenv == 1 || n8 <= GROUP_FUSE_MAX);
+    int cmax8 = -1;
+    for (int c = 0; c < bp.n_lane && c < BSW_MAX_LANE_CLASSES; ++c)
+        if (bp.lane_bits[c] == 8 && (cl[c] || cr[c])) cmax8 = c;
+    const bool wide = cmax8 >= 0 && bp.lane_cols[cmax8] > 136;         /* sides beyond 136 columns (250 bp reads): the lane kernels have no fused form */
+    const bool fusable = fenv != 0 && work8_l && work8_r && (fenv == 1 || n8 <= group_fuse_max(wide));
     const uint64_t work_g = fusable ? work8_l + work8_r : work;
     /* ... and past the group kernel's fused range the LANE kernels run such a chunk in one launch (bsw_lane2_kernel's fused
      * instantiation, 136 columns: 1.2 - 1.7 ms for 65 k - 262 k PE seeds where two lane launches take 2.0 and two group launches
      * 1.4 - 4.0, profiles/r6/crossover_group.json): lane bins from LANE_WORK_MIN bases over both sides */
     static const int lenv = getenv("BSW_LANE_FUSE") ? atoi(getenv("BSW_LANE_FUSE")) : -1;
-    int cmax8 = -1;
-    for (int c = 0; c < bp.n_lane && c < BSW_MAX_LANE_CLASSES; ++c)
-        if (bp.lane_bits[c] == 8 && (cl[c] || cr[c])) cmax8 = c;
-    const bool lane_fusable = group_ok && lenv != 0 && !fusable && (!streaming || lenv == 1) && work8_l && work8_r && n8 <= LANE_FUSE_MAX && cmax8 >= 0 && bp.lane_cols[cmax8] <= 136;
+    const bool lane_fusable = group_ok && lenv != 0 && !fusable && (!streaming || lenv == 1) && work8_l && work8_r && n8 <= LANE_FUSE_MAX && cmax8 >= 0 && !wide;
     bool group = false;
     if (genv == 1) group = group_ok && n8 > 0 && kern != BSW_KERNEL_WAVE;
     else if (kern == BSW_KERNEL_AUTO) {
+        /* (a chunk the group kernel runs fused stays with it whatever its work: 250 bp reads, 49 k seeds 2.8 ms fused against 5.9
+         * for the lane kernels' four chained launches, profiles/r6/crossover_group_250bp.json) */
         const bool lane = genv == 0 || !group_ok ? lane_bins_pay(n_lane, cl, cr)
-                                                 : (work >= LANE_WORK_MIN || lane_bins_pay(n16, cl, cr) || (lane_fusable && work8_l + work8_r >= LANE_WORK_MIN));
+                                                 : ((!fusable && work >= LANE_WORK_MIN) || lane_bins_pay(n16, cl, cr) || (lane_fusable && work8_l + work8_r >= LANE_WORK_MIN));
         if (!lane) {
             group = genv != 0 && group_ok && work_g >= GROUP_WORK_MIN;
             if (!group) { bp.lane_on = 0; return false; }
@@ -136,7 +139,7 @@ BSW_LOCAL int fuse_lists(bsw_binparams &bp, int kern, bool group, bool packed_ok
     static const int genv = getenv("BSW_GROUP_FUSE") ? atoi(getenv("BSW_GROUP_FUSE")) : -1;
     static const int lenv = getenv("BSW_LANE_FUSE") ? atoi(getenv("BSW_LANE_FUSE")) : -1;
     const int fenv = group ? genv : lenv;
-    if (!bp.lane_on || !packed_ok || fenv == 0 || (fenv != 1 && n8 > (group ? GROUP_FUSE_MAX : LANE_FUSE_MAX))) return -1;
+    if (!bp.lane_on || !packed_ok || fenv == 0) return -1;
     if (!group && fenv != 1 && (kern != BSW_KERNEL_AUTO || streaming)) return -1;      /* (forced lane bins keep a list per side: BSW_KERNEL_LANE is what the tests of that path use) */
     int cmax = -1;
     uint32_t nl = 0, nr = 0;
@@ -145,6 +148,7 @@ BSW_LOCAL int fuse_lists(bsw_binparams &bp, int kern, bool group, bool packed_ok
         if (cl[c] || cr[c]) cmax = c;
         nl += cl[c]; nr += cr[c];
     }
+    if (fenv != 1 && n8 > (group ? group_fuse_max(cmax >= 0 && bp.lane_cols[cmax] > 136) : LANE_FUSE_MAX)) return -1;
     const int c0 = bsw_side_lane_class(&bp, 8, 0);
     if (cmax < 0 || c0 < 0 || !nl || !nr || nl > n8) return -1;       /* (a one-sided chunk has nothing to fuse) */
     if (bp.lane_cols[cmax] > (group ? 256 : 136)) return -1;           /* (the lane kernels: bsw_lane2_kernel<17>; the 232-column class has no fused form) */
@@ -363,7 +367,7 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
                 ++A.cl[c];
                 A.lane_work[c] += (uint64_t)t.lqlen;
                 if (bits == 8) A.work8_l += (uint64_t)t.lqlen;
-                A.h0_lo = std::min(A.h0_lo, t.h0); A.h0_hi = std::max(A.h0_hi, t.h0);
+                if (bits == 8) { A.h0_lo = std::min(A.h0_lo, t.h0); A.h0_hi = std::max(A.h0_hi, t.h0); }      /* (the 8-bit seeds': a few 16-bit ones — h0 in the hundreds — would widen the buckets to nothing) */
             }
             if (t.rqlen) {
                 const int c = lane_cls(bits, t.rqlen);
@@ -638,15 +642,15 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
             const bool side = nj == 1 && fk && fk->ok && fk->naux > 0 && (fk->mode == 1 || fk->mode == 2);
             hipStream_t ns = s;
             if (side) {
-                /* (the FIRST borrowed stream: the last one shares a hardware queue with the slot stream — the list's launch then
+                /* (NOT the last borrowed stream: it shares a hardware queue with the slot stream — the list's launch then
                  * ran in front of the lane launches instead of beside them, 16 k PE seeds 0.86 ms against 0.70) */
-                ns = fk->aux[0];
+                ns = fk->aux[fk->naux > 1 ? 1 : 0];                   /* (the second: a launch chain's first follower takes the first) */
                 HIPCHK(e, hipEventRecord(fk->ev_fork_r, s));            /* the bins, the zeroed counters */
                 HIPCHK(e, hipStreamWaitEvent(ns, fk->ev_fork_r, 0));
             }
             HIPCHK(e, bsw::launch_wave(pl.redo_cls, J.variant, *J.P, J.d_seq, J.d_tasks, J.d_order + pl.nlist_off, pl.lane_all_cnt, J.d_order + pl.nlist_cnt_at, nullptr, J.d_out, ns));
             if (J.d_pair) HIPCHK(e, bsw::launch_pairs_from_results(J.d_order + pl.nlist_off, pl.lane_all_cnt, J.d_order + pl.nlist_cnt_at, J.d_out, J.d_pair, ns));
-            if (side) HIPCHK(e, hipEventRecord(fk->ev_link[2 * BSW_MAX_LANE_CLASSES - 1], ns));
+            if (side) HIPCHK(e, hipEventRecord(fk->ev_nlist, ns));
             nlist_side = side;
             if (J.launches) ++*J.launches;
         }
@@ -672,7 +676,7 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
     int nchain = 0;
     bool chain_pays = false;
     bool any_group = false;
-    for (int j = 0; j < nj; ++j) any_group = any_group || jobs[j].pl->lane_group || jobs[j].pl->fused_cls >= 0 || jobs[j].pl->nsplit;      /* (nor for a fused launch, nor beside the N list's) */
+    for (int j = 0; j < nj; ++j) any_group = any_group || jobs[j].pl->lane_group || jobs[j].pl->fused_cls >= 0;      /* (nor for a fused launch) */
     if (fk && fk->mode == 2 && !any_group) {        /* (the group kernel's launches are short: nothing for a chain to fill) */
         bool fits = true;
         for (int side = 0; side < 2; ++side)
@@ -788,7 +792,7 @@ static int enqueue_parts(errs &e, const lane_job *jobs, int nj, hipStream_t s, c
         if (d_pair) HIPCHK(e, bsw::launch_pairs_from_results(d_order + pl.redo_off, pl.lane_all_cnt, redo_cnt, d_out, d_pair, s));
         if (launches) *launches += folded ? 1 : 2;
     }
-    if (nlist_side) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_link[2 * BSW_MAX_LANE_CLASSES - 1], 0));       /* join: the N list's launch */
+    if (nlist_side) HIPCHK(e, hipStreamWaitEvent(s, fk->ev_nlist, 0));       /* join: the N list's launch */
     return BSW_OK;
 }
 

@@ -172,6 +172,7 @@ static void ctx_release(bsw_ctx *ctx)
                 if (f.mode == 1) for (auto a : f.aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }      /* (mode 2 borrows the slot streams) */
                 if (f.ev_fork) (void)hipEventDestroy(f.ev_fork);
                 if (f.ev_fork_r) (void)hipEventDestroy(f.ev_fork_r);
+                if (f.ev_nlist) (void)hipEventDestroy(f.ev_nlist);
                 if (f.flag_mem) (void)hipFree(f.flag_mem);
                 for (auto ev : f.ev_left) if (ev) (void)hipEventDestroy(ev);
                 for (auto ev : f.ev_right) if (ev) (void)hipEventDestroy(ev);
@@ -342,7 +343,8 @@ extern "C" int bsw_create_sized(const bsw_config *cfg, size_t cfg_size, bsw_ctx 
                  * creation order, and every pipeline leg of bench.py lost 5 - 20 % when that happened, gpurun_out/r7g) */
                 for (int a = 0; a < BSW_FORK_AUX && good && f.mode == 1; ++a) good = hipStreamCreateWithPriority(&f.aux[a], hipStreamNonBlocking, least) == hipSuccess;
                 good = good && hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming) == hipSuccess &&
-                       hipEventCreateWithFlags(&f.ev_fork_r, hipEventDisableTiming) == hipSuccess;
+                       hipEventCreateWithFlags(&f.ev_fork_r, hipEventDisableTiming) == hipSuccess &&
+                       hipEventCreateWithFlags(&f.ev_nlist, hipEventDisableTiming) == hipSuccess;
                 for (int c = 0; c < BSW_MAX_LANE_CLASSES && good; ++c)
                     good = hipEventCreateWithFlags(&f.ev_left[c], hipEventDisableTiming) == hipSuccess &&
                            hipEventCreateWithFlags(&f.ev_right[c], hipEventDisableTiming) == hipSuccess;

@@ -68,6 +68,9 @@ inline bool lane_bins_pay(uint32_t n_lane, const uint32_t *cl, const uint32_t *c
 #define GROUP_WORK_MIN 1500000ull
 #define LANE_WORK_MIN  5000000ull
 #define GROUP_FUSE_MAX 49152u        /* 8-bit lane seeds up to which a group chunk runs both sides in one launch (fuse_lists): 3 waves per SIMD */
+#define GROUP_FUSE_MAX_WIDE 98304u   /* ... when the chunk has sides beyond 136 columns (250 bp reads): the lane kernels then need four chained launches,
+                                        5.7 - 6.0 ms, and the fused group launch stays ahead up to ~110 k seeds (65 k: 3.5 ms, 131 k: 6.4) */
+inline uint32_t group_fuse_max(bool wide) { return wide ? GROUP_FUSE_MAX_WIDE : GROUP_FUSE_MAX; }
 #define LANE_FUSE_MAX  262144u       /* ... and a lane-kernel chunk (bsw_lane2_kernel<17, 2, ., ., true>): 2 waves per SIMD */
 #define NSPLIT_MAX     131072u       /* lane seeds up to which a chunk's queries with an N go to the general kernel (bsw_binparams.nsplit):
                                         262 144 PE seeds with an N in one query of nine — bench.py's generator, ten times a sequencer's
@@ -211,6 +214,7 @@ struct stage_t {
 #define BSW_FORK_AUX (BSW_MAX_LANE_CLASSES - 1)
 struct fork_t {
     hipStream_t aux[BSW_FORK_AUX] = {nullptr};
+    hipEvent_t ev_nlist = nullptr;    /* behind the N list's launch on a borrowed stream (bsw_binparams.nsplit; forked off at ev_fork_r) */
     hipEvent_t ev_fork = nullptr, ev_fork_r = nullptr, ev_left[BSW_MAX_LANE_CLASSES] = {nullptr}, ev_right[BSW_MAX_LANE_CLASSES] = {nullptr};
     hipEvent_t ev_link[2 * BSW_MAX_LANE_CLASSES] = {nullptr};    /* mode 2: one per link of the chain */
     /* mode 2 (tail fill): a chunk's lane launches form a chain, each released when EVERY workgroup of the one before it

@@ -169,7 +169,7 @@ static int refbatch_enqueue(bsw_ctx *ctx, errs &e, size_t q0, size_t q1, int var
                     const uint8_t *lc = bits == 8 ? lcls8 : lcls16;
                     ++pt.n_lane;
                     if (bits == 16) { ++pt.n16; ++pt.cw16[wc]; }
-                    if (lq) { ++pt.cl[lc[lq]]; pt.h0_lo = std::min(pt.h0_lo, h0); pt.h0_hi = std::max(pt.h0_hi, h0); }
+                    if (lq) { ++pt.cl[lc[lq]]; if (bits == 8) { pt.h0_lo = std::min(pt.h0_lo, h0); pt.h0_hi = std::max(pt.h0_hi, h0); } }
                     if (rq) ++pt.cr[lc[rq]];
                     if (bits == 8) { pt.w8l += (uint64_t)lq; pt.w8r += (uint64_t)rq; }
                 }

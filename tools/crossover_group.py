@@ -14,6 +14,11 @@ host = graft.load_package().host
 p = host.default_params()
 wl, kern = sys.argv[1], int(sys.argv[2])
 spec = dict(seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.05) if wl == "pe_mixed" else {}
+if os.environ.get("CROSSOVER_READ_LEN"):                            # e.g. 250: BASELINE configs[4] (w = 500)
+    spec["read_len"] = int(os.environ["CROSSOVER_READ_LEN"])
+    if spec["read_len"] > 200:
+        spec["w"] = 500
+        p = host.default_params(w=500)
 if os.environ.get("CROSSOVER_N_RATE"):
     spec["n_rate"] = float(os.environ["CROSSOVER_N_RATE"])          # (bench.py's workloads have 0.001)
 tasks, arena = host.synth_tasks(262144, seed=51, **spec)
