@@ -114,7 +114,7 @@ BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint
         const bool lane = genv == 0 || !group_ok ? lane_bins_pay(n_lane, cl, cr)
                                                  : ((!fusable && work >= LANE_WORK_MIN) || lane_bins_pay(n16, cl, cr) || (lane_fusable && work8_l + work8_r >= LANE_WORK_MIN));
         if (!lane) {
-            group = genv != 0 && group_ok && work_g >= GROUP_WORK_MIN;
+            group = genv != 0 && group_ok && work_g >= (wide ? GROUP_WORK_MIN_WIDE : GROUP_WORK_MIN);
             if (!group) { bp.lane_on = 0; return false; }
         }
     }
@@ -177,12 +177,23 @@ BSW_LOCAL void plan_fused(batch_plan &pl, const bsw_binparams &bp, int fused_cls
 /* See bsw_device.h (bsw_binparams.nsplit).  For chunks that do not fill the machine; BSW_NSPLIT = 0 / 1: never / every chunk with
  * 8-bit lane seeds (measurements, tests).  The host does not know which queries hold an N (it never reads a base): the lists keep
  * their counted sizes and the device leaves the places of the seeds it moved unfilled. */
-BSW_LOCAL bool nsplit_pays(int kern, const bsw_binparams &bp, bool packed_ok, uint32_t n8, bool streaming)
+static int nsplit_env()
 {
     static const int env = getenv("BSW_NSPLIT") ? atoi(getenv("BSW_NSPLIT")) : -1;
-    if (!bp.lane_on || !packed_ok || !n8 || env == 0) return false;
-    if (env == 1) return true;
+    return env;
+}
+BSW_LOCAL bool nsplit_candidate(int kern, const bsw_binparams &bp, bool packed_ok, uint32_t n8, bool streaming)
+{
+    if (!bp.lane_on || !packed_ok || !n8 || nsplit_env() == 0) return false;
+    if (nsplit_env() == 1) return true;
     return kern == BSW_KERNEL_AUTO && !streaming && n8 <= NSPLIT_MAX;
+}
+BSW_LOCAL bool nsplit_pays(int kern, const bsw_binparams &bp, bool packed_ok, uint32_t n8, bool streaming, double n_bases)
+{
+    if (!nsplit_candidate(kern, bp, packed_ok, n8, streaming)) return false;
+    if (nsplit_env() == 1) return true;
+    if (n_bases < 0) return n8 <= NSPLIT_MAX_BLIND;
+    return n_bases <= (double)NLIST_WORK_MAX;
 }
 
 BSW_LOCAL void plan_nsplit(batch_plan &pl, bsw_binparams &bp, bool nsplit, uint32_t n_lane)
@@ -438,7 +449,44 @@ static int prepare_chunk_t(errs &e, const bsw_params *p, int kern, Src &&src, si
     pl.order_len = cur + n_lane;
     pl.redo_cls = bsw_wave_class_of(&bp, std::max(bp.cols8, bp.cols16) - 1);
     plan_fused(pl, bp, fused_cls, group, cl);
-    plan_nsplit(pl, bp, nsplit_pays(kern, bp, packed_ok, group ? n_lane : n_lane - n16, ci.streaming), n_lane);
+    {
+        /* the share of seeds with an N in a query: the pass never reads a base, a SAMPLE of the chunk's seeds does (both queries of
+         * up to 512 seeds, evenly spaced; ~0.1 ms) — only for chunks the split could pay for.  x the chunk's query bases = the work
+         * the general kernel would get */
+        const uint32_t n8 = group ? n_lane : n_lane - n16;
+        double nfrac = -1.0;
+        if (nsplit_candidate(kern, bp, packed_ok, n8, ci.streaming) && nsplit_env() != 1) {
+            const auto has_n = [&](const uint8_t *q, int len, bool backwards) -> bool {
+                if (!q || len <= 0) return false;
+                if (packed) {
+                    const uint64_t *w = (const uint64_t *)q;
+                    const int nw = (len + 15) >> 4;
+                    uint64_t acc = 0;
+                    for (int k = 0; k < nw; ++k) {
+                        uint64_t v = w[k];
+                        if (k == nw - 1 && (len & 15)) v &= (1ull << (4 * (len & 15))) - 1ull;
+                        acc |= v;
+                    }
+                    return (acc & 0x4444444444444444ull) != 0;
+                }
+                const uint8_t *b = backwards ? q - (len - 1) : q;
+                for (int k = 0; k < len; ++k) if (b[k] >= 4) return true;
+                return false;
+            };
+            const size_t S = std::min<size_t>(n, 512);
+            size_t hits = 0, seen = 0;
+            bsw_task tmp;
+            int rcl = 0;
+            for (size_t k = 0; k < S; ++k) {
+                const bsw_task *tp = src(k * n / S, tmp, rcl);
+                if (!tp) continue;
+                ++seen;
+                hits += (has_n(tp->lquery, tp->lqlen, rev_left) || has_n(tp->rquery, tp->rqlen, false)) ? 1 : 0;
+            }
+            nfrac = (seen ? (double)hits / (double)seen : 0.0) * (double)(work8_l + work8_r);      /* -> the list's query bases */
+        }
+        plan_nsplit(pl, bp, nsplit_pays(kern, bp, packed_ok, n8, ci.streaming, nfrac), n_lane);
+    }
     memcpy(pl.dep, dep, sizeof(pl.dep));
     memcpy(bp.wave_start, pl.wave_start, sizeof(bp.wave_start));
     bp.lane_all_off = pl.lane_all_off;

@@ -67,14 +67,18 @@ inline bool lane_bins_pay(uint32_t n_lane, const uint32_t *cl, const uint32_t *c
  *     16 k seeds 0.75 / 0.69 / 1.23 / 0.69    49 k 1.85 / 1.16 / 1.22 / 1.17    131 k 4.62 / 2.62 / 1.33 / 1.33    262 k 9.08 / 4.69 / 1.65 / 1.64 */
 #define GROUP_WORK_MIN 1500000ull
 #define LANE_WORK_MIN  5000000ull
+#define GROUP_WORK_MIN_WIDE 2200000ull   /* ... a chunk with sides beyond 136 columns (four stripes, two waves per SIMD: 250 bp reads cross at ~10.5 k seeds, 1.30 ms) */
 #define GROUP_FUSE_MAX 49152u        /* 8-bit lane seeds up to which a group chunk runs both sides in one launch (fuse_lists): 3 waves per SIMD */
 #define GROUP_FUSE_MAX_WIDE 98304u   /* ... when the chunk has sides beyond 136 columns (250 bp reads): the lane kernels then need four chained launches,
                                         5.7 - 6.0 ms, and the fused group launch stays ahead up to ~110 k seeds (65 k: 3.5 ms, 131 k: 6.4) */
 inline uint32_t group_fuse_max(bool wide) { return wide ? GROUP_FUSE_MAX_WIDE : GROUP_FUSE_MAX; }
 #define LANE_FUSE_MAX  262144u       /* ... and a lane-kernel chunk (bsw_lane2_kernel<17, 2, ., ., true>): 2 waves per SIMD */
-#define NSPLIT_MAX     131072u       /* lane seeds up to which a chunk's queries with an N go to the general kernel (bsw_binparams.nsplit):
-                                        262 144 PE seeds with an N in one query of nine — bench.py's generator, ten times a sequencer's
-                                        rate — would put 58 k seeds on one wavefront each (3.5 ms where the lane kernels alone take 2.3) */
+#define NSPLIT_MAX     262144u       /* lane seeds up to which a chunk's queries with an N go to the general kernel (bsw_binparams.nsplit) ... */
+#define NLIST_WORK_MAX 1800000ull    /* ... as long as a sample of the chunk says the list stays below this many QUERY BASES (the general kernel
+                                        takes ~0.4 ms per million beside a lane launch of 1.0 - 1.7 ms): measured on / off with bench.py's N rate,
+                                        ten times a sequencer's — 131 k PE seeds (1.6 M bases on the list) 1.57 / 2.29 ms, 262 k (3.2 M) 2.86 / 2.48,
+                                        131 k one-bin seeds (2.1 M) 1.77 / 1.55, 65 k (1.0 M) 1.04 / 1.54; a sequencer's rate: 262 k PE seeds 1.73 / 2.63 */
+#define NSPLIT_MAX_BLIND 131072u     /* ... and without a sample (the wire format's nibble streams) */
 #define RAW_SLACK 64                 /* bytes the pack kernel may read past the last sequence */
 #define RAW_FRONT 32                 /* ... and in front of the first one (reversed left queries) */
 
@@ -358,7 +362,8 @@ BSW_LOCAL int fuse_lists(bsw_binparams &bp, int kern, bool group, bool packed_ok
 BSW_LOCAL void plan_fused(batch_plan &pl, const bsw_binparams &bp, int fused_cls, bool group, const uint32_t *cl);
 /* bsw_binparams.nsplit for a chunk (policy), and the N list's place behind the redo list once pl.redo_off / pl.order_len are set
  * (order_len grows by the list; call before bp's offsets are copied from the plan) */
-BSW_LOCAL bool nsplit_pays(int kern, const bsw_binparams &bp, bool packed_ok, uint32_t n8, bool streaming);
+BSW_LOCAL bool nsplit_pays(int kern, const bsw_binparams &bp, bool packed_ok, uint32_t n8, bool streaming, double n_bases = -1.0 /* query bases of the seeds with an N in a query, estimated from a sample; < 0: unknown */);
+BSW_LOCAL bool nsplit_candidate(int kern, const bsw_binparams &bp, bool packed_ok, uint32_t n8, bool streaming);       /* worth taking the sample */
 BSW_LOCAL void plan_nsplit(batch_plan &pl, bsw_binparams &bp, bool nsplit, uint32_t n_lane);
 BSW_LOCAL bool decide_lane_mode(int kern, bool group_ok, bsw_binparams &bp, uint32_t &n_lane, uint32_t n16, uint32_t *cl, uint32_t *cr,
                                 uint32_t *cw, const uint32_t *cw16, uint8_t *dep, uint64_t work8_l, uint64_t work8_r, bool streaming = false);

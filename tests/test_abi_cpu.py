@@ -363,3 +363,23 @@ def test_auto_policy_fuses_the_two_sides_of_mid_sized_chunks(host):
     l, le, re_ = lists(host.plan_batch(p, t3, kernel=host.KERNEL_AUTO)[1])
     assert l == 300000 - int(((t3["lqlen"] == 0) & (t3["rqlen"] == 0)).sum())
     assert le == int((t3["lqlen"] > 0).sum()) and re_ == int((t3["rqlen"] > 0).sum())                    # throughput-bound: a list per side
+
+
+def test_n_split_follows_a_sample_of_the_chunk(host):
+    """bsw_binparams.nsplit moves the lane seeds with an N in a query to the general kernel — one wavefront per seed — so it must
+    not fire on a chunk of low-quality reads: the host pass samples the queries of 512 seeds and splits only while the N list
+    would stay below NLIST_WORK_MAX (1.8 M query bases), for chunks of up to NSPLIT_MAX (262 144) lane seeds (plan only: no GPU)."""
+    p = host.default_params()
+    NONE = 0xffffffff
+    spec = dict(seed_len_min=19, seed_len_max=60, seed_at_start=0, junk_frac=0.05)
+
+    def holes(tasks):
+        order, seg, _ = host.plan_batch(p, tasks, kernel=host.KERNEL_AUTO)
+        return int((order[seg[9]:seg[25]] == NONE).sum())
+    few, a1 = host.synth_tasks(200_000, seed=31, n_rate=0.0001, **spec)          # a sequencer's rate: ~2.6 % of the seeds, 5 k of 200 k
+    assert 2_000 < holes(few) < 12_000
+    many, a2 = host.synth_tasks(200_000, seed=32, n_rate=0.003, **spec)          # ~28 % of the seeds: 55 k would go one per wavefront
+    assert holes(many) == 0
+    assert holes(many[:40_000]) > 8_000                                          # ... 11 k of 40 k (1.2 M bases) still pay
+    big, a3 = host.synth_tasks(270_000, seed=33, n_rate=0.0001, **spec)          # past NSPLIT_MAX: a list per side, no split
+    assert holes(big) == 0

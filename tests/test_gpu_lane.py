@@ -374,7 +374,8 @@ def test_group_kernel_runs_both_sides_of_a_seed_in_one_launch(host, oracle, read
     and pair records; 250 bp reads take the four-stripe instantiation.  Past GROUP_FUSE_MAX seeds (the third case) the LANE kernels
     do the same up to LANE_FUSE_MAX (bsw_lane2_kernel's fused instantiation); there the 16-bit seeds keep their own lane class with a
     list per side."""
-    spec = dict(read_len=read_len, seed_len_min=19, seed_len_max=60, seed_at_start=0, sub_rate=0.02, indel_rate=0.01, junk_frac=0.1, n_rate=0.002)
+    spec = dict(read_len=read_len, seed_len_min=19, seed_len_max=60, seed_at_start=0, sub_rate=0.02, indel_rate=0.01, junk_frac=0.1,
+                n_rate=0.002 if n < 50_000 else 0.0005)         # (the N list is capped by its work — NLIST_WORK_MAX: a sample of the chunk decides)
     if read_len == 250:
         spec.update(w=500, seed_len_max=20)                               # (h0 + 231 + b <= 255: longer seeds of 250 bp reads are 16-bit seeds)
     ta, a1 = host.synth_tasks(n, seed=91, **spec)
@@ -422,7 +423,7 @@ def test_queries_with_an_n_leave_the_lane_lists_of_a_chunk_that_does_not_fill_th
     hold Ns runs 1.6 - 2x as long as the others.  The 8-bit lane seeds with an N in a query go on a list of their own for the
     general kernel (beside the lane launches); the lane lists keep their counted sizes, unused tails marked.  One-sided seeds
     (nothing to fuse): 20 000 run the group kernel, 60 000 the lane kernels.  Bytes, packed and pair-record paths."""
-    tasks, arena = host.synth_tasks(n, seed=23, sub_rate=0.02, indel_rate=0.005, junk_frac=0.05, n_rate=0.003)
+    tasks, arena = host.synth_tasks(n, seed=23, sub_rate=0.02, indel_rate=0.005, junk_frac=0.05, n_rate=0.003 if n < 50_000 else 0.001)     # (the list's work is capped: NLIST_WORK_MAX)
     p = host.default_params()
     order, seg, _ = host.plan_batch(p, tasks, kernel=host.KERNEL_AUTO)
     right = order[seg[17]:seg[25]]
