@@ -375,7 +375,7 @@ def test_group_kernel_runs_both_sides_of_a_seed_in_one_launch(host, oracle, read
     do the same up to LANE_FUSE_MAX (bsw_lane2_kernel's fused instantiation); there the 16-bit seeds keep their own lane class with a
     list per side."""
     spec = dict(read_len=read_len, seed_len_min=19, seed_len_max=60, seed_at_start=0, sub_rate=0.02, indel_rate=0.01, junk_frac=0.1,
-                n_rate=0.002 if n < 50_000 else 0.0005)         # (the N list is capped by its work — NLIST_WORK_MAX: a sample of the chunk decides)
+                n_rate=0.0005 if n > 50_000 else 0.001 if read_len > 200 else 0.002)      # (the N list is capped by its work — NLIST_WORK_MAX, 1.8 M query bases: a sample of the chunk decides; these stay well below)
     if read_len == 250:
         spec.update(w=500, seed_len_max=20)                               # (h0 + 231 + b <= 255: longer seeds of 250 bp reads are 16-bit seeds)
     ta, a1 = host.synth_tasks(n, seed=91, **spec)
