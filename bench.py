@@ -118,6 +118,29 @@ def side_paths(host, device):
             assert (got["tag"] == wt["tag"][ends[bi] - n_b:ends[bi]]).all(), "wire format: result batch %d does not carry its tasks' tags" % bi
         oarena.free()
         warena.free()
+        # batches that do not fill the machine (what a host that hands over a few thousand to a few hundred thousand seeds at a time gets;
+        # the wire format's own operating point): resident PE mixed-bin batches through BSW_KERNEL_AUTO, median of 8 runs each, reads with
+        # the headline workload's N rate.  A launch lasts as long as its slowest wavefront there: both sides of a seed run in ONE launch,
+        # queries with an N go to the general kernel beside it
+        mid = {}
+        mspec = dict(WORKLOADS["150bp_w100_mixed_bins"])
+        mt, marena = host.synth_tasks(262144, seed=77, **mspec)
+        pm = host.default_params(w=mspec["w"])
+        for nmid in (4096, 16384, 32768, 65536, 131072, 262144):
+            b = c.upload(pm, mt[:nmid])
+            for _ in range(2):
+                c.run(b)
+            c.sync(); c.run_history()
+            for _ in range(8):
+                c.run(b)
+            c.sync()
+            ms = float(np.median(c.run_history()))
+            r = c.download(b)
+            nl = int(b.info()["launches"])
+            b.free()
+            mid[str(nmid)] = {"ms": round(ms, 4), "gcups": round(cells_of(r) / ms / 1e6, 1), "kernel_launches": nl}
+        res["mid_sized_batches"] = {"workload": "150bp_w100_mixed_bins, resident, BSW_KERNEL_AUTO, DP kernels of one batch (bsw_run)", "by_seeds": mid}
+        del marena
     arena.free()
     return res
 
