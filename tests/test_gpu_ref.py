@@ -134,3 +134,28 @@ def test_synthetic_genome_reads_through_the_streaming_path(host, oracle):
             ctx.ref_free(ref)
     finally:
         arena.free()
+
+
+@pytest.mark.parametrize("n", [30_000, 70_000])
+def test_one_chunk_against_the_resident_reference_takes_the_mid_sized_paths(host, oracle, n):
+    """bsw_submit_ref as ONE chunk under BSW_KERNEL_AUTO: the chunk does not fill the machine, so both sides of a seed run in one
+    launch (group kernel at 30 000 seeds, lane kernel at 70 000) and the seeds with an N in a query go to the general kernel —
+    decided from a sample of the reads, whose left queries sit FORWARDS in the caller's memory in this mode (the host pass reads
+    them backwards from the seed).  Same results as the oracle on the host-extracted tasks."""
+    p = host.default_params()
+    lp, L = 400_000, 150
+    arena = host.HostArena(n * L + 64)
+    try:
+        pac, rt, _ = host.synth_ref_tasks(n, lp, p, arena=arena.u8, seed=17, read_len=L, seed_len_min=19, seed_len_max=60,
+                                          seed_at_start=0, sub_rate=0.02, indel_rate=0.004, n_rate=0.001, junk_frac=0.05)
+        reads = [arena.u8[i * L:(i + 1) * L] for i in range(n)]
+        tasks, keep = host.seeds_to_tasks(p, pac, lp, reads, rt["seed"].copy())
+        want = oracle.pair_batch(p, tasks, nthreads=8)
+        with host.BswContext(device=0, chunk_tasks=n, streams=2) as ctx:
+            ref = ctx.ref_upload(pac, lp)
+            got = ctx.submit_ref(p, ref, rt)
+            ctx.wait()
+            assert_same(got, want, tasks)
+            ctx.ref_free(ref)
+    finally:
+        arena.free()
