@@ -443,3 +443,29 @@ def test_queries_with_an_n_leave_the_lane_lists_of_a_chunk_that_does_not_fill_th
         gp = c.extend_pairs(p, tasks)
         for f in ("tag", "qb", "qe", "rb", "re", "score", "truesc", "w"):
             assert (gp[f] == want[f]).all(), f
+
+
+def test_launch_chain_runs_beside_the_n_list(host, oracle):
+    """131 072 seeds of 250 bp reads under BSW_KERNEL_AUTO: past the group kernel's fused range, so the lane kernels run their four
+    chained launches (136- and 232-column classes, left and right) — and beside them the general kernel runs the seeds with an N
+    in a query from their own list (bsw_binparams.nsplit), on the second borrowed stream.  Resident batch and one-chunk submit."""
+    n = 131_072
+    tasks, arena = host.synth_tasks(n, seed=61, read_len=250, seed_len_min=19, seed_len_max=40, seed_at_start=0,
+                                    sub_rate=0.04, indel_rate=0.01, junk_frac=0.05, n_rate=0.0001, w=500)
+    p = host.default_params(w=500)
+    order, seg, _ = host.plan_batch(p, tasks, kernel=host.KERNEL_AUTO)
+    lists = order[seg[9]:seg[25]]
+    nn = int((lists == 0xffffffff).sum())
+    assert int(seg[25] - seg[17]) > 0 and 0 < nn < n // 10              # a list per side (not fused), some seeds moved to the N list
+    want = oracle.pair_batch_avx2(p, tasks, nthreads=8)
+    with host.BswContext(device=0) as c:
+        b = c.upload(p, tasks); c.run(b); got = c.download(b)
+        assert b.info()["launches"] >= 6                                  # the N list, four lane launches, the redo launch
+        for _ in range(3):
+            c.run(b)
+        again = c.download(b)
+        b.free()
+        assert_same(got, want, tasks)
+        assert again.tobytes() == got.tobytes()
+        assert c.chain_timeouts() == 0
+        assert_same(c.extend_pairs(p, tasks), want, tasks)
